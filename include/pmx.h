@@ -1,0 +1,138 @@
+/*
+ * pmx.h - C ABI of the MI355X screening engine (libpmx.so, built from pharmaconet_amd/csrc).
+ *
+ * The reference (SeonghwanSeo/PharmacoNet, /root/reference) has no FFI for this path; its seams are
+ * Python-level. Each entry point below names the reference interface it stands in for (paths are
+ * relative to /root/reference). The Python shim that binds these symbols is
+ * pharmaconet_amd/_ffi.py; the stub a reference maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions: every function returns 0 on success and a non-zero pmx_status otherwise;
+ * pmx_last_error() gives the calling thread's last message. No exceptions cross the boundary.
+ * Handles are opaque; a handle is bound to the device it was created on. Calls on one handle are
+ * not re-entrant; distinct handles / streams are independent. `stream` is a hipStream_t passed as
+ * void* (NULL = the default stream). Pointers named *_dev are device pointers on that device.
+ */
+#ifndef PMX_H
+#define PMX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PMX_NUM_TYPES 7          /* Hydrophobic, Aromatic, Cation, Anion, HBond_donor, HBond_acceptor, Halogen */
+#define PMX_MAX_LEVELS 20        /* src/pmnet/scoring/graph_match.py:88 */
+#define PMX_MAX_MODEL_NODES 64
+#define PMX_MAX_MODEL_CLUSTERS 64
+#define PMX_MAX_LIGAND_NODES 64
+#define PMX_MAX_LIGAND_CLUSTERS 64
+#define PMX_MAX_CONFORMERS 64
+
+typedef enum {
+    PMX_OK = 0,
+    PMX_ERR_INVALID = 1, /* bad argument / model or library outside the structural limits above */
+    PMX_ERR_HIP = 2,     /* a HIP runtime call failed */
+    PMX_ERR_OOM = 3
+} pmx_status;
+
+/* Per-ligand status written by pmx_score. */
+#define PMX_LIGAND_OK 0
+#define PMX_LIGAND_UNSUPPORTED 1 /* record exceeds a structural limit; score is NaN */
+
+typedef struct pmx_model pmx_model;
+typedef struct pmx_library pmx_library;
+
+/*
+ * Flat pharmacophore model: the object graph built by PharmacophoreModel.__setstate__
+ * (src/pmnet/pharmacophore_model.py:191-204) made positional. edge_mean / edge_std are the
+ * float32 values of `model_node1.neighbor_edge_dict[model_node2].distance_mean / .distance_std`
+ * (src/pmnet/scoring/match_utils.py:35-48) for every ordered node pair, self-loops included.
+ * Clusters are listed in `model.node_clusters` order (pharmacophore_model.py:202-204);
+ * cluster_typemask is the stored `node_types` set, cluster_center / cluster_size feed the
+ * cluster-distance prefilter (src/pmnet/scoring/graph_match.py:263-268).
+ * All pointers are host pointers; the data is copied.
+ */
+typedef struct {
+    int32_t n_nodes;
+    int32_t n_clusters;
+    const uint8_t *node_type;        /* [n_nodes] type id 0..6 */
+    const float *edge_mean;          /* [n_nodes * n_nodes] */
+    const float *edge_std;           /* [n_nodes * n_nodes] */
+    const uint64_t *cluster_nodes;   /* [n_clusters] bit m = node m belongs to the cluster */
+    const uint8_t *cluster_typemask; /* [n_clusters] */
+    const double *cluster_center;    /* [n_clusters * 3] */
+    const double *cluster_size;      /* [n_clusters] */
+} pmx_model_desc;
+
+/*
+ * Packed ligand library (format: pharmaconet_amd/library.py): what GraphMatcher reads from each
+ * ligand's LigandGraph (src/pmnet/scoring/ligand.py:110-259) - typed nodes, per-conformer node
+ * positions, clusters in priority_fn order (graph_match.py:43-60). Replaces the per-file
+ * `Ligand.load_from_file` objects that screening.py:46-47 hands to scoring_file one at a time.
+ */
+typedef struct {
+    uint64_t n_ligands;
+    const uint64_t *offsets; /* [n_ligands + 1] byte offsets into data, each a multiple of 16 */
+    const uint8_t *data;
+    int32_t on_device;       /* 0: host pointers (copied to the device); 1: device pointers (copied device-to-device) */
+} pmx_library_view;
+
+typedef struct {
+    uint64_t n_ligands;
+    uint64_t n_bytes;
+    uint64_t total_conformers;
+    int32_t max_nodes, max_conformers, max_clusters;
+    int32_t n_unsupported;
+} pmx_library_info;
+
+const char *pmx_last_error(void);
+int pmx_version(void);
+
+/* PharmacophoreModel.load (pharmacophore_model.py:163-176) -> device-resident tables. */
+int pmx_model_create(const pmx_model_desc *desc, int device, pmx_model **out);
+int pmx_model_destroy(pmx_model *model);
+
+int pmx_library_upload(const pmx_library_view *view, int device, pmx_library **out);
+int pmx_library_info_get(const pmx_library *lib, pmx_library_info *info);
+int pmx_library_destroy(pmx_library *lib);
+
+/*
+ * Batched PharmacophoreModel._scoring (pharmacophore_model.py:101-106), i.e.
+ * GraphMatcher(model, ligand, weights).run() (graph_match.py:94-101) for ligands
+ * [first, first + count). weights[7] = DEFAULT_WEIGHTS updated by the caller's dict
+ * (graph_match.py:32-40,81-83) in type-id order. scores_dev[count] receives the float32 value
+ * of the float the reference returns (0 for ligands without clusters or candidates,
+ * graph_match.py:95-99); status_dev[count] (may be NULL) receives PMX_LIGAND_*.
+ * Asynchronous on `stream` except for one small device-to-host read per chunk.
+ */
+int pmx_score(const pmx_model *model, const pmx_library *lib, const float weights[PMX_NUM_TYPES], uint64_t first,
+              uint64_t count, float *scores_dev, int32_t *status_dev, void *stream);
+
+/* The same for several models over one library (one pocket after the other; scores_dev is [n_models][count]). */
+int pmx_score_multi(const pmx_model *const *models, int n_models, const pmx_library *lib,
+                    const float weights[PMX_NUM_TYPES], uint64_t first, uint64_t count, float *scores_dev,
+                    int32_t *status_dev, void *stream);
+
+/*
+ * The ranking step of screening.py:70 (`result.sort(key=score, reverse=True)`, stable): the k best
+ * of scores_dev[n] in descending score order, ties in ascending index order. index_dev may be
+ * NULL (element i has index base_index + i) or give each element's global index.
+ * out_scores_dev[k], out_index_dev[k]; if n < k the tail is filled with -inf / UINT64_MAX.
+ */
+int pmx_topk(const float *scores_dev, const uint64_t *index_dev, uint64_t n, uint64_t base_index, int k,
+             float *out_scores_dev, uint64_t *out_index_dev, int device, void *stream);
+
+/* Timing / diagnostics of the last pmx_score on this thread: kernel-time split measured with HIP events. */
+typedef struct {
+    double ms_sizes, ms_tables, ms_tree, ms_total;
+    uint64_t table_bytes;   /* bytes of intermediate pair-score tables written for the call */
+    uint64_t n_chunks;
+} pmx_score_stats;
+int pmx_score_stats_get(pmx_score_stats *out);
+int pmx_set_profiling(int enabled); /* when enabled pmx_score records HIP events around each kernel (adds syncs) */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PMX_H */

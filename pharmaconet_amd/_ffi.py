@@ -1,0 +1,120 @@
+"""ctypes binding of libpmx.so (include/pmx.h). The product path fails loudly when the HIP
+library is missing or cannot be loaded: there is no CPU fallback in this package."""
+
+from __future__ import annotations
+
+import ctypes
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+LIB_PATH = PKG / "libpmx.so"
+
+NUM_TYPES = 7
+
+
+class PmxError(RuntimeError):
+    pass
+
+
+class ModelDesc(ctypes.Structure):
+    _fields_ = [
+        ("n_nodes", ctypes.c_int32),
+        ("n_clusters", ctypes.c_int32),
+        ("node_type", ctypes.c_void_p),
+        ("edge_mean", ctypes.c_void_p),
+        ("edge_std", ctypes.c_void_p),
+        ("cluster_nodes", ctypes.c_void_p),
+        ("cluster_typemask", ctypes.c_void_p),
+        ("cluster_center", ctypes.c_void_p),
+        ("cluster_size", ctypes.c_void_p),
+    ]
+
+
+class LibraryView(ctypes.Structure):
+    _fields_ = [
+        ("n_ligands", ctypes.c_uint64),
+        ("offsets", ctypes.c_void_p),
+        ("data", ctypes.c_void_p),
+        ("on_device", ctypes.c_int32),
+    ]
+
+
+class LibraryInfo(ctypes.Structure):
+    _fields_ = [
+        ("n_ligands", ctypes.c_uint64),
+        ("n_bytes", ctypes.c_uint64),
+        ("total_conformers", ctypes.c_uint64),
+        ("max_nodes", ctypes.c_int32),
+        ("max_conformers", ctypes.c_int32),
+        ("max_clusters", ctypes.c_int32),
+        ("n_unsupported", ctypes.c_int32),
+    ]
+
+
+class ScoreStats(ctypes.Structure):
+    _fields_ = [
+        ("ms_sizes", ctypes.c_double),
+        ("ms_tables", ctypes.c_double),
+        ("ms_tree", ctypes.c_double),
+        ("ms_total", ctypes.c_double),
+        ("table_bytes", ctypes.c_uint64),
+        ("n_chunks", ctypes.c_uint64),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/pmx.h declares
+SIGNATURES = {
+    "pmx_last_error": (ctypes.c_char_p, []),
+    "pmx_version": (ctypes.c_int, []),
+    "pmx_model_create": (ctypes.c_int, [ctypes.POINTER(ModelDesc), ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
+    "pmx_model_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "pmx_library_upload": (ctypes.c_int, [ctypes.POINTER(LibraryView), ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
+    "pmx_library_info_get": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(LibraryInfo)]),
+    "pmx_library_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "pmx_score": (
+        ctypes.c_int,
+        [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float), ctypes.c_uint64, ctypes.c_uint64,
+         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p],
+    ),
+    "pmx_score_multi": (
+        ctypes.c_int,
+        [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float),
+         ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p],
+    ),
+    "pmx_topk": (
+        ctypes.c_int,
+        [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, ctypes.c_void_p,
+         ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p],
+    ),
+    "pmx_score_stats_get": (ctypes.c_int, [ctypes.POINTER(ScoreStats)]),
+    "pmx_set_profiling": (ctypes.c_int, [ctypes.c_int]),
+}
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load libpmx.so from the package directory (built by `python -m pharmaconet_amd.build`)."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise PmxError(
+                f"{LIB_PATH} is missing: build the HIP extension with `python -m pharmaconet_amd.build` "
+                "(hipcc, gfx950). There is no CPU scoring path."
+            )
+        try:
+            lib = ctypes.CDLL(str(LIB_PATH))
+        except OSError as e:  # e.g. libamdhip64 not found
+            raise PmxError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = lib
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        msg = load().pmx_last_error()
+        raise PmxError(f"libpmx error {rc}: {msg.decode() if msg else '?'}")

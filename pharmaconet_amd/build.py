@@ -1,0 +1,67 @@
+"""Builds pharmaconet_amd/libpmx.so (HIP, gfx950 only) in-tree with hipcc.
+
+`python -m pharmaconet_amd.build [--force]`. The .so is git-ignored but travels with the tree.
+"""
+
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+REPO = PKG.parent
+CSRC = PKG / "csrc"
+LIB = PKG / "libpmx.so"
+SOURCES = ("pmx_api.hip", "pmx_topk.hip")
+DEPS = ("pmx_kernels.hip", "pmx_device.h")
+FLAGS = (
+    "--offload-arch=gfx950",
+    "-O3",
+    "-std=c++17",
+    "-fPIC",
+    "-ffp-contract=off",  # distances and thresholds must round like the reference's float32 NumPy code
+    "-fno-fast-math",
+    "-Wall",
+    "-Wno-unused-function",
+)
+
+
+def hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and Path(cand).exists():
+            return cand
+    raise RuntimeError("hipcc not found")
+
+
+def _stale() -> bool:
+    if not LIB.exists():
+        return True
+    built = LIB.stat().st_mtime
+    inputs = [CSRC / s for s in SOURCES + DEPS] + [REPO / "include" / "pmx.h"]
+    return any(p.stat().st_mtime > built for p in inputs)
+
+
+def build_native(force: bool = False, verbose: bool = False) -> Path:
+    if not force and not _stale():
+        return LIB
+    cc = hipcc()
+    objs = []
+    for src in SOURCES:
+        obj = CSRC / (src.rsplit(".", 1)[0] + ".o")
+        cmd = [cc, *FLAGS, f"-I{REPO / 'include'}", f"-I{CSRC}", "-c", str(CSRC / src), "-o", str(obj)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+        objs.append(str(obj))
+    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", str(LIB)]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_native(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,409 @@
+// pmx_api.hip - host side of libpmx.so: the C ABI of include/pmx.h over the kernels of pmx_kernels.hip.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <vector>
+
+#include "pmx.h"
+#include "pmx_kernels.hip"
+
+using namespace pmx;
+
+// ------------------------------------------------------------------------------------- errors
+static thread_local char g_err[512] = "";
+static thread_local pmx_score_stats g_stats = {};
+static int g_profiling = 0;
+
+static int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIPCHECK(expr)                                                                                         \
+    do {                                                                                                       \
+        hipError_t e_ = (expr);                                                                                \
+        if (e_ != hipSuccess)                                                                                  \
+            return fail(e_ == hipErrorOutOfMemory ? PMX_ERR_OOM : PMX_ERR_HIP, "%s failed: %s (%s:%d)", #expr, \
+                        hipGetErrorString(e_), __FILE__, __LINE__);                                            \
+    } while (0)
+
+extern "C" const char *pmx_last_error(void) { return g_err; }
+extern "C" int pmx_version(void) { return 100; }
+extern "C" int pmx_set_profiling(int enabled) {
+    g_profiling = enabled;
+    return PMX_OK;
+}
+extern "C" int pmx_score_stats_get(pmx_score_stats *out) {
+    if (!out) return fail(PMX_ERR_INVALID, "null stats");
+    *out = g_stats;
+    return PMX_OK;
+}
+
+// -------------------------------------------------------------------------------------- model
+struct pmx_model {
+    int device;
+    DevModel dm;
+    void *blob;
+};
+
+// Largest float T with fl(T / std) < 2 under round-to-nearest-even float32 division: the quotient
+// rounds below 2 exactly when T / std < 2 - 2^-24, and std * (2 - 2^-24) is exact in double.
+static float pass_threshold(float std) {
+    const double bound = (double)std * (2.0 - std::ldexp(1.0, -24));
+    float t = (float)bound;
+    if ((double)t >= bound) t = std::nextafterf(t, -INFINITY);
+    return t;
+}
+
+extern "C" int pmx_model_create(const pmx_model_desc *d, int device, pmx_model **out) {
+    if (!d || !out) return fail(PMX_ERR_INVALID, "null argument");
+    const int Nm = d->n_nodes, K = d->n_clusters;
+    if (Nm < 0 || Nm > PMX_MAX_MODEL_NODES) return fail(PMX_ERR_INVALID, "model has %d nodes (max %d)", Nm, PMX_MAX_MODEL_NODES);
+    if (K < 0 || K > PMX_MAX_MODEL_CLUSTERS) return fail(PMX_ERR_INVALID, "model has %d clusters (max %d)", K, PMX_MAX_MODEL_CLUSTERS);
+    for (int i = 0; i < Nm; ++i)
+        if (d->node_type[i] >= PMX_NUM_TYPES) return fail(PMX_ERR_INVALID, "node %d has type id %d", i, d->node_type[i]);
+    HIPCHECK(hipSetDevice(device));
+
+    const size_t n_edge = (size_t)Nm * Nm, n_pair = (size_t)K * K;
+    const size_t off_edge = 0;
+    const size_t off_type = off_edge + round16(n_edge * sizeof(float4));
+    const size_t off_cnodes = off_type + 64;
+    const size_t off_tnodes = off_cnodes + 64 * 8;
+    const size_t off_tclus = off_tnodes + 128 * 8;
+    const size_t off_cpair = off_tclus + 128 * 8;
+    const size_t total = off_cpair + round16(n_pair * sizeof(float2)) + 16;
+    std::vector<unsigned char> host(total, 0);
+    float4 *edge = reinterpret_cast<float4 *>(host.data() + off_edge);
+    uint8_t *ntype = host.data() + off_type;
+    uint64_t *cnodes = reinterpret_cast<uint64_t *>(host.data() + off_cnodes);
+    uint64_t *tnodes = reinterpret_cast<uint64_t *>(host.data() + off_tnodes);
+    uint64_t *tclus = reinterpret_cast<uint64_t *>(host.data() + off_tclus);
+    float2 *cpair = reinterpret_cast<float2 *>(host.data() + off_cpair);
+
+    const double s_const = std::sqrt(0.5 * 1.4426950408889634074); // sqrt(0.5 * log2(e))
+    for (size_t i = 0; i < n_edge; ++i) {
+        const float mean = d->edge_mean[i], sd = d->edge_std[i];
+        if (!(sd > 0.f)) return fail(PMX_ERR_INVALID, "edge %zu has distance_std %g", i, (double)sd);
+        edge[i] = make_float4(mean, (float)(s_const / (double)sd), pass_threshold(sd), sd);
+    }
+    uint64_t type_nodes[PMX_NUM_TYPES] = {0};
+    for (int m = 0; m < Nm; ++m) {
+        ntype[m] = d->node_type[m];
+        type_nodes[d->node_type[m]] |= 1ull << m;
+    }
+    for (int a = 0; a < K; ++a) cnodes[a] = d->cluster_nodes[a];
+    for (int mask = 0; mask < 128; ++mask) {
+        uint64_t nodes = 0, clus = 0;
+        for (int t = 0; t < PMX_NUM_TYPES; ++t)
+            if (mask >> t & 1) nodes |= type_nodes[t];
+        for (int a = 0; a < K; ++a)
+            if (d->cluster_typemask[a] & mask) clus |= 1ull << a;
+        tnodes[mask] = nodes;
+        tclus[mask] = clus;
+    }
+    for (int a = 0; a < K; ++a)
+        for (int b = 0; b < K; ++b) {
+            const double *ca = d->cluster_center + 3 * a, *cb = d->cluster_center + 3 * b;
+            const double dist = std::sqrt((ca[0] - cb[0]) * (ca[0] - cb[0]) + (ca[1] - cb[1]) * (ca[1] - cb[1]) +
+                                          (ca[2] - cb[2]) * (ca[2] - cb[2])); // graph_match.py:263-264
+            cpair[a * K + b] = make_float2((float)dist, (float)(d->cluster_size[a] + d->cluster_size[b])); // :265
+        }
+
+    void *blob = nullptr;
+    HIPCHECK(hipMalloc(&blob, total));
+    hipError_t e = hipMemcpy(blob, host.data(), total, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(blob);
+        return fail(PMX_ERR_HIP, "hipMemcpy failed: %s", hipGetErrorString(e));
+    }
+    pmx_model *m = new pmx_model();
+    m->device = device;
+    m->blob = blob;
+    unsigned char *b8 = static_cast<unsigned char *>(blob);
+    m->dm.Nm = Nm;
+    m->dm.K = K;
+    m->dm.edge = reinterpret_cast<const float4 *>(b8 + off_edge);
+    m->dm.node_type = b8 + off_type;
+    m->dm.cnodes = reinterpret_cast<const uint64_t *>(b8 + off_cnodes);
+    m->dm.tnodes = reinterpret_cast<const uint64_t *>(b8 + off_tnodes);
+    m->dm.tclus = reinterpret_cast<const uint64_t *>(b8 + off_tclus);
+    m->dm.cpair = reinterpret_cast<const float2 *>(b8 + off_cpair);
+    *out = m;
+    return PMX_OK;
+}
+
+extern "C" int pmx_model_destroy(pmx_model *m) {
+    if (!m) return PMX_OK;
+    (void)hipSetDevice(m->device);
+    (void)hipFree(m->blob);
+    delete m;
+    return PMX_OK;
+}
+
+// ------------------------------------------------------------------------------------ library
+struct pmx_library {
+    int device;
+    DevLibrary dl;
+    uint64_t *offsets;
+    uint8_t *data;
+    pmx_library_info info;
+};
+
+extern "C" int pmx_library_upload(const pmx_library_view *v, int device, pmx_library **out) {
+    if (!v || !out) return fail(PMX_ERR_INVALID, "null argument");
+    if (!v->offsets) return fail(PMX_ERR_INVALID, "null offsets");
+    HIPCHECK(hipSetDevice(device));
+    const uint64_t n = v->n_ligands;
+    const hipMemcpyKind kind = v->on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    uint64_t nbytes = 0;
+    if (v->on_device) {
+        HIPCHECK(hipMemcpy(&nbytes, v->offsets + n, 8, hipMemcpyDeviceToHost));
+    } else {
+        nbytes = v->offsets[n];
+        for (uint64_t i = 0; i < n; ++i)
+            if (v->offsets[i] % 16 || v->offsets[i + 1] < v->offsets[i] + 8)
+                return fail(PMX_ERR_INVALID, "record %llu: bad offset", (unsigned long long)i);
+    }
+    pmx_library *lib = new pmx_library();
+    lib->device = device;
+    lib->offsets = nullptr;
+    lib->data = nullptr;
+    hipError_t e = hipMalloc((void **)&lib->offsets, (n + 1) * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&lib->data, std::max<uint64_t>(nbytes, 16));
+    if (e == hipSuccess) e = hipMemcpy(lib->offsets, v->offsets, (n + 1) * 8, kind);
+    if (e == hipSuccess && nbytes) e = hipMemcpy(lib->data, v->data, nbytes, kind);
+    unsigned long long *stats_dev = nullptr;
+    unsigned long long stats[5] = {0, 0, 0, 0, 0};
+    if (e == hipSuccess) e = hipMalloc((void **)&stats_dev, sizeof(stats));
+    if (e == hipSuccess) e = hipMemset(stats_dev, 0, sizeof(stats));
+    lib->dl.n = n;
+    lib->dl.offsets = lib->offsets;
+    lib->dl.data = lib->data;
+    if (e == hipSuccess && n) {
+        library_stats_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256)>>>(lib->dl, stats_dev);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(stats, stats_dev, sizeof(stats), hipMemcpyDeviceToHost);
+    if (stats_dev) (void)hipFree(stats_dev);
+    if (e != hipSuccess) {
+        if (lib->offsets) (void)hipFree(lib->offsets);
+        if (lib->data) (void)hipFree(lib->data);
+        delete lib;
+        return fail(e == hipErrorOutOfMemory ? PMX_ERR_OOM : PMX_ERR_HIP, "library upload failed: %s", hipGetErrorString(e));
+    }
+    lib->info.n_ligands = n;
+    lib->info.n_bytes = nbytes;
+    lib->info.total_conformers = stats[0];
+    lib->info.max_nodes = (int32_t)stats[1];
+    lib->info.max_conformers = (int32_t)stats[2];
+    lib->info.max_clusters = (int32_t)stats[3];
+    lib->info.n_unsupported = (int32_t)stats[4];
+    *out = lib;
+    return PMX_OK;
+}
+
+extern "C" int pmx_library_info_get(const pmx_library *lib, pmx_library_info *info) {
+    if (!lib || !info) return fail(PMX_ERR_INVALID, "null argument");
+    *info = lib->info;
+    return PMX_OK;
+}
+
+extern "C" int pmx_library_destroy(pmx_library *lib) {
+    if (!lib) return PMX_OK;
+    (void)hipSetDevice(lib->device);
+    (void)hipFree(lib->offsets);
+    (void)hipFree(lib->data);
+    delete lib;
+    return PMX_OK;
+}
+
+// ---------------------------------------------------------------------------------- workspace
+struct Workspace {
+    uint32_t chunk_cap = 0;
+    uint32_t *units = nullptr;
+    int32_t *status = nullptr;
+    uint64_t *taboff = nullptr;
+    uint8_t *arena = nullptr;
+    size_t arena_cap = 0;
+    uint32_t *meta = nullptr;      // device: [0] max levels, [1] ligand counter, [2..3] table bytes (u64)
+    uint32_t *meta_host = nullptr; // pinned mirror
+    int num_cu = 0;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+};
+static std::map<int, Workspace> g_ws;
+static std::mutex g_mu;
+
+static uint32_t chunk_size() {
+    static uint32_t v = [] {
+        const char *s = std::getenv("PMX_CHUNK");
+        long x = s ? std::atol(s) : 0;
+        return (uint32_t)(x > 0 ? std::min<long>(x, 1 << 22) : 65536);
+    }();
+    return v;
+}
+
+static int ensure_workspace(int device, Workspace **out) {
+    Workspace &w = g_ws[device];
+    const uint32_t cap = chunk_size();
+    if (w.chunk_cap < cap) {
+        if (w.units) (void)hipFree(w.units);
+        if (w.status) (void)hipFree(w.status);
+        if (w.taboff) (void)hipFree(w.taboff);
+        HIPCHECK(hipMalloc((void **)&w.units, (size_t)cap * 4));
+        HIPCHECK(hipMalloc((void **)&w.status, (size_t)cap * 4));
+        HIPCHECK(hipMalloc((void **)&w.taboff, ((size_t)cap + 1) * 8));
+        w.chunk_cap = cap;
+    }
+    if (!w.meta) {
+        HIPCHECK(hipMalloc((void **)&w.meta, 64));
+        HIPCHECK(hipHostMalloc((void **)&w.meta_host, 64));
+        hipDeviceProp_t prop;
+        HIPCHECK(hipGetDeviceProperties(&prop, device));
+        w.num_cu = prop.multiProcessorCount;
+        for (auto &ev : w.ev) HIPCHECK(hipEventCreate(&ev));
+    }
+    *out = &w;
+    return PMX_OK;
+}
+
+static constexpr size_t kLdsPerCu = 160 * 1024;
+
+template <int G>
+static int score_chunks(const pmx_model *model, const pmx_library *lib, const Weights &W, uint64_t first, uint64_t count,
+                        float *scores_dev, int32_t *status_dev, hipStream_t stream, Workspace &ws) {
+    constexpr int GPW = 64 / G;
+    const uint32_t cap = ws.chunk_cap;
+    static bool attr_set = false;
+    const int Nm = model->dm.Nm;
+    const int tab_waves = 4;
+    const size_t tab_lds = (size_t)Nm * Nm * sizeof(float4) + 64 * 8 + 128 * 8 + (size_t)tab_waves * GPW * sizeof(GroupLevels);
+    if (!attr_set) {
+        HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&tables_kernel<G>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));
+        HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&tree_kernel<G>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));
+        attr_set = true;
+    }
+    for (uint64_t done = 0; done < count; done += cap) {
+        const uint32_t n = (uint32_t)std::min<uint64_t>(cap, count - done);
+        const uint64_t lig0 = first + done;
+        int32_t *status = status_dev ? status_dev + done : ws.status;
+        float *scores = scores_dev + done;
+        HIPCHECK(hipMemsetAsync(ws.meta, 0, 64, stream));
+        if (g_profiling) HIPCHECK(hipEventRecord(ws.ev[0], stream));
+        sizes_kernel<G><<<dim3((n + 255) / 256), dim3(256), 0, stream>>>(lib->dl, model->dm.tclus, lig0, n, ws.units, status, ws.meta);
+        scan_kernel<<<dim3(1), dim3(1024), 0, stream>>>(ws.units, n, ws.taboff, reinterpret_cast<uint64_t *>(ws.meta + 2));
+        HIPCHECK(hipGetLastError());
+        HIPCHECK(hipMemcpyAsync(ws.meta_host, ws.meta, 64, hipMemcpyDeviceToHost, stream));
+        HIPCHECK(hipStreamSynchronize(stream));
+        const uint32_t max_levels = ws.meta_host[0];
+        uint64_t table_total;
+        std::memcpy(&table_total, ws.meta_host + 2, 8);
+        if (table_total > ws.arena_cap) {
+            if (ws.arena) (void)hipFree(ws.arena);
+            ws.arena = nullptr;
+            ws.arena_cap = 0;
+            const size_t want = (size_t)(table_total + table_total / 4 + (1u << 20));
+            HIPCHECK(hipMalloc((void **)&ws.arena, want));
+            ws.arena_cap = want;
+        }
+        if (g_profiling) HIPCHECK(hipEventRecord(ws.ev[1], stream));
+        if (table_total > 0) {
+            const uint32_t groups_per_block = tab_waves * GPW;
+            tables_kernel<G><<<dim3((n + groups_per_block - 1) / groups_per_block), dim3(64 * tab_waves), tab_lds, stream>>>(
+                model->dm, lib->dl, W, lig0, n, status, ws.taboff, ws.arena);
+            HIPCHECK(hipGetLastError());
+        }
+        if (g_profiling) HIPCHECK(hipEventRecord(ws.ev[2], stream));
+        {
+            const int depth = std::max<int>(1, (int)max_levels);
+            const size_t lds = (size_t)GPW * tree_group_bytes<G>(depth);
+            int waves_per_cu = (int)std::min<size_t>(16, kLdsPerCu / (lds + 256));
+            waves_per_cu = std::max(1, waves_per_cu);
+            const uint32_t want = (n + GPW - 1) / GPW;
+            const uint32_t grid = std::min<uint32_t>(want, (uint32_t)(ws.num_cu * waves_per_cu));
+            tree_kernel<G><<<dim3(grid), dim3(64), lds, stream>>>(ws.arena, ws.taboff, status, lib->dl, lig0, n, ws.meta + 1, depth, scores);
+            HIPCHECK(hipGetLastError());
+        }
+        if (g_profiling) {
+            HIPCHECK(hipEventRecord(ws.ev[3], stream));
+            HIPCHECK(hipEventSynchronize(ws.ev[3]));
+            float a = 0, b = 0, c = 0;
+            HIPCHECK(hipEventElapsedTime(&a, ws.ev[0], ws.ev[1]));
+            HIPCHECK(hipEventElapsedTime(&b, ws.ev[1], ws.ev[2]));
+            HIPCHECK(hipEventElapsedTime(&c, ws.ev[2], ws.ev[3]));
+            g_stats.ms_sizes += a;
+            g_stats.ms_tables += b;
+            g_stats.ms_tree += c;
+            g_stats.ms_total += a + b + c;
+        }
+        g_stats.table_bytes += table_total;
+        g_stats.n_chunks += 1;
+    }
+    return PMX_OK;
+}
+
+static int next_pow2(int x) {
+    int g = 1;
+    while (g < x) g <<= 1;
+    return g;
+}
+
+extern "C" int pmx_score(const pmx_model *model, const pmx_library *lib, const float weights[PMX_NUM_TYPES], uint64_t first,
+                         uint64_t count, float *scores_dev, int32_t *status_dev, void *stream_) {
+    if (!model || !lib || !weights || (!scores_dev && count)) return fail(PMX_ERR_INVALID, "null argument");
+    if (model->device != lib->device) return fail(PMX_ERR_INVALID, "model and library live on different devices");
+    if (first > lib->info.n_ligands || count > lib->info.n_ligands - first) return fail(PMX_ERR_INVALID, "ligand range out of bounds");
+    std::lock_guard<std::mutex> lock(g_mu);
+    g_stats = pmx_score_stats{};
+    if (count == 0) return PMX_OK;
+    HIPCHECK(hipSetDevice(model->device));
+    Workspace *ws = nullptr;
+    int rc = ensure_workspace(model->device, &ws);
+    if (rc) return rc;
+    Weights W;
+    for (int t = 0; t < PMX_NUM_TYPES; ++t) W.w[t] = weights[t];
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int G = next_pow2(std::max(1, std::min(lib->info.max_conformers, PMX_MAX_CONFORMERS)));
+    switch (G) {
+    case 1: return score_chunks<1>(model, lib, W, first, count, scores_dev, status_dev, stream, *ws);
+    case 2: return score_chunks<2>(model, lib, W, first, count, scores_dev, status_dev, stream, *ws);
+    case 4: return score_chunks<4>(model, lib, W, first, count, scores_dev, status_dev, stream, *ws);
+    case 8: return score_chunks<8>(model, lib, W, first, count, scores_dev, status_dev, stream, *ws);
+    case 16: return score_chunks<16>(model, lib, W, first, count, scores_dev, status_dev, stream, *ws);
+    case 32: return score_chunks<32>(model, lib, W, first, count, scores_dev, status_dev, stream, *ws);
+    default: return score_chunks<64>(model, lib, W, first, count, scores_dev, status_dev, stream, *ws);
+    }
+}
+
+extern "C" int pmx_score_multi(const pmx_model *const *models, int n_models, const pmx_library *lib,
+                               const float weights[PMX_NUM_TYPES], uint64_t first, uint64_t count, float *scores_dev,
+                               int32_t *status_dev, void *stream) {
+    if (!models || n_models < 0) return fail(PMX_ERR_INVALID, "null argument");
+    pmx_score_stats acc = {};
+    for (int i = 0; i < n_models; ++i) {
+        int rc = pmx_score(models[i], lib, weights, first, count, scores_dev + (size_t)i * count, i == 0 ? status_dev : nullptr, stream);
+        if (rc) return rc;
+        acc.ms_sizes += g_stats.ms_sizes;
+        acc.ms_tables += g_stats.ms_tables;
+        acc.ms_tree += g_stats.ms_tree;
+        acc.ms_total += g_stats.ms_total;
+        acc.table_bytes += g_stats.table_bytes;
+        acc.n_chunks += g_stats.n_chunks;
+    }
+    g_stats = acc;
+    return PMX_OK;
+}
+
+// error hook for pmx_topk.hip (keeps the thread-local message in one translation unit)
+int pmx_topk_fail(int code, const char *msg) { return fail(code, "%s", msg); }
