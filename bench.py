@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""Benchmark of the screening hot path: ligand-conformers scored per second for one pocket.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One *step* = one pass of the hot path (`PharmacophoreModel.screen`: sizes -> pair-score tables ->
+tree search -> scores, then top-k) over this rank's resident library. Workload at N = 1 is
+BASELINE.json configs[1]: the 6OIM-like pharmacophore model against 1M synthetic ligands
+(<= 32 pharmacophore points, 8 conformers each). For N > 1 every rank holds its own 1M-ligand shard of
+the synthetic library (weak scaling) and each step ends with the all-gather of per-rank top-k over RCCL.
+
+Rank 0 prints ONE JSON line. `value` is measured with the library already resident in HBM.
+`roofline.achieved` prices the dominant kernel (tree_kernel) at the ALGORITHMIC bytes of the path
+(packed ligand bytes + 8-byte offset in, 4-byte score + 4-byte status out, per ligand it processes)
+over its HIP-event duration; this path is not HBM-bound, the fraction is reported as asked.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+REPO = Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s HBM3E spec
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def build_library(model, n_ligands, n_conf, base_count, rank, device):
+    import torch
+
+    from pharmaconet_amd.constants import TYPE_ID
+    from pharmaconet_amd.engine import DeviceLibrary
+    from pharmaconet_amd.synthetic import BASE_SEED, expand_library_on_device, synthetic_library
+
+    st = model.__getstate__()
+    centers = np.array([n["center"] for n in st["nodes"]], dtype=np.float64)
+    types = np.array([TYPE_ID[n["type"]] for n in st["nodes"]])
+    t0 = time.time()
+    base_count = min(base_count, n_ligands)
+    base = synthetic_library(
+        base_count, first=rank * base_count, num_conformers=n_conf, model_nodes=(centers, types),
+        active_fraction=0.1, seed=BASE_SEED, max_nodes=32, conformer_noise=0.0,
+    )
+    replicas = (n_ligands + base_count - 1) // base_count
+    offsets, data = expand_library_on_device(base, replicas, device, seed=BASE_SEED + 1000 * rank)
+    n_total = replicas * base_count
+    lib = DeviceLibrary.from_device_buffers(offsets, data, device)
+    torch.cuda.synchronize()
+    log(f"[rank {rank}] library: {n_total} ligands ({base_count} topologies x {replicas}), "
+        f"{lib.num_bytes / 1e9:.2f} GB, max nodes {lib.max_nodes}, built in {time.time() - t0:.1f}s")
+    return lib, offsets, data
+
+
+def cpu_baseline(model, offsets, data, n_conf, budget_s=15.0):
+    """Time the CPU oracle (oracle/, a port of the reference's algorithm pinned to its outputs) on a
+    bounded sample of the same library with every host core."""
+    from oracle import oracle as orc
+    from pharmaconet_amd.constants import weights_vector
+    from pharmaconet_amd.library import PackedLibrary
+
+    cores = os.cpu_count() or 1
+
+    def sample(n):
+        off = offsets[: n + 1].cpu().numpy().astype(np.uint64)
+        return PackedLibrary(off, data[: int(off[-1])].cpu().numpy())
+
+    w = weights_vector(None)
+    probe = sample(min(2048, offsets.numel() - 1))
+    t0 = time.perf_counter()
+    orc.oracle_score(model.flat, probe, w, num_threads=cores)
+    dt = time.perf_counter() - t0
+    rate = len(probe) / max(dt, 1e-6)
+    n = int(min(offsets.numel() - 1, max(len(probe), rate * budget_s)))
+    lib = sample(n)
+    t0 = time.perf_counter()
+    orc.oracle_score(model.flat, lib, w, num_threads=cores)
+    dt = time.perf_counter() - t0
+    return {
+        "value": n * n_conf / dt,
+        "unit": "ligand-conformers/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"first {n} ligands of the same library, OpenMP over ligands, {dt:.1f}s",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--ligands", type=int, default=1_000_000, help="ligands per GPU")
+    ap.add_argument("--conformers", type=int, default=8)
+    ap.add_argument("--topologies", type=int, default=4096, help="distinct synthetic molecules per GPU")
+    ap.add_argument("--topk", type=int, default=1000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        log(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=device)
+
+    import __graft_entry__ as entry
+
+    entry.build()
+    from pharmaconet_amd import PharmacophoreModel
+    from pharmaconet_amd import engine
+    from pharmaconet_amd.distributed import allgather_topk, merge_topk
+
+    model = PharmacophoreModel.load(REPO / "tests" / "golden" / "model_6oim_like.pm")
+    lib, offsets, data = build_library(model, args.ligands, args.conformers, args.topologies, rank, device)
+    n_lig = len(lib)
+    n_conf_total = lib.total_conformers
+    index_base = rank * n_lig
+
+    def step():
+        res = engine.screen(model, lib, topk=args.topk, index_base=index_base)
+        if world > 1:
+            top = allgather_topk(res.topk_scores, res.topk_indices, args.topk)
+        else:
+            top = merge_topk(res.topk_scores.cpu().numpy(), res.topk_indices.cpu().numpy(), args.topk)
+        return res, top
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    engine.set_profiling(True)  # HIP events around each kernel launch of the timed steps
+    ms_tree = ms_tables = ms_sizes = 0.0
+    launches = 0
+    table_bytes = 0
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res, top = step()
+        st = engine.last_score_stats()
+        ms_tree += st["ms_tree"]
+        ms_tables += st["ms_tables"]
+        ms_sizes += st["ms_sizes"]
+        launches += st["n_chunks"]
+        table_bytes += st["table_bytes"]
+        log(f"[rank {rank}] step stats: {st}")
+    barrier()
+    elapsed = time.perf_counter() - t0
+    engine.set_profiling(False)
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = elapsed * 1e3 / max(args.steps, 1)
+        value = world * n_conf_total * args.steps / elapsed
+        # algorithmic bytes: records + 8 B offset in, 4 B score + 4 B status out, per ligand
+        alg_bytes_per_ligand = lib.num_bytes / n_lig + 8 + 4 + 4
+        ligands_per_launch = n_lig * args.steps / max(launches, 1)
+        tree_ms_per_launch = ms_tree / max(launches, 1)
+        achieved = (alg_bytes_per_ligand * ligands_per_launch) / (tree_ms_per_launch * 1e-3) / 1e9 if tree_ms_per_launch > 0 else 0.0
+        out = {
+            "metric": "ligand-conformers scored/sec (1 pocket)",
+            "value": value,
+            "unit": "ligand-conformers/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"6OIM-like model (37 nodes, 11 clusters) vs {n_lig} synthetic ligands per GPU "
+                            f"(<=32 pharmacophore points, {args.conformers} conformers each), top-{args.topk}",
+                "ligands_per_gpu": n_lig,
+                "conformers_per_ligand": args.conformers,
+                "parallelism": f"ligand-sharded x{world}" if world > 1 else "single GPU",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "tree_kernel",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "algorithmic_bytes_per_ligand": alg_bytes_per_ligand,
+                "ligands_per_launch": ligands_per_launch,
+                "kernel_ms_per_launch": {"sizes+scan": ms_sizes / max(launches, 1), "tables_kernel": ms_tables / max(launches, 1),
+                                         "tree_kernel": tree_ms_per_launch},
+                "intermediate_table_bytes_per_ligand": table_bytes / max(n_lig * args.steps, 1),
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(model, offsets, data, args.conformers)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -128,6 +128,10 @@ typedef struct {
     double ms_sizes, ms_tables, ms_tree, ms_total;
     uint64_t table_bytes;   /* bytes of intermediate pair-score tables written for the call */
     uint64_t n_chunks;
+    uint64_t n_tasks;        /* subtrees handed to the task queue by over-budget tree walkers */
+    uint64_t n_rounds;       /* task-queue rounds (one tree-kernel launch each) */
+    uint64_t queue_overflow; /* 1 if the task queue filled up (results stay exact; raise PMX_TASKQ_MB) */
+    uint64_t n_steps;        /* tree-search steps (candidate evaluations, leaf visits, returns) */
 } pmx_score_stats;
 int pmx_score_stats_get(pmx_score_stats *out);
 int pmx_set_profiling(int enabled); /* when enabled pmx_score records HIP events around each kernel (adds syncs) */

@@ -59,6 +59,10 @@ class ScoreStats(ctypes.Structure):
         ("ms_total", ctypes.c_double),
         ("table_bytes", ctypes.c_uint64),
         ("n_chunks", ctypes.c_uint64),
+        ("n_tasks", ctypes.c_uint64),
+        ("n_rounds", ctypes.c_uint64),
+        ("queue_overflow", ctypes.c_uint64),
+        ("n_steps", ctypes.c_uint64),
     ]
 
 
@@ -97,6 +101,10 @@ def load() -> ctypes.CDLL:
     """Load libpmx.so from the package directory (built by `python -m pharmaconet_amd.build`)."""
     global _lib
     if _lib is None:
+        # torch bundles its own libamdhip64 (same SONAME as /opt/rocm's); import it first so that the
+        # process has ONE HIP runtime - the one that owns torch's device buffers and streams.
+        import torch  # noqa: F401
+
         if not LIB_PATH.exists():
             raise PmxError(
                 f"{LIB_PATH} is missing: build the HIP extension with `python -m pharmaconet_amd.build` "

@@ -235,8 +235,12 @@ struct Workspace {
     uint64_t *taboff = nullptr;
     uint8_t *arena = nullptr;
     size_t arena_cap = 0;
-    uint32_t *meta = nullptr;      // device: [0] max levels, [1] ligand counter, [2..3] table bytes (u64)
+    uint32_t *meta = nullptr;      // device: [0] max levels, [1] fetch counter, [2..3] table bytes (u64), [4] task queue tail, [5] queue overflow
     uint32_t *meta_host = nullptr; // pinned mirror
+    uint8_t *queue = nullptr;      // task queue of the tree kernels
+    size_t queue_bytes = 0;
+    unsigned long long *bestbuf = nullptr; // [chunk_cap][64] per-conformer maxima of split ligands
+    uint8_t *deferred = nullptr;           // [chunk_cap]
     int num_cu = 0;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 };
@@ -247,9 +251,15 @@ static uint32_t chunk_size() {
     static uint32_t v = [] {
         const char *s = std::getenv("PMX_CHUNK");
         long x = s ? std::atol(s) : 0;
-        return (uint32_t)(x > 0 ? std::min<long>(x, 1 << 22) : 65536);
+        return (uint32_t)(x > 0 ? std::min<long>(x, 1 << 22) : 131072);
     }();
     return v;
+}
+
+static long env_long(const char *name, long dflt) {
+    const char *s = std::getenv(name);
+    if (!s || !*s) return dflt;
+    return std::atol(s);
 }
 
 static int ensure_workspace(int device, Workspace **out) {
@@ -262,6 +272,10 @@ static int ensure_workspace(int device, Workspace **out) {
         HIPCHECK(hipMalloc((void **)&w.units, (size_t)cap * 4));
         HIPCHECK(hipMalloc((void **)&w.status, (size_t)cap * 4));
         HIPCHECK(hipMalloc((void **)&w.taboff, ((size_t)cap + 1) * 8));
+        if (w.bestbuf) (void)hipFree(w.bestbuf);
+        if (w.deferred) (void)hipFree(w.deferred);
+        HIPCHECK(hipMalloc((void **)&w.bestbuf, (size_t)cap * 64 * 8));
+        HIPCHECK(hipMalloc((void **)&w.deferred, (size_t)cap));
         w.chunk_cap = cap;
     }
     if (!w.meta) {
@@ -271,6 +285,10 @@ static int ensure_workspace(int device, Workspace **out) {
         HIPCHECK(hipGetDeviceProperties(&prop, device));
         w.num_cu = prop.multiProcessorCount;
         for (auto &ev : w.ev) HIPCHECK(hipEventCreate(&ev));
+    }
+    if (!w.queue) {
+        w.queue_bytes = (size_t)std::max<long>(16, env_long("PMX_TASKQ_MB", 1024)) << 20;
+        HIPCHECK(hipMalloc((void **)&w.queue, w.queue_bytes));
     }
     *out = &w;
     return PMX_OK;
@@ -290,7 +308,9 @@ static int score_chunks(const pmx_model *model, const pmx_library *lib, const We
     if (!attr_set) {
         HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&tables_kernel<G>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));
-        HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&tree_kernel<G>),
+        HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&tree_kernel<G, false>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));
+        HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&tree_kernel<G, true>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));
         attr_set = true;
     }
@@ -327,13 +347,59 @@ static int score_chunks(const pmx_model *model, const pmx_library *lib, const We
         if (g_profiling) HIPCHECK(hipEventRecord(ws.ev[2], stream));
         {
             const int depth = std::max<int>(1, (int)max_levels);
-            const size_t lds = (size_t)GPW * tree_group_bytes<G>(depth);
+            const size_t lds = (size_t)GPW * tree_group_bytes<G>(depth, std::max(1, model->dm.K));
             int waves_per_cu = (int)std::min<size_t>(16, kLdsPerCu / (lds + 256));
             waves_per_cu = std::max(1, waves_per_cu);
-            const uint32_t want = (n + GPW - 1) / GPW;
-            const uint32_t grid = std::min<uint32_t>(want, (uint32_t)(ws.num_cu * waves_per_cu));
-            tree_kernel<G><<<dim3(grid), dim3(64), lds, stream>>>(ws.arena, ws.taboff, status, lib->dl, lig0, n, ws.meta + 1, depth, scores);
+            const uint32_t max_grid = (uint32_t)(ws.num_cu * waves_per_cu);
+            TreeParams tp;
+            tp.arena = ws.arena;
+            tp.taboff = ws.taboff;
+            tp.status = status;
+            tp.lib = lib->dl;
+            tp.first = lig0;
+            tp.count = n;
+            tp.task_lo = 0;
+            tp.counter = ws.meta + 1;
+            tp.qtail = ws.meta + 4;
+            tp.queue = ws.queue;
+            tp.qcap = (uint32_t)std::min<size_t>(ws.queue_bytes / task_bytes<G>(), 0x7fffffffu);
+            tp.bestbuf = ws.bestbuf;
+            tp.deferred = ws.deferred;
+            tp.depth_cap = depth;
+            tp.K = std::max(1, model->dm.K);
+            tp.budget = (uint32_t)std::max<long>(64, env_long("PMX_BUDGET", 8192));
+            tp.scores = scores;
+            tp.nsteps = reinterpret_cast<unsigned long long *>(ws.meta + 6);
+            HIPCHECK(hipMemsetAsync(ws.bestbuf, 0, (size_t)n * G * 8, stream));
+            HIPCHECK(hipMemsetAsync(ws.deferred, 0, n, stream));
+            tree_kernel<G, false><<<dim3(std::min<uint32_t>((n + GPW - 1) / GPW, max_grid)), dim3(64), lds, stream>>>(tp);
             HIPCHECK(hipGetLastError());
+            // rounds over the task queue: walkers that ran over budget appended subtrees
+            uint32_t lo = 0;
+            for (;;) {
+                HIPCHECK(hipMemcpyAsync(ws.meta_host, ws.meta, 64, hipMemcpyDeviceToHost, stream));
+                HIPCHECK(hipStreamSynchronize(stream));
+                const uint32_t hi = std::min<uint32_t>(ws.meta_host[4], tp.qcap);
+                if (ws.meta_host[5]) g_stats.queue_overflow = 1;
+                if (hi <= lo) {
+                    unsigned long long ns;
+                    std::memcpy(&ns, ws.meta_host + 6, 8);
+                    g_stats.n_steps += ns;
+                    break;
+                }
+                tp.count = hi - lo;
+                tp.task_lo = lo;
+                HIPCHECK(hipMemsetAsync(ws.meta + 1, 0, 4, stream));
+                tree_kernel<G, true><<<dim3(std::min<uint32_t>((tp.count + GPW - 1) / GPW, max_grid)), dim3(64), lds, stream>>>(tp);
+                HIPCHECK(hipGetLastError());
+                g_stats.n_tasks += tp.count;
+                g_stats.n_rounds += 1;
+                lo = hi;
+            }
+            if (lo > 0) {
+                finalize_kernel<G><<<dim3((n + 255) / 256), dim3(256), 0, stream>>>(lib->dl, lig0, n, ws.deferred, ws.bestbuf, scores);
+                HIPCHECK(hipGetLastError());
+            }
         }
         if (g_profiling) {
             HIPCHECK(hipEventRecord(ws.ev[3], stream));
@@ -400,6 +466,10 @@ extern "C" int pmx_score_multi(const pmx_model *const *models, int n_models, con
         acc.ms_total += g_stats.ms_total;
         acc.table_bytes += g_stats.table_bytes;
         acc.n_chunks += g_stats.n_chunks;
+        acc.n_tasks += g_stats.n_tasks;
+        acc.n_steps += g_stats.n_steps;
+        acc.n_rounds += g_stats.n_rounds;
+        acc.queue_overflow |= g_stats.queue_overflow;
     }
     g_stats = acc;
     return PMX_OK;

@@ -329,108 +329,271 @@ __global__ __launch_bounds__(256) void tables_kernel(DevModel M, DevLibrary lib,
 // Iterative form of ClusterMatchTree.dfs_run (tree.py:55-104). A frame f describes the tree node at
 // level f - 1 (frame 0 = root): `cur` = next candidate of level f to try, `mx` = max_num_matches so
 // far, flags = {matched, any candidate child existed, skip child handled}. The matched ancestors of
-// the current path are kept as a list (match q: table row offset, k_j, chosen candidate a_j), and the
-// conformer mask / float64 totals are indexed by the number of matches (a skip child shares its
-// parent's). A candidate (f, b) is evaluated against the matched ancestors when it is reached:
+// the current path are kept as a list (match q: table row offset, k_j, chosen candidate a_j, level j),
+// and the conformer mask / float64 totals are indexed by the number of matches (a skip child shares
+// its parent's). A candidate (f, b) is evaluated against the matched ancestors when it is reached:
 //   mask  = mask(parent) & AND_q V[entry(q, f, b)]                     (tree.py:78-84)
 //   total = total(parent) + S[f][b] + sum_q P[entry(q, f, b)]          (tree.py:38-41)
-// LDS bytes of one conformer group's tree state for stacks that hold `depth` levels.
-template <int G>
-__host__ __device__ inline uint32_t tree_group_bytes(int depth) {
-    const uint32_t tot_bytes = (uint32_t)(depth + 1) * G * 8;                                  // float64 totals [depth + 1][G]
-    const uint32_t msk_bytes = (uint32_t)round16((uint64_t)(depth + 1) * sizeof(vmask_t<G>)); // conformer masks
-    const uint32_t frm_bytes = (uint32_t)round16((uint64_t)(depth + 1) * 4);                  // frames {cur, mx, flags, nm}
-    const uint32_t mat_bytes = (uint32_t)round16((uint64_t)depth * 8);                        // matched ancestors
-    return tot_bytes + msk_bytes + frm_bytes + mat_bytes + 32 + 48 + 80;                       // + k[32], ksum[24], rowbase[20]
-}
+//
+// Work splitting. Trees are heavy-tailed (median ~1e3 nodes, tail > 1e7), and a tree walked by one
+// group is a serial chain. The only coupling between sibling subtrees is the skip rule
+// `num_matches + max_num_matches < 5` (tree.py:98). Since `num_matches(A) + max_num_matches(A)` is the
+// largest match count of any leaf below A's candidate children, the rule only asks whether a node
+// with >= 5 matches exists there. Hence a subtree rooted at a node Y with num_matches(Y) >= 5 can be
+// cut out: every ancestor's decision is already settled by Y's existence (returning 1 for Y gives
+// each ancestor A at least 5 - num_matches(A)), decisions inside the subtree depend on candidate
+// existence only, and leaves only feed a per-conformer maximum. A walker that exceeds its step budget
+// therefore stops descending into such nodes and appends them to a task queue; tasks are walked by
+// the same code (TASKS = true) in rounds, splitting again when over budget, and per-conformer maxima
+// of split ligands are combined with atomicMax in `bestbuf` (non-negative doubles order as uint64).
+struct TaskHeader { // 64 bytes, followed by double tot[G]
+    uint32_t lig;   // ligand index inside the chunk
+    uint8_t f0;     // frame of the subtree's root
+    uint8_t nm;     // matches on the path, root included
+    uint8_t pad[2];
+    uint64_t mask;  // conformer mask of the root
+    uint8_t path[2 * PMX_MAX_LEVELS]; // (level, candidate) of every match on the path
+    uint8_t pad2[8];
+};
+static_assert(sizeof(TaskHeader) == 64, "TaskHeader layout");
 
 template <int G>
-__global__ __launch_bounds__(64) void tree_kernel(const uint8_t *arena, const uint64_t *taboff, const int32_t *status,
-                                                  DevLibrary lib, uint64_t first, uint32_t count, uint32_t *counter,
-                                                  int depth_cap, float *scores) {
+__host__ __device__ constexpr uint32_t task_bytes() {
+    return sizeof(TaskHeader) + G * 8;
+}
+
+struct TreeParams {
+    const uint8_t *arena;
+    const uint64_t *taboff;
+    const int32_t *status;
+    DevLibrary lib;
+    uint64_t first;      // library index of the chunk's first ligand
+    uint32_t count;      // work items: ligands (TASKS = false) or tasks [task_lo, task_lo + count)
+    uint32_t task_lo;
+    uint32_t *counter;   // dynamic fetch counter
+    uint32_t *qtail;     // task queue tail; qtail[1] = overflow flag
+    uint8_t *queue;
+    uint32_t qcap;
+    unsigned long long *bestbuf; // [chunk][G]
+    uint8_t *deferred;           // [chunk] ligand was split: score comes from bestbuf
+    int depth_cap;
+    int K;               // model clusters (bound on candidates per level)
+    uint32_t budget;     // steps after which a walker donates its unexplored subtrees to the queue
+    unsigned long long *nsteps; // total DFS steps (diagnostics)
+    float *scores;
+};
+
+// LDS bytes of one conformer group's tree state for stacks that hold `depth` levels of a model with K clusters.
+template <int G>
+__host__ __device__ inline uint32_t tree_group_bytes(int depth, int K) {
+    const uint32_t tot_bytes = (uint32_t)(depth + 1) * G * 8;                                      // float64 totals [depth + 1][G]
+    const uint32_t todo_bytes = (uint32_t)(depth + 1) * 8;                                         // unexplored existing candidates per frame
+    const uint32_t cm_bytes = (uint32_t)round16((uint64_t)(depth + 1) * K * sizeof(vmask_t<G>));  // conformer masks of a frame's candidates
+    const uint32_t msk_bytes = (uint32_t)round16((uint64_t)(depth + 1) * sizeof(vmask_t<G>));     // conformer masks by match count
+    const uint32_t frm_bytes = (uint32_t)round16((uint64_t)(depth + 1) * 4);                      // frames {-, mx, flags, nm}
+    const uint32_t mat_bytes = (uint32_t)round16((uint64_t)depth * 8);                            // matched ancestors
+    return tot_bytes + todo_bytes + cm_bytes + msk_bytes + frm_bytes + mat_bytes + 32 + 48 + 80;   // + k[32], ksum[24], rowbase[20]
+}
+
+// Pair-table index of (matched ancestor q, candidate 0 of level f): + b gives candidate b.
+__device__ inline int entry_base(const int2 mq, int ksf, int kf) {
+    return mq.x + (mq.y & 255) * ksf + ((mq.y >> 8) & 255) * kf;
+}
+
+// sum_q P[entry(q, f, b)][c] in ancestor order (tree.py:78-82), loads issued four at a time
+template <int G>
+__device__ inline double pair_sum(const float *Pt, const int2 *mat, int nm, int ksf, int kf, int b, int c) {
+    double pair = 0.0;
+    int q = 0;
+    for (; q + 4 <= nm; q += 4) {
+        const int i0 = entry_base(mat[q], ksf, kf) + b, i1 = entry_base(mat[q + 1], ksf, kf) + b;
+        const int i2 = entry_base(mat[q + 2], ksf, kf) + b, i3 = entry_base(mat[q + 3], ksf, kf) + b;
+        const float p0 = Pt[(size_t)i0 * G + c], p1 = Pt[(size_t)i1 * G + c];
+        const float p2 = Pt[(size_t)i2 * G + c], p3 = Pt[(size_t)i3 * G + c];
+        pair += (double)p0;
+        pair += (double)p1;
+        pair += (double)p2;
+        pair += (double)p3;
+    }
+    for (; q < nm; ++q) pair += (double)Pt[(size_t)(entry_base(mat[q], ksf, kf) + b) * G + c];
+    return pair;
+}
+
+template <int G, bool TASKS>
+__global__ __launch_bounds__(64) void tree_kernel(TreeParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using vm_t = vmask_t<G>;
     const int lane = threadIdx.x & 63;
     const int g = lane / G, c = lane % G;
-    const int D = depth_cap; // levels the stacks can hold
+    const int D = p.depth_cap; // levels the stacks can hold
+    const int K = p.K;
 
     const uint32_t tot_bytes = (uint32_t)(D + 1) * G * 8;
+    const uint32_t todo_bytes = (uint32_t)(D + 1) * 8;
+    const uint32_t cm_bytes = (uint32_t)round16((uint64_t)(D + 1) * K * sizeof(vm_t));
     const uint32_t msk_bytes = (uint32_t)round16((uint64_t)(D + 1) * sizeof(vm_t));
     const uint32_t frm_bytes = (uint32_t)round16((uint64_t)(D + 1) * 4);
     const uint32_t mat_bytes = (uint32_t)round16((uint64_t)D * 8);
-    unsigned char *base = smem + (size_t)g * tree_group_bytes<G>(D);
-    double *tot = reinterpret_cast<double *>(base);                                 // [D + 1][G]
-    vm_t *msk = reinterpret_cast<vm_t *>(base + tot_bytes);                         // [D + 1]
-    uchar4 *frm = reinterpret_cast<uchar4 *>(base + tot_bytes + msk_bytes);         // [D + 1] {cur, mx, flags, nm}
-    int2 *mat = reinterpret_cast<int2 *>(base + tot_bytes + msk_bytes + frm_bytes); // [D] {R, k_j | a_j << 8}
-    uint8_t *hk = base + tot_bytes + msk_bytes + frm_bytes + mat_bytes;             // k[32]
-    uint16_t *hksum = reinterpret_cast<uint16_t *>(hk + 32);                        // [24]
-    uint32_t *hrow = reinterpret_cast<uint32_t *>(hk + 32 + 48);                    // [20]
+    unsigned char *base = smem + (size_t)g * tree_group_bytes<G>(D, K);
+    double *tot = reinterpret_cast<double *>(base);                         // [D + 1][G]
+    uint64_t *todo = reinterpret_cast<uint64_t *>(base + tot_bytes);        // [D + 1]
+    vm_t *cm = reinterpret_cast<vm_t *>(base + tot_bytes + todo_bytes);     // [D + 1][K]
+    vm_t *msk = reinterpret_cast<vm_t *>(base + tot_bytes + todo_bytes + cm_bytes); // [D + 1]
+    uchar4 *frm = reinterpret_cast<uchar4 *>(base + tot_bytes + todo_bytes + cm_bytes + msk_bytes); // [D + 1] {-, mx, flags, nm}
+    int2 *mat = reinterpret_cast<int2 *>(base + tot_bytes + todo_bytes + cm_bytes + msk_bytes + frm_bytes); // [D] {R, k_j | a_j << 8 | j << 16}
+    uint8_t *hk = base + tot_bytes + todo_bytes + cm_bytes + msk_bytes + frm_bytes + mat_bytes; // k[32]
+    uint16_t *hksum = reinterpret_cast<uint16_t *>(hk + 32);                // [24]
+    uint32_t *hrow = reinterpret_cast<uint32_t *>(hk + 32 + 48);            // [20]
+    constexpr unsigned F_MATCHED = 1, F_ANY = 2, F_SKIP = 4, F_EXPANDED = 8;
 
-    // One flat loop: each group is either between ligands (f < 0: finish the previous one, fetch the
-    // next) or inside a tree (one DFS step per iteration), so groups of a wave advance independently.
-    bool running = true, have = false;
-    int f = -1, nl = 0, C = 1;
-    uint32_t li = 0;
+    // One flat loop: each group is either between work items (f < f0: finish the previous one, fetch
+    // the next) or inside a tree (one DFS step per iteration), so groups of a wave advance independently.
+    bool running = true, have = false, exported = false;
+    int f = -1, f0 = 0, nl = 0, C = 1;
+    uint32_t li = 0, steps = 0, steps_total = 0;
     double best = 0.0;
     const vm_t *Vt = nullptr;
     const float *St = nullptr, *Pt = nullptr;
+
+    // hand the subtree of candidate b of frame fr (conformer mask m) to the task queue
+    auto donate = [&](int fr, int nmr, int b, vm_t m) -> bool {
+        uint32_t slot = 0;
+        if (c == 0) slot = atomicAdd(p.qtail, 1u);
+        slot = __shfl(slot, g * G);
+        if (slot >= p.qcap) {
+            if (c == 0) p.qtail[1] = 1;
+            return false;
+        }
+        const int kr = hk[fr], ksr = hksum[fr];
+        const double pair = pair_sum<G>(Pt, mat, nmr, ksr, kr, b, c);
+        TaskHeader *th = reinterpret_cast<TaskHeader *>(p.queue + (size_t)slot * task_bytes<G>());
+        th->lig = li;
+        th->f0 = (uint8_t)(fr + 1);
+        th->nm = (uint8_t)(nmr + 1);
+        th->mask = (uint64_t)m;
+        for (int q = 0; q < nmr; ++q) {
+            const int y = mat[q].y;
+            th->path[2 * q] = (uint8_t)(y >> 16);
+            th->path[2 * q + 1] = (uint8_t)(y >> 8);
+        }
+        th->path[2 * nmr] = (uint8_t)fr;
+        th->path[2 * nmr + 1] = (uint8_t)b;
+        reinterpret_cast<double *>(th + 1)[c] = tot[nmr * G + c] + (double)St[(size_t)(ksr + b) * G + c] + pair;
+        return true;
+    };
+
     while (running) {
-        if (f < 0) {
-            if (have) { // mean over conformers (graph_match.py:109); idle lanes hold 0
-                double s = best;
+        if (f < f0) {
+            if (have) {
+                if (c == 0) atomicAdd(p.nsteps, (unsigned long long)steps_total + steps);
+                if (TASKS || exported) { // split ligand: combine per-conformer maxima across walkers
+                    if (best > 0.0) atomicMax(&p.bestbuf[(size_t)li * G + c], (unsigned long long)__double_as_longlong(best));
+                    if (!TASKS && c == 0) p.deferred[li] = 1;
+                } else { // mean over conformers (graph_match.py:109); idle lanes hold 0
+                    double s = best;
 #pragma unroll
-                for (int d = 1; d < G; d <<= 1) s += __shfl_xor(s, d);
-                if (c == 0) scores[li] = (float)(s / (double)C);
+                    for (int d = 1; d < G; d <<= 1) s += __shfl_xor(s, d);
+                    if (c == 0) p.scores[li] = (float)(s / (double)C);
+                }
                 have = false;
             }
             uint32_t nx = 0;
-            if (c == 0) nx = atomicAdd(counter, 1u); // dynamic fetch: next ligand of the chunk
+            if (c == 0) nx = atomicAdd(p.counter, 1u); // dynamic fetch of the next work item
             nx = __shfl(nx, g * G);
-            if (nx >= count) {
+            f = -1;
+            f0 = 0;
+            if (nx >= p.count) {
                 running = false;
                 continue;
             }
-            li = nx;
-            if (status[li] != PMX_LIGAND_OK) {
-                if (c == 0) scores[li] = __builtin_nanf("");
+            const TaskHeader *task = nullptr;
+            if (TASKS) {
+                task = reinterpret_cast<const TaskHeader *>(p.queue + (size_t)(p.task_lo + nx) * task_bytes<G>());
+                li = task->lig;
+            } else {
+                li = nx;
+                if (p.status[li] != PMX_LIGAND_OK) {
+                    if (c == 0) p.scores[li] = __builtin_nanf("");
+                    continue;
+                }
+            }
+            const uint64_t off = p.taboff[li];
+            if (!TASKS && p.taboff[li + 1] == off) { // no ligand cluster has a candidate (graph_match.py:95-99)
+                if (c == 0) p.scores[li] = 0.f;
                 continue;
             }
-            const uint64_t off = taboff[li];
-            if (taboff[li + 1] == off) { // no ligand cluster has a candidate (graph_match.py:95-99)
-                if (c == 0) scores[li] = 0.f;
-                continue;
-            }
-            const uint8_t *blk = arena + off;
+            const uint8_t *blk = p.arena + off;
             const TabHeader *H = reinterpret_cast<const TabHeader *>(blk);
             nl = (int)H->nl;
             const uint32_t T = H->T, ksumtot = H->ksumtot;
             Vt = reinterpret_cast<const vm_t *>(blk + sizeof(TabHeader));
             St = reinterpret_cast<const float *>(blk + sizeof(TabHeader) + round16(uint64_t(T) * sizeof(vm_t)));
             Pt = St + round16(uint64_t(ksumtot) * G * 4) / 4;
-            for (int i = 0; i < nl; ++i) {
-                hk[i] = H->k[i];
+            for (int i = c; i <= nl; i += G) { // the group's lanes share the header copy
                 hksum[i] = H->ksum[i];
-                hrow[i] = H->rowbase[i];
+                if (i < nl) {
+                    hk[i] = H->k[i];
+                    hrow[i] = H->rowbase[i];
+                }
             }
-            hksum[nl] = H->ksum[nl];
-            C = parse_record(lib.data + lib.offsets[first + li]).C;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             best = 0.0; // graph_match.py:104
             have = true;
-            f = 0; // root frame
-            tot[c] = 0.0;
-            msk[0] = (vm_t)((C >= 64) ? ~0ull : ((1ull << C) - 1ull));
-            frm[0] = make_uchar4(0, 0, 0, 0);
+            exported = false;
+            steps = 0;
+            steps_total = 0;
+            if (TASKS) {
+                const int nm0 = task->nm;
+                f0 = f = task->f0;
+                for (int q = c; q < nm0; q += G) {
+                    const int j = task->path[2 * q], a = task->path[2 * q + 1];
+                    const int kj = H->k[j];
+                    mat[q] = make_int2((int)H->rowbase[j] - kj * (int)H->ksum[j + 1], kj | (a << 8) | (j << 16));
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                tot[nm0 * G + c] = reinterpret_cast<const double *>(task + 1)[c];
+                msk[nm0] = (vm_t)task->mask;
+                frm[f] = make_uchar4(0, 0, F_MATCHED, (unsigned char)nm0);
+            } else {
+                C = parse_record(p.lib.data + p.lib.offsets[p.first + li]).C;
+                f0 = f = 0; // root frame
+                tot[c] = 0.0;
+                msk[0] = (vm_t)((C >= 64) ? ~0ull : ((1ull << C) - 1ull));
+                frm[0] = make_uchar4(0, 0, 0, 0);
+            }
             continue;
+        }
+        ++steps;
+        if (steps > p.budget) {
+            // Over budget: donate every unexplored candidate subtree on the stack (shallow frames first -
+            // they are the large ones) to the task queue, then carry on with what is left under a fresh
+            // budget. Only frames with >= 4 matches may donate (their children have >= 5, see above).
+            steps_total += steps;
+            steps = 0;
+            for (int fr = f0; fr <= f && fr < nl; ++fr) {
+                uchar4 Fr = frm[fr];
+                const int nmr = Fr.w;
+                if (nmr < 4 || !(Fr.z & F_EXPANDED)) continue;
+                uint64_t left = todo[fr];
+                while (left) {
+                    const int b = __ffsll((unsigned long long)left) - 1;
+                    if (!donate(fr, nmr, b, cm[fr * K + b])) break;
+                    left &= left - 1;
+                    exported = true;
+                    Fr.y = Fr.y > 1 ? Fr.y : 1; // the donated child returns at least 1
+                }
+                todo[fr] = left;
+                frm[fr] = Fr;
+            }
         }
         uchar4 F = frm[f];
         const int nm = F.w;
-        const bool matched = F.z & 1;
+        const bool matched = F.z & F_MATCHED;
         if (f == nl) { // leaf (tree.py:103-104): per-conformer maximum (graph_match.py:105-108)
             const double t = tot[nm * G + c];
             if (((msk[nm] >> c) & 1) && t > best) best = t;
             --f;
-            if (f >= 0) {
+            if (f >= f0) {
                 uchar4 Pf = frm[f];
                 const unsigned char ret = matched ? 1 : 0;
                 Pf.y = Pf.y > ret ? Pf.y : ret;
@@ -438,43 +601,52 @@ __global__ __launch_bounds__(64) void tree_kernel(const uint8_t *arena, const ui
             }
             continue;
         }
-        const int kf = hk[f];
-        if (F.x < kf) { // try candidate b of level f (tree.py:94-97)
-            const int b = F.x;
-            F.x = (unsigned char)(b + 1);
-            vm_t m = msk[nm];
-            const int ksf = hksum[f];
-            for (int q = 0; q < nm && m; ++q) {
-                const int2 mq = mat[q];
-                const int idx = mq.x + (mq.y & 255) * ksf + (mq.y >> 8) * kf + b;
-                m &= Vt[idx];
-            }
-            if (m) {
-                double pair = 0.0;
-                for (int q = 0; q < nm; ++q) {
-                    const int2 mq = mat[q];
-                    const int idx = mq.x + (mq.y & 255) * ksf + (mq.y >> 8) * kf + b;
-                    pair += (double)Pt[(size_t)idx * G + c];
+        const int kf = hk[f], ksf = hksum[f];
+        if (!(F.z & F_EXPANDED)) {
+            // Evaluate every candidate of level f against the matched ancestors at once: lane c takes
+            // candidates c, c + G, ...; mask(b) = mask(parent) & AND_q V[entry(q, f, b)]  (tree.py:78-84).
+            uint64_t E = 0;
+            const vm_t pm = msk[nm];
+            for (int b0 = 0; b0 < kf; b0 += G) {
+                const int b = b0 + c;
+                const bool on = b < kf;
+                const int bb = on ? b : 0;
+                vm_t m = on ? pm : (vm_t)0;
+                int q = 0;
+                for (; q + 4 <= nm; q += 4) {
+                    const vm_t v0 = Vt[entry_base(mat[q], ksf, kf) + bb], v1 = Vt[entry_base(mat[q + 1], ksf, kf) + bb];
+                    const vm_t v2 = Vt[entry_base(mat[q + 2], ksf, kf) + bb], v3 = Vt[entry_base(mat[q + 3], ksf, kf) + bb];
+                    m &= (vm_t)(v0 & v1 & v2 & v3);
                 }
-                // parent + self + accumulated pair (tree.py:38-41)
-                const double t = tot[nm * G + c] + (double)St[(size_t)(ksf + b) * G + c] + pair;
-                F.z |= 2; // a candidate child exists
-                frm[f] = F;
-                tot[(nm + 1) * G + c] = t;
-                msk[nm + 1] = m;
-                // entry(this match, level f', b') = rowbase[f] + k_f * (ksum[f'] - ksum[f + 1]) + b * k_f' + b'
-                mat[nm] = make_int2((int)hrow[f] - kf * (int)hksum[f + 1], kf | (b << 8));
-                ++f;
-                frm[f] = make_uchar4(0, 0, 1, (unsigned char)(nm + 1));
-            } else {
-                frm[f] = F;
+                for (; q < nm; ++q) m &= Vt[entry_base(mat[q], ksf, kf) + bb];
+                if (on) cm[f * K + b] = m;
+                const unsigned long long bal = __ballot(on && m != 0);
+                E |= ((G == 64) ? bal : ((bal >> (g * G)) & ((1ull << G) - 1ull))) << b0;
             }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            todo[f] = E;
+            F.z |= F_EXPANDED | (E ? F_ANY : 0);
+            frm[f] = F;
             continue;
         }
-        if (!(F.z & 4)) { // skip child (tree.py:98-101)
-            F.z |= 4;
+        const uint64_t left = todo[f];
+        if (left) { // descend into the next existing candidate child (tree.py:94-97)
+            const int b = __ffsll((unsigned long long)left) - 1;
+            todo[f] = left & (left - 1);
+            // parent + self + accumulated pair (tree.py:38-41)
+            const double t = tot[nm * G + c] + (double)St[(size_t)(ksf + b) * G + c] + pair_sum<G>(Pt, mat, nm, ksf, kf, b, c);
+            tot[(nm + 1) * G + c] = t;
+            msk[nm + 1] = cm[f * K + b];
+            // entry(this match, level f', b') = rowbase[f] + k_f * (ksum[f'] - ksum[f + 1]) + b * k_f' + b'
+            mat[nm] = make_int2((int)hrow[f] - kf * (int)hksum[f + 1], kf | (b << 8) | (f << 16));
+            ++f;
+            frm[f] = make_uchar4(0, 0, F_MATCHED, (unsigned char)(nm + 1));
+            continue;
+        }
+        if (!(F.z & F_SKIP)) { // skip child (tree.py:98-101)
+            F.z |= F_SKIP;
             frm[f] = F;
-            if (!(F.z & 2) || (nm + F.y) < 5) {
+            if (!(F.z & F_ANY) || (nm + F.y) < 5) {
                 ++f;
                 frm[f] = make_uchar4(0, 0, 0, (unsigned char)nm);
                 continue;
@@ -483,12 +655,24 @@ __global__ __launch_bounds__(64) void tree_kernel(const uint8_t *arena, const ui
         // all children done: return max_num_matches + matched (tree.py:102)
         const unsigned char ret = (unsigned char)(F.y + (matched ? 1 : 0));
         --f;
-        if (f >= 0) {
+        if (f >= f0) {
             uchar4 Pf = frm[f];
             Pf.y = Pf.y > ret ? Pf.y : ret;
             frm[f] = Pf;
         }
     }
+}
+
+// Scores of ligands that were split into tasks: mean over conformers of the combined maxima.
+template <int G>
+__global__ void finalize_kernel(DevLibrary lib, uint64_t first, uint32_t count, const uint8_t *deferred,
+                                const unsigned long long *bestbuf, float *scores) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count || !deferred[i]) return;
+    const int C = parse_record(lib.data + lib.offsets[first + i]).C;
+    double s = 0.0;
+    for (int c = 0; c < C; ++c) s += __longlong_as_double((long long)bestbuf[(size_t)i * G + c]);
+    scores[i] = (float)(s / (double)C);
 }
 
 // -------------------------------------------------------------------------------- library stats

@@ -346,6 +346,7 @@ def synthetic_library(
     active_fraction: float = 0.1,
     seed: int = BASE_SEED,
     max_nodes: int = 32,
+    conformer_noise: float = 0.45,
 ) -> PackedLibrary:
     """Ligands `first .. first + count` of the synthetic library `seed` (molecule-level generator).
 
@@ -358,7 +359,8 @@ def synthetic_library(
         n_fragments = None
         while True:
             lig = random_molecule(
-                rng, num_conformers, n_fragments=n_fragments, model_nodes=model_nodes, active_like=active
+                rng, num_conformers, n_fragments=n_fragments, model_nodes=model_nodes, active_like=active,
+                conformer_noise=conformer_noise,
             )
             rec = pack_ligand(lig)
             n_nodes = int.from_bytes(rec[0:2], "little")
@@ -367,3 +369,62 @@ def synthetic_library(
             n_fragments = max(1, (n_fragments or 8) - 2)
         records.append(rec)
     return PackedLibrary.from_records(records)
+
+
+# ------------------------------------------------------------------ device-side library expansion
+def coordinate_layout(lib: PackedLibrary) -> tuple[np.ndarray, np.ndarray, int]:
+    """Per 4-byte word of `lib.data`: is it a coordinate, and which (ligand node, axis) it belongs to.
+
+    Returns `(is_coord bool [W], group int32 [W], n_groups)`; words of one node's x (or y, z) over all
+    conformers share a group id, so a per-group offset moves that node rigidly in every conformer."""
+    n_words = int(lib.data.shape[0]) // 4
+    is_coord = np.zeros(n_words, dtype=bool)
+    group = np.zeros(n_words, dtype=np.int32)
+    next_group = 0
+    hdr = lib.headers()
+    for i in range(len(lib)):
+        n, c = int(hdr[i, 0]), int(hdr[i, 1])
+        k = int(hdr[i, 2])
+        start = int(lib.offsets[i]) + ((8 + n + k + 3) & ~3)
+        w0 = start // 4
+        count = 3 * n * c
+        is_coord[w0 : w0 + count] = True
+        group[w0 : w0 + count] = next_group + np.repeat(np.arange(3 * n, dtype=np.int32), c)
+        next_group += 3 * n
+    return is_coord, group, next_group
+
+
+def expand_library_on_device(
+    base: PackedLibrary,
+    replicas: int,
+    device,
+    seed: int = BASE_SEED,
+    ligand_sigma: float = 0.35,
+    conformer_sigma: float = 0.30,
+):
+    """`replicas` perturbed copies of every ligand of `base`, built in HBM with torch.
+
+    Copy r of base ligand b keeps b's topology (types, clusters) and gets its own geometry: every node is
+    displaced by N(0, ligand_sigma) (the same in all conformers) and every conformer coordinate by a
+    further N(0, conformer_sigma). Ligand index = r * len(base) + b. Returns `(offsets int64 [N + 1],
+    data uint8)` device tensors in the packed library format."""
+    import torch
+
+    dev = torch.device(device)
+    is_coord, group, n_groups = coordinate_layout(base)
+    base_words = torch.from_numpy(base.data.view(np.float32).copy()).to(dev)
+    coord = torch.from_numpy(is_coord).to(dev)
+    gid = torch.from_numpy(group.astype(np.int64)).to(dev)
+    n_words = base_words.numel()
+    nbytes = n_words * 4
+    out = torch.empty((replicas, n_words), dtype=torch.float32, device=dev)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(int(seed))
+    for r in range(replicas):
+        node_shift = torch.randn(n_groups, generator=gen, device=dev, dtype=torch.float32) * ligand_sigma
+        noise = torch.randn(n_words, generator=gen, device=dev, dtype=torch.float32) * conformer_sigma
+        out[r] = torch.where(coord, base_words + node_shift[gid] + noise, base_words)
+    base_off = torch.from_numpy(base.offsets[:-1].astype(np.int64)).to(dev)
+    offsets = (base_off[None, :] + (torch.arange(replicas, device=dev, dtype=torch.int64) * nbytes)[:, None]).reshape(-1)
+    offsets = torch.cat([offsets, torch.tensor([replicas * nbytes], device=dev, dtype=torch.int64)])
+    return offsets, out.view(torch.uint8).reshape(-1)
