@@ -131,7 +131,9 @@ typedef struct {
     uint64_t n_tasks;        /* subtrees handed to the task queue by over-budget tree walkers */
     uint64_t n_rounds;       /* task-queue rounds (one tree-kernel launch each) */
     uint64_t queue_overflow; /* 1 if the task queue filled up (results stay exact; raise PMX_TASKQ_MB) */
-    uint64_t n_steps;        /* tree-search steps (candidate evaluations, leaf visits, returns) */
+    uint64_t n_steps;        /* tree-search steps (frame expansions, descents, leaf visits, returns) */
+    uint64_t n_iters;        /* wavefront iterations of the tree kernels (n_steps / n_iters = busy conformer groups per wave) */
+    uint64_t n_steps_first;  /* of which in the first (per-ligand) tree kernel of the first chunk with tasks */
 } pmx_score_stats;
 int pmx_score_stats_get(pmx_score_stats *out);
 int pmx_set_profiling(int enabled); /* when enabled pmx_score records HIP events around each kernel (adds syncs) */

@@ -63,6 +63,8 @@ class ScoreStats(ctypes.Structure):
         ("n_rounds", ctypes.c_uint64),
         ("queue_overflow", ctypes.c_uint64),
         ("n_steps", ctypes.c_uint64),
+        ("n_iters", ctypes.c_uint64),
+        ("n_steps_first", ctypes.c_uint64),
     ]
 
 

@@ -51,7 +51,8 @@ def build_native(force: bool = False, verbose: bool = False) -> Path:
     objs = []
     for src in SOURCES:
         obj = CSRC / (src.rsplit(".", 1)[0] + ".o")
-        cmd = [cc, *FLAGS, f"-I{REPO / 'include'}", f"-I{CSRC}", "-c", str(CSRC / src), "-o", str(obj)]
+        extra = os.environ.get("PMX_CXXFLAGS", "").split()
+        cmd = [cc, *FLAGS, *extra, f"-I{REPO / 'include'}", f"-I{CSRC}", "-c", str(CSRC / src), "-o", str(obj)]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

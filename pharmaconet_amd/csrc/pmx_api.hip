@@ -10,6 +10,7 @@
 #include <map>
 #include <mutex>
 #include <vector>
+#include <time.h>
 
 #include "pmx.h"
 #include "pmx_kernels.hip"
@@ -279,8 +280,8 @@ static int ensure_workspace(int device, Workspace **out) {
         w.chunk_cap = cap;
     }
     if (!w.meta) {
-        HIPCHECK(hipMalloc((void **)&w.meta, 64));
-        HIPCHECK(hipHostMalloc((void **)&w.meta_host, 64));
+        HIPCHECK(hipMalloc((void **)&w.meta, 1024));
+        HIPCHECK(hipHostMalloc((void **)&w.meta_host, 1024));
         hipDeviceProp_t prop;
         HIPCHECK(hipGetDeviceProperties(&prop, device));
         w.num_cu = prop.multiProcessorCount;
@@ -295,6 +296,20 @@ static int ensure_workspace(int device, Workspace **out) {
 }
 
 static constexpr size_t kLdsPerCu = 160 * 1024;
+
+static bool trace_on() {
+    static int v = -1;
+    if (v < 0) v = std::getenv("PMX_TRACE") ? 1 : 0;
+    return v == 1;
+}
+#define TRACE(...)                        \
+    do {                                  \
+        if (trace_on()) {                 \
+            fprintf(stderr, "[pmx] " __VA_ARGS__); \
+            fprintf(stderr, "\n");        \
+            fflush(stderr);               \
+        }                                 \
+    } while (0)
 
 template <int G>
 static int score_chunks(const pmx_model *model, const pmx_library *lib, const Weights &W, uint64_t first, uint64_t count,
@@ -319,14 +334,16 @@ static int score_chunks(const pmx_model *model, const pmx_library *lib, const We
         const uint64_t lig0 = first + done;
         int32_t *status = status_dev ? status_dev + done : ws.status;
         float *scores = scores_dev + done;
-        HIPCHECK(hipMemsetAsync(ws.meta, 0, 64, stream));
+        HIPCHECK(hipMemsetAsync(ws.meta, 0, 1024, stream));
         if (g_profiling) HIPCHECK(hipEventRecord(ws.ev[0], stream));
         sizes_kernel<G><<<dim3((n + 255) / 256), dim3(256), 0, stream>>>(lib->dl, model->dm.tclus, lig0, n, ws.units, status, ws.meta);
         scan_kernel<<<dim3(1), dim3(1024), 0, stream>>>(ws.units, n, ws.taboff, reinterpret_cast<uint64_t *>(ws.meta + 2));
         HIPCHECK(hipGetLastError());
-        HIPCHECK(hipMemcpyAsync(ws.meta_host, ws.meta, 64, hipMemcpyDeviceToHost, stream));
+        TRACE("chunk %llu: sizes+scan launched, n=%u", (unsigned long long)done, n);
+        HIPCHECK(hipMemcpyAsync(ws.meta_host, ws.meta, 1024, hipMemcpyDeviceToHost, stream));
         HIPCHECK(hipStreamSynchronize(stream));
         const uint32_t max_levels = ws.meta_host[0];
+        TRACE("max_levels=%u", max_levels);
         uint64_t table_total;
         std::memcpy(&table_total, ws.meta_host + 2, 8);
         if (table_total > ws.arena_cap) {
@@ -347,7 +364,12 @@ static int score_chunks(const pmx_model *model, const pmx_library *lib, const We
         if (g_profiling) HIPCHECK(hipEventRecord(ws.ev[2], stream));
         {
             const int depth = std::max<int>(1, (int)max_levels);
-            const size_t lds = (size_t)GPW * tree_group_bytes<G>(depth, std::max(1, model->dm.K));
+            const int Kc = std::max(1, model->dm.K);
+            uint32_t tabcap = (uint32_t)std::max<long>(0, env_long("PMX_TABCAP", 16384));
+            tabcap = (uint32_t)round16(tabcap);
+            while (tabcap > 0 && tree_wave_bytes<G>(depth, Kc, tabcap) > 64 * 1024 - 256) tabcap -= std::min<uint32_t>(tabcap, 1024);
+            const size_t lds = tree_wave_bytes<G>(depth, Kc, tabcap);
+            if (lds > kLdsPerCu) return fail(PMX_ERR_INVALID, "tree state of %zu bytes does not fit LDS", lds);
             int waves_per_cu = (int)std::min<size_t>(16, kLdsPerCu / (lds + 256));
             waves_per_cu = std::max(1, waves_per_cu);
             const uint32_t max_grid = (uint32_t)(ws.num_cu * waves_per_cu);
@@ -366,31 +388,53 @@ static int score_chunks(const pmx_model *model, const pmx_library *lib, const We
             tp.bestbuf = ws.bestbuf;
             tp.deferred = ws.deferred;
             tp.depth_cap = depth;
-            tp.K = std::max(1, model->dm.K);
+            tp.K = Kc;
+            tp.tabcap = tabcap;
             tp.budget = (uint32_t)std::max<long>(64, env_long("PMX_BUDGET", 8192));
             tp.scores = scores;
             tp.nsteps = reinterpret_cast<unsigned long long *>(ws.meta + 6);
+            tp.dbg = ws.meta + 32;
+            tp.max_iters = (unsigned long long)std::max<long>(1, env_long("PMX_MAXITERS", 1L << 40));
             HIPCHECK(hipMemsetAsync(ws.bestbuf, 0, (size_t)n * G * 8, stream));
             HIPCHECK(hipMemsetAsync(ws.deferred, 0, n, stream));
-            tree_kernel<G, false><<<dim3(std::min<uint32_t>((n + GPW - 1) / GPW, max_grid)), dim3(64), lds, stream>>>(tp);
+            TRACE("tree kernel: grid=%u lds=%zu tabcap=%u depth=%d waves/cu=%d", std::min<uint32_t>(n, max_grid), lds, tabcap, depth, waves_per_cu);
+            tree_kernel<G, false><<<dim3(std::min<uint32_t>(n, max_grid)), dim3(64), lds, stream>>>(tp);
             HIPCHECK(hipGetLastError());
+            TRACE("tree kernel launched");
             // rounds over the task queue: walkers that ran over budget appended subtrees
             uint32_t lo = 0;
             for (;;) {
-                HIPCHECK(hipMemcpyAsync(ws.meta_host, ws.meta, 64, hipMemcpyDeviceToHost, stream));
+                HIPCHECK(hipMemcpyAsync(ws.meta_host, ws.meta, 1024, hipMemcpyDeviceToHost, stream));
                 HIPCHECK(hipStreamSynchronize(stream));
+                if (lo == 0 && g_stats.n_rounds == 0) {
+                    unsigned long long ns1;
+                    std::memcpy(&ns1, ws.meta_host + 6, 8);
+                    g_stats.n_steps_first += ns1;
+                }
                 const uint32_t hi = std::min<uint32_t>(ws.meta_host[4], tp.qcap);
+                TRACE("round: lo=%u hi=%u", lo, hi);
                 if (ws.meta_host[5]) g_stats.queue_overflow = 1;
+                if (ws.meta_host[32]) {
+                    char buf[400];
+                    int o = snprintf(buf, sizeof(buf), "tree walk hit the iteration cap (nl=%u busy=%u):", ws.meta_host[33], ws.meta_host[34]);
+                    for (int gq = 0; gq < 8 && o < 380; ++gq) {
+                        const uint32_t *d = ws.meta_host + 32 + 16 + gq * 8;
+                        o += snprintf(buf + o, sizeof(buf) - o, " [g%d li=%u busy=%u f=%d f0=%d sp=%d sfr=%d frm=%08x todo=%x]", gq, d[0], d[1], (int)d[2], (int)d[3], (int)d[4], (int)d[5], d[6], d[7]);
+                    }
+                    return fail(PMX_ERR_INVALID, "%s", buf);
+                }
                 if (hi <= lo) {
                     unsigned long long ns;
                     std::memcpy(&ns, ws.meta_host + 6, 8);
                     g_stats.n_steps += ns;
+                    std::memcpy(&ns, ws.meta_host + 8, 8);
+                    g_stats.n_iters += ns;
                     break;
                 }
                 tp.count = hi - lo;
                 tp.task_lo = lo;
                 HIPCHECK(hipMemsetAsync(ws.meta + 1, 0, 4, stream));
-                tree_kernel<G, true><<<dim3(std::min<uint32_t>((tp.count + GPW - 1) / GPW, max_grid)), dim3(64), lds, stream>>>(tp);
+                tree_kernel<G, true><<<dim3(std::min<uint32_t>(tp.count, max_grid)), dim3(64), lds, stream>>>(tp);
                 HIPCHECK(hipGetLastError());
                 g_stats.n_tasks += tp.count;
                 g_stats.n_rounds += 1;
@@ -468,6 +512,8 @@ extern "C" int pmx_score_multi(const pmx_model *const *models, int n_models, con
         acc.n_chunks += g_stats.n_chunks;
         acc.n_tasks += g_stats.n_tasks;
         acc.n_steps += g_stats.n_steps;
+        acc.n_iters += g_stats.n_iters;
+        acc.n_steps_first += g_stats.n_steps_first;
         acc.n_rounds += g_stats.n_rounds;
         acc.queue_overflow |= g_stats.queue_overflow;
     }

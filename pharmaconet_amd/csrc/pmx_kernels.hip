@@ -327,13 +327,19 @@ __global__ __launch_bounds__(256) void tables_kernel(DevModel M, DevLibrary lib,
 
 // ------------------------------------------------------------------------------------ tree_kernel
 // Iterative form of ClusterMatchTree.dfs_run (tree.py:55-104). A frame f describes the tree node at
-// level f - 1 (frame 0 = root): `cur` = next candidate of level f to try, `mx` = max_num_matches so
-// far, flags = {matched, any candidate child existed, skip child handled}. The matched ancestors of
-// the current path are kept as a list (match q: table row offset, k_j, chosen candidate a_j, level j),
-// and the conformer mask / float64 totals are indexed by the number of matches (a skip child shares
-// its parent's). A candidate (f, b) is evaluated against the matched ancestors when it is reached:
-//   mask  = mask(parent) & AND_q V[entry(q, f, b)]                     (tree.py:78-84)
-//   total = total(parent) + S[f][b] + sum_q P[entry(q, f, b)]          (tree.py:38-41)
+// level f - 1 (frame 0 = root): `todo` = existing candidate children of level f not yet explored,
+// `mx` = max_num_matches so far, flags = {matched, any candidate child existed, skip child handled,
+// expanded}. The matched ancestors of the current path are kept as a list (match q: table row offset,
+// k_j, chosen candidate a_j, level j), and the conformer mask / float64 totals are indexed by the
+// number of matches (a skip child shares its parent's). Entering a frame evaluates every candidate
+// (f, b) against the matched ancestors at once (lanes of the group take different b):
+//   mask(b)  = mask(parent) & AND_q V[entry(q, f, b)]                  (tree.py:78-84)
+// and descending into an existing candidate adds
+//   total(b) = total(parent) + S[f][b] + sum_q P[entry(q, f, b)]       (tree.py:38-41)
+//
+// One wavefront per ligand. The ligand's tables (V, S, P; ~10 KB at BASELINE shapes) are staged in
+// LDS once, and the wave's 64 / G conformer groups walk different subtrees of the SAME tree, so a
+// step is a short chain of LDS reads instead of dependent HBM round trips.
 //
 // Work splitting. Trees are heavy-tailed (median ~1e3 nodes, tail > 1e7), and a tree walked by one
 // group is a serial chain. The only coupling between sibling subtrees is the skip rule
@@ -342,10 +348,14 @@ __global__ __launch_bounds__(256) void tables_kernel(DevModel M, DevLibrary lib,
 // with >= 5 matches exists there. Hence a subtree rooted at a node Y with num_matches(Y) >= 5 can be
 // cut out: every ancestor's decision is already settled by Y's existence (returning 1 for Y gives
 // each ancestor A at least 5 - num_matches(A)), decisions inside the subtree depend on candidate
-// existence only, and leaves only feed a per-conformer maximum. A walker that exceeds its step budget
-// therefore stops descending into such nodes and appends them to a task queue; tasks are walked by
-// the same code (TASKS = true) in rounds, splitting again when over budget, and per-conformer maxima
-// of split ligands are combined with atomicMax in `bestbuf` (non-negative doubles order as uint64).
+// existence only, and leaves only feed a per-conformer maximum. So a frame with >= 4 matches may give
+// away unexplored candidate children:
+//   * inside the wave: whenever a group is idle, busy groups push one child each onto a small LDS
+//     stack and idle groups pop (ballot-ranked, no atomics);
+//   * across waves: a job that exceeds its iteration budget appends all its open children to a global
+//     task queue; tasks are run by the same kernel (TASKS = true) in rounds, splitting again when over
+//     budget; per-conformer maxima of split ligands are combined with atomicMax in `bestbuf`
+//     (non-negative doubles order as uint64).
 struct TaskHeader { // 64 bytes, followed by double tot[G]
     uint32_t lig;   // ligand index inside the chunk
     uint8_t f0;     // frame of the subtree's root
@@ -368,7 +378,7 @@ struct TreeParams {
     const int32_t *status;
     DevLibrary lib;
     uint64_t first;      // library index of the chunk's first ligand
-    uint32_t count;      // work items: ligands (TASKS = false) or tasks [task_lo, task_lo + count)
+    uint32_t count;      // jobs: ligands (TASKS = false) or tasks [task_lo, task_lo + count)
     uint32_t task_lo;
     uint32_t *counter;   // dynamic fetch counter
     uint32_t *qtail;     // task queue tail; qtail[1] = overflow flag
@@ -378,8 +388,11 @@ struct TreeParams {
     uint8_t *deferred;           // [chunk] ligand was split: score comes from bestbuf
     int depth_cap;
     int K;               // model clusters (bound on candidates per level)
-    uint32_t budget;     // steps after which a walker donates its unexplored subtrees to the queue
+    uint32_t tabcap;     // LDS bytes reserved for one ligand's tables
+    uint32_t budget;     // wave iterations after which a job donates its open subtrees to the queue
     unsigned long long *nsteps; // total DFS steps (diagnostics)
+    uint32_t *dbg;       // [0] = error flag (iteration cap hit), then 8 words per group
+    unsigned long long max_iters; // safety cap on wave iterations per job (a tree walk is finite; never spin forever)
     float *scores;
 };
 
@@ -392,7 +405,21 @@ __host__ __device__ inline uint32_t tree_group_bytes(int depth, int K) {
     const uint32_t msk_bytes = (uint32_t)round16((uint64_t)(depth + 1) * sizeof(vmask_t<G>));     // conformer masks by match count
     const uint32_t frm_bytes = (uint32_t)round16((uint64_t)(depth + 1) * 4);                      // frames {-, mx, flags, nm}
     const uint32_t mat_bytes = (uint32_t)round16((uint64_t)depth * 8);                            // matched ancestors
-    return tot_bytes + todo_bytes + cm_bytes + msk_bytes + frm_bytes + mat_bytes + 32 + 48 + 80;   // + k[32], ksum[24], rowbase[20]
+    return tot_bytes + todo_bytes + cm_bytes + msk_bytes + frm_bytes + mat_bytes;
+}
+
+constexpr uint32_t kTreeSharedHdr = 32 + 48 + 80; // k[32], ksum[24], rowbase[20] of the job's ligand
+
+template <int G>
+__host__ __device__ constexpr uint32_t tree_local_stack_entries() {
+    return 2 * (64 / G);
+}
+
+// LDS bytes of one wave of tree_kernel.
+template <int G>
+__host__ __device__ inline uint32_t tree_wave_bytes(int depth, int K, uint32_t tabcap) {
+    return (uint32_t)round16(tabcap) + kTreeSharedHdr + tree_local_stack_entries<G>() * task_bytes<G>() +
+           (64 / G) * tree_group_bytes<G>(depth, K);
 }
 
 // Pair-table index of (matched ancestor q, candidate 0 of level f): + b gives candidate b.
@@ -419,54 +446,96 @@ __device__ inline double pair_sum(const float *Pt, const int2 *mat, int nm, int 
     return pair;
 }
 
-template <int G, bool TASKS>
-__global__ __launch_bounds__(64) void tree_kernel(TreeParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+// Walks one job (a whole ligand tree, or a subtree task) with all conformer groups of the wave.
+// INLDS: the tables were staged at smem[0 .. tabcap); otherwise they are read from the arena.
+template <int G, bool TASKS, bool INLDS>
+__device__ __attribute__((noinline)) void run_job(const TreeParams &p, unsigned char *smem, const uint32_t li, const TaskHeader *task,
+                        const uint8_t *blk) {
     using vm_t = vmask_t<G>;
+    constexpr int GPW = 64 / G;
+    constexpr int LCAP = (int)tree_local_stack_entries<G>();
+    constexpr unsigned F_MATCHED = 1, F_ANY = 2, F_SKIP = 4, F_EXPANDED = 8;
     const int lane = threadIdx.x & 63;
     const int g = lane / G, c = lane % G;
-    const int D = p.depth_cap; // levels the stacks can hold
-    const int K = p.K;
+    const int D = p.depth_cap, K = p.K;
+    const uint32_t budget = p.budget, qcap = p.qcap;
+    const unsigned long long max_iters = p.max_iters;
+    uint32_t *const qtail = p.qtail;
+    uint8_t *const queue = p.queue;
+    const unsigned long long below = (g == 0) ? 0ull : ((1ull << (g * G)) - 1ull); // lanes of lower groups
 
+    // ---- LDS carve
+    unsigned char *shared = smem + round16(p.tabcap);
+    uint8_t *hk = shared;                                               // k[32]
+    uint16_t *hksum = reinterpret_cast<uint16_t *>(shared + 32);        // [24]
+    uint32_t *hrow = reinterpret_cast<uint32_t *>(shared + 32 + 48);    // [20]
+    unsigned char *lstk = shared + kTreeSharedHdr;                      // local task stack
     const uint32_t tot_bytes = (uint32_t)(D + 1) * G * 8;
     const uint32_t todo_bytes = (uint32_t)(D + 1) * 8;
     const uint32_t cm_bytes = (uint32_t)round16((uint64_t)(D + 1) * K * sizeof(vm_t));
     const uint32_t msk_bytes = (uint32_t)round16((uint64_t)(D + 1) * sizeof(vm_t));
     const uint32_t frm_bytes = (uint32_t)round16((uint64_t)(D + 1) * 4);
-    const uint32_t mat_bytes = (uint32_t)round16((uint64_t)D * 8);
-    unsigned char *base = smem + (size_t)g * tree_group_bytes<G>(D, K);
-    double *tot = reinterpret_cast<double *>(base);                         // [D + 1][G]
-    uint64_t *todo = reinterpret_cast<uint64_t *>(base + tot_bytes);        // [D + 1]
-    vm_t *cm = reinterpret_cast<vm_t *>(base + tot_bytes + todo_bytes);     // [D + 1][K]
+    unsigned char *base = lstk + LCAP * task_bytes<G>() + (size_t)g * tree_group_bytes<G>(D, K);
+    double *tot = reinterpret_cast<double *>(base);                                 // [D + 1][G]
+    uint64_t *todo = reinterpret_cast<uint64_t *>(base + tot_bytes);                // [D + 1]
+    vm_t *cm = reinterpret_cast<vm_t *>(base + tot_bytes + todo_bytes);             // [D + 1][K]
     vm_t *msk = reinterpret_cast<vm_t *>(base + tot_bytes + todo_bytes + cm_bytes); // [D + 1]
     uchar4 *frm = reinterpret_cast<uchar4 *>(base + tot_bytes + todo_bytes + cm_bytes + msk_bytes); // [D + 1] {-, mx, flags, nm}
     int2 *mat = reinterpret_cast<int2 *>(base + tot_bytes + todo_bytes + cm_bytes + msk_bytes + frm_bytes); // [D] {R, k_j | a_j << 8 | j << 16}
-    uint8_t *hk = base + tot_bytes + todo_bytes + cm_bytes + msk_bytes + frm_bytes + mat_bytes; // k[32]
-    uint16_t *hksum = reinterpret_cast<uint16_t *>(hk + 32);                // [24]
-    uint32_t *hrow = reinterpret_cast<uint32_t *>(hk + 32 + 48);            // [20]
-    constexpr unsigned F_MATCHED = 1, F_ANY = 2, F_SKIP = 4, F_EXPANDED = 8;
 
-    // One flat loop: each group is either between work items (f < f0: finish the previous one, fetch
-    // the next) or inside a tree (one DFS step per iteration), so groups of a wave advance independently.
-    bool running = true, have = false, exported = false;
-    int f = -1, f0 = 0, nl = 0, C = 1;
-    uint32_t li = 0, steps = 0, steps_total = 0;
-    double best = 0.0;
-    const vm_t *Vt = nullptr;
-    const float *St = nullptr, *Pt = nullptr;
-
-    // hand the subtree of candidate b of frame fr (conformer mask m) to the task queue
-    auto donate = [&](int fr, int nmr, int b, vm_t m) -> bool {
-        uint32_t slot = 0;
-        if (c == 0) slot = atomicAdd(p.qtail, 1u);
-        slot = __shfl(slot, g * G);
-        if (slot >= p.qcap) {
-            if (c == 0) p.qtail[1] = 1;
-            return false;
+    // ---- the job's tables
+    const TabHeader *H = reinterpret_cast<const TabHeader *>(blk);
+    const int nl = (int)H->nl;
+    const uint32_t T = H->T, ksumtot = H->ksumtot;
+    const uint32_t v_bytes = (uint32_t)round16(uint64_t(T) * sizeof(vm_t));
+    const uint32_t s_bytes = (uint32_t)round16(uint64_t(ksumtot) * G * 4);
+    const uint32_t p_bytes = (uint32_t)round16(uint64_t(T) * G * 4);
+    const unsigned char *tab = blk + sizeof(TabHeader);
+    if (INLDS) {
+        const uint32_t n16 = (v_bytes + s_bytes + p_bytes) / 16;
+        const uint4 *src = reinterpret_cast<const uint4 *>(tab);
+        uint4 *dst = reinterpret_cast<uint4 *>(smem);
+        for (uint32_t i = lane; i < n16; i += 64) dst[i] = src[i];
+        tab = smem;
+    }
+    const vm_t *Vt = reinterpret_cast<const vm_t *>(tab);
+    const float *St = reinterpret_cast<const float *>(tab + v_bytes);
+    const float *Pt = reinterpret_cast<const float *>(tab + v_bytes + s_bytes);
+    for (int i = lane; i <= nl; i += 64) {
+        hksum[i] = H->ksum[i];
+        if (i < nl) {
+            hk[i] = H->k[i];
+            hrow[i] = H->rowbase[i];
         }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+
+    // ---- walker state
+    bool busy = false, exported = false;
+    int f = -1, f0 = 0, sfr = 1 << 20, sp = 0, C = 1;
+    uint32_t iters = 0;
+    unsigned long long nsteps = 0, total_iters = 0;
+    double best = 0.0; // graph_match.py:104
+
+    // start a walker on the subtree described by a task record (global queue or local stack)
+    auto adopt = [&](const TaskHeader *th) {
+        const int nm0 = th->nm;
+        f0 = f = th->f0;
+        sfr = f;
+        for (int q = c; q < nm0; q += G) {
+            const int j = th->path[2 * q], a = th->path[2 * q + 1];
+            const int kj = hk[j];
+            mat[q] = make_int2((int)hrow[j] - kj * (int)hksum[j + 1], kj | (a << 8) | (j << 16));
+        }
+        tot[nm0 * G + c] = reinterpret_cast<const double *>(th + 1)[c];
+        msk[nm0] = (vm_t)th->mask;
+        frm[f] = make_uchar4(0, 0, F_MATCHED, (unsigned char)nm0);
+        busy = true;
+    };
+    // describe candidate b of frame fr (conformer mask m) as a task record
+    auto describe = [&](TaskHeader *th, int fr, int nmr, int b, vm_t m) {
         const int kr = hk[fr], ksr = hksum[fr];
         const double pair = pair_sum<G>(Pt, mat, nmr, ksr, kr, b, c);
-        TaskHeader *th = reinterpret_cast<TaskHeader *>(p.queue + (size_t)slot * task_bytes<G>());
         th->lig = li;
         th->f0 = (uint8_t)(fr + 1);
         th->nm = (uint8_t)(nmr + 1);
@@ -479,187 +548,261 @@ __global__ __launch_bounds__(64) void tree_kernel(TreeParams p) {
         th->path[2 * nmr] = (uint8_t)fr;
         th->path[2 * nmr + 1] = (uint8_t)b;
         reinterpret_cast<double *>(th + 1)[c] = tot[nmr * G + c] + (double)St[(size_t)(ksr + b) * G + c] + pair;
-        return true;
+    };
+    // a frame may give children away once it has >= 4 matches (their subtrees hold >= 5, see above)
+    auto donatable = [&](int fr) -> bool {
+        const uchar4 Fr = frm[fr];
+        return Fr.w >= 4 && (Fr.z & F_EXPANDED) && todo[fr] != 0;
     };
 
-    while (running) {
-        if (f < f0) {
-            if (have) {
-                if (c == 0) atomicAdd(p.nsteps, (unsigned long long)steps_total + steps);
-                if (TASKS || exported) { // split ligand: combine per-conformer maxima across walkers
-                    if (best > 0.0) atomicMax(&p.bestbuf[(size_t)li * G + c], (unsigned long long)__double_as_longlong(best));
-                    if (!TASKS && c == 0) p.deferred[li] = 1;
-                } else { // mean over conformers (graph_match.py:109); idle lanes hold 0
-                    double s = best;
-#pragma unroll
-                    for (int d = 1; d < G; d <<= 1) s += __shfl_xor(s, d);
-                    if (c == 0) p.scores[li] = (float)(s / (double)C);
+    if (g == 0) {
+        if (TASKS) {
+            adopt(task);
+        } else {
+            C = parse_record(p.lib.data + p.lib.offsets[p.first + li]).C;
+            f0 = f = 0; // root frame
+            sfr = 0;
+            tot[c] = 0.0;
+            msk[0] = (vm_t)((C >= 64) ? ~0ull : ((1ull << C) - 1ull));
+            frm[0] = make_uchar4(0, 0, 0, 0);
+            busy = true;
+        }
+    }
+
+    for (;;) {
+        const unsigned long long busy_bal = __ballot(busy && c == 0);
+        sp = __builtin_amdgcn_readfirstlane(sp);
+        if (!busy_bal && sp == 0) break;
+        const int n_busy = __popcll(busy_bal), n_idle = GPW - n_busy;
+        nsteps += (unsigned)n_busy;
+        if (++total_iters > max_iters) { // cannot happen for a finite tree; report instead of spinning
+            if (c == 0) {
+                uint32_t *d = p.dbg + 16 + g * 8;
+                d[0] = li; d[1] = busy; d[2] = (uint32_t)f; d[3] = (uint32_t)f0; d[4] = (uint32_t)sp; d[5] = (uint32_t)sfr;
+                d[6] = busy && f >= 0 ? *reinterpret_cast<uint32_t *>(&frm[f]) : 0u; d[7] = busy && f >= 0 ? (uint32_t)todo[f] : 0u;
+                p.dbg[0] = 1; p.dbg[1] = (uint32_t)nl; p.dbg[2] = (uint32_t)n_busy;
+            }
+            break;
+        }
+
+        // ---- in-wave work sharing
+        if (GPW > 1 && n_idle > 0) {
+            const int need = n_idle - sp;
+            if (need > 0 && n_busy > 0) {
+                bool can = false;
+                if (busy) {
+                    // skip frames that can never give a child away (fewer than 4 matches, or exhausted)
+                    while (sfr <= f && sfr < nl) {
+                        const uchar4 Fs = frm[sfr];
+                        if (Fs.w < 4 || ((Fs.z & F_EXPANDED) && todo[sfr] == 0)) ++sfr;
+                        else break;
+                    }
+                    can = sfr <= f && sfr < nl && donatable(sfr);
                 }
-                have = false;
+                const unsigned long long don_bal = __ballot(can && c == 0);
+                const int rank = __popcll(don_bal & below);
+                const int room = LCAP - sp;
+                const int take = min(min(need, room), (int)__popcll(don_bal));
+                if (can && rank < take) {
+                    uchar4 Fr = frm[sfr];
+                    const uint64_t left = todo[sfr];
+                    const int b = __ffsll((unsigned long long)left) - 1;
+                    todo[sfr] = left & (left - 1);
+                    describe(reinterpret_cast<TaskHeader *>(lstk + (size_t)(sp + rank) * task_bytes<G>()), sfr, Fr.w, b, cm[sfr * K + b]);
+                    Fr.y = Fr.y > 1 ? Fr.y : 1; // the child given away returns at least 1
+                    frm[sfr] = Fr;
+                }
+                sp = __builtin_amdgcn_readfirstlane(sp + take);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             }
-            uint32_t nx = 0;
-            if (c == 0) nx = atomicAdd(p.counter, 1u); // dynamic fetch of the next work item
-            nx = __shfl(nx, g * G);
-            f = -1;
-            f0 = 0;
-            if (nx >= p.count) {
-                running = false;
-                continue;
+            if (sp > 0) {
+                const unsigned long long idle_bal = __ballot(!busy && c == 0);
+                const int rank = __popcll(idle_bal & below);
+                const int npop = min(sp, n_idle);
+                if (!busy && rank < npop) adopt(reinterpret_cast<const TaskHeader *>(lstk + (size_t)(sp - 1 - rank) * task_bytes<G>()));
+                sp = __builtin_amdgcn_readfirstlane(sp - npop);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             }
-            const TaskHeader *task = nullptr;
-            if (TASKS) {
-                task = reinterpret_cast<const TaskHeader *>(p.queue + (size_t)(p.task_lo + nx) * task_bytes<G>());
-                li = task->lig;
-            } else {
-                li = nx;
-                if (p.status[li] != PMX_LIGAND_OK) {
-                    if (c == 0) p.scores[li] = __builtin_nanf("");
-                    continue;
+        }
+
+        // ---- over budget: hand every open subtree (and the local stack) to the global queue
+        if (++iters > budget) {
+            iters = 0;
+            bool gave = false;
+            if (busy) {
+                for (int fr = max(f0, sfr); fr <= f && fr < nl; ++fr) {
+                    if (!donatable(fr)) continue;
+                    uchar4 Fr = frm[fr];
+                    uint64_t left = todo[fr];
+                    while (left) {
+                        uint32_t slot = 0;
+                        if (c == 0) slot = atomicAdd(qtail, 1u);
+                        slot = __shfl(slot, g * G);
+                        if (slot >= qcap) { // queue full: the walker keeps the rest
+                            if (c == 0) qtail[1] = 1;
+                            break;
+                        }
+                        const int b = __ffsll((unsigned long long)left) - 1;
+                        describe(reinterpret_cast<TaskHeader *>(queue + (size_t)slot * task_bytes<G>()), fr, Fr.w, b, cm[fr * K + b]);
+                        left &= left - 1;
+                        gave = true;
+                        Fr.y = Fr.y > 1 ? Fr.y : 1;
+                    }
+                    todo[fr] = left;
+                    frm[fr] = Fr;
                 }
             }
-            const uint64_t off = p.taboff[li];
-            if (!TASKS && p.taboff[li + 1] == off) { // no ligand cluster has a candidate (graph_match.py:95-99)
-                if (c == 0) p.scores[li] = 0.f;
-                continue;
-            }
-            const uint8_t *blk = p.arena + off;
-            const TabHeader *H = reinterpret_cast<const TabHeader *>(blk);
-            nl = (int)H->nl;
-            const uint32_t T = H->T, ksumtot = H->ksumtot;
-            Vt = reinterpret_cast<const vm_t *>(blk + sizeof(TabHeader));
-            St = reinterpret_cast<const float *>(blk + sizeof(TabHeader) + round16(uint64_t(T) * sizeof(vm_t)));
-            Pt = St + round16(uint64_t(ksumtot) * G * 4) / 4;
-            for (int i = c; i <= nl; i += G) { // the group's lanes share the header copy
-                hksum[i] = H->ksum[i];
-                if (i < nl) {
-                    hk[i] = H->k[i];
-                    hrow[i] = H->rowbase[i];
+            // local stack -> global queue (group e copies entry e, 16 bytes per lane and pass)
+            for (int e0 = 0; e0 < sp; e0 += GPW) {
+                const int e = e0 + g;
+                uint32_t slot = 0;
+                if (e < sp && c == 0) slot = atomicAdd(qtail, 1u);
+                slot = __shfl(slot, g * G);
+                if (e < sp) {
+                    if (slot < qcap) {
+                        const uint4 *src = reinterpret_cast<const uint4 *>(lstk + (size_t)e * task_bytes<G>());
+                        uint4 *dst = reinterpret_cast<uint4 *>(queue + (size_t)slot * task_bytes<G>());
+                        for (uint32_t w = c; w < task_bytes<G>() / 16; w += G) dst[w] = src[w];
+                        gave = true;
+                    } else if (c == 0) {
+                        qtail[1] = 1; // cannot happen in practice: entry is lost only if the queue is full
+                    }
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            best = 0.0; // graph_match.py:104
-            have = true;
-            exported = false;
-            steps = 0;
-            steps_total = 0;
-            if (TASKS) {
-                const int nm0 = task->nm;
-                f0 = f = task->f0;
-                for (int q = c; q < nm0; q += G) {
-                    const int j = task->path[2 * q], a = task->path[2 * q + 1];
-                    const int kj = H->k[j];
-                    mat[q] = make_int2((int)H->rowbase[j] - kj * (int)H->ksum[j + 1], kj | (a << 8) | (j << 16));
+            if (__ballot(gave)) exported = true;
+            // entries that did not fit stay on the local stack only if the queue was full; keep them
+            if (!__builtin_amdgcn_readfirstlane((int)qtail[1])) sp = 0;
+        }
+
+        // ---- one DFS step per busy group
+        if (busy) {
+            uchar4 F = frm[f];
+            const int nm = F.w;
+            const bool matched = F.z & F_MATCHED;
+            if (f == nl) { // leaf (tree.py:103-104): per-conformer maximum (graph_match.py:105-108)
+                const double t = tot[nm * G + c];
+                if (((msk[nm] >> c) & 1) && t > best) best = t;
+                --f;
+                if (f >= f0) {
+                    uchar4 Pf = frm[f];
+                    const unsigned char ret = matched ? 1 : 0;
+                    Pf.y = Pf.y > ret ? Pf.y : ret;
+                    frm[f] = Pf;
+                }
+            } else if (!(F.z & F_EXPANDED)) {
+                // evaluate every candidate of level f against the matched ancestors (tree.py:78-84)
+                const int kf = hk[f], ksf = hksum[f];
+                uint64_t E = 0;
+                const vm_t pm = msk[nm];
+                for (int b0 = 0; b0 < kf; b0 += G) {
+                    const int b = b0 + c;
+                    const bool on = b < kf;
+                    const int bb = on ? b : 0;
+                    vm_t m = on ? pm : (vm_t)0;
+                    int q = 0;
+                    for (; q + 4 <= nm; q += 4) {
+                        const vm_t v0 = Vt[entry_base(mat[q], ksf, kf) + bb], v1 = Vt[entry_base(mat[q + 1], ksf, kf) + bb];
+                        const vm_t v2 = Vt[entry_base(mat[q + 2], ksf, kf) + bb], v3 = Vt[entry_base(mat[q + 3], ksf, kf) + bb];
+                        m &= (vm_t)(v0 & v1 & v2 & v3);
+                    }
+                    for (; q < nm; ++q) m &= Vt[entry_base(mat[q], ksf, kf) + bb];
+                    if (on) cm[f * K + b] = m;
+                    const unsigned long long bal = __ballot(on && m != 0);
+                    E |= ((G == 64) ? bal : ((bal >> (g * G)) & ((1ull << G) - 1ull))) << b0;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                tot[nm0 * G + c] = reinterpret_cast<const double *>(task + 1)[c];
-                msk[nm0] = (vm_t)task->mask;
-                frm[f] = make_uchar4(0, 0, F_MATCHED, (unsigned char)nm0);
+                todo[f] = E;
+                F.z |= F_EXPANDED | (E ? F_ANY : 0);
+                frm[f] = F;
             } else {
-                C = parse_record(p.lib.data + p.lib.offsets[p.first + li]).C;
-                f0 = f = 0; // root frame
-                tot[c] = 0.0;
-                msk[0] = (vm_t)((C >= 64) ? ~0ull : ((1ull << C) - 1ull));
-                frm[0] = make_uchar4(0, 0, 0, 0);
-            }
-            continue;
-        }
-        ++steps;
-        if (steps > p.budget) {
-            // Over budget: donate every unexplored candidate subtree on the stack (shallow frames first -
-            // they are the large ones) to the task queue, then carry on with what is left under a fresh
-            // budget. Only frames with >= 4 matches may donate (their children have >= 5, see above).
-            steps_total += steps;
-            steps = 0;
-            for (int fr = f0; fr <= f && fr < nl; ++fr) {
-                uchar4 Fr = frm[fr];
-                const int nmr = Fr.w;
-                if (nmr < 4 || !(Fr.z & F_EXPANDED)) continue;
-                uint64_t left = todo[fr];
-                while (left) {
+                const uint64_t left = todo[f];
+                if (left) { // descend into the next existing candidate child (tree.py:94-97)
+                    const int kf = hk[f], ksf = hksum[f];
                     const int b = __ffsll((unsigned long long)left) - 1;
-                    if (!donate(fr, nmr, b, cm[fr * K + b])) break;
-                    left &= left - 1;
-                    exported = true;
-                    Fr.y = Fr.y > 1 ? Fr.y : 1; // the donated child returns at least 1
+                    todo[f] = left & (left - 1);
+                    // parent + self + accumulated pair (tree.py:38-41)
+                    const double t = tot[nm * G + c] + (double)St[(size_t)(ksf + b) * G + c] + pair_sum<G>(Pt, mat, nm, ksf, kf, b, c);
+                    tot[(nm + 1) * G + c] = t;
+                    msk[nm + 1] = cm[f * K + b];
+                    // entry(this match, level f', b') = rowbase[f] + k_f * (ksum[f'] - ksum[f + 1]) + b * k_f' + b'
+                    mat[nm] = make_int2((int)hrow[f] - kf * (int)hksum[f + 1], kf | (b << 8) | (f << 16));
+                    ++f;
+                    frm[f] = make_uchar4(0, 0, F_MATCHED, (unsigned char)(nm + 1));
+                    if (f < sfr) sfr = f;
+                } else if (!(F.z & F_SKIP) && (!(F.z & F_ANY) || (nm + F.y) < 5)) { // skip child (tree.py:98-101)
+                    F.z |= F_SKIP;
+                    frm[f] = F;
+                    ++f;
+                    frm[f] = make_uchar4(0, 0, 0, (unsigned char)nm);
+                    if (f < sfr) sfr = f;
+                } else { // all children done: return max_num_matches + matched (tree.py:102)
+                    const unsigned char ret = (unsigned char)(F.y + (matched ? 1 : 0));
+                    --f;
+                    if (f >= f0) {
+                        uchar4 Pf = frm[f];
+                        Pf.y = Pf.y > ret ? Pf.y : ret;
+                        frm[f] = Pf;
+                    }
                 }
-                todo[fr] = left;
-                frm[fr] = Fr;
             }
+            if (f < f0) busy = false;
         }
-        uchar4 F = frm[f];
-        const int nm = F.w;
-        const bool matched = F.z & F_MATCHED;
-        if (f == nl) { // leaf (tree.py:103-104): per-conformer maximum (graph_match.py:105-108)
-            const double t = tot[nm * G + c];
-            if (((msk[nm] >> c) & 1) && t > best) best = t;
-            --f;
-            if (f >= f0) {
-                uchar4 Pf = frm[f];
-                const unsigned char ret = matched ? 1 : 0;
-                Pf.y = Pf.y > ret ? Pf.y : ret;
-                frm[f] = Pf;
-            }
-            continue;
-        }
-        const int kf = hk[f], ksf = hksum[f];
-        if (!(F.z & F_EXPANDED)) {
-            // Evaluate every candidate of level f against the matched ancestors at once: lane c takes
-            // candidates c, c + G, ...; mask(b) = mask(parent) & AND_q V[entry(q, f, b)]  (tree.py:78-84).
-            uint64_t E = 0;
-            const vm_t pm = msk[nm];
-            for (int b0 = 0; b0 < kf; b0 += G) {
-                const int b = b0 + c;
-                const bool on = b < kf;
-                const int bb = on ? b : 0;
-                vm_t m = on ? pm : (vm_t)0;
-                int q = 0;
-                for (; q + 4 <= nm; q += 4) {
-                    const vm_t v0 = Vt[entry_base(mat[q], ksf, kf) + bb], v1 = Vt[entry_base(mat[q + 1], ksf, kf) + bb];
-                    const vm_t v2 = Vt[entry_base(mat[q + 2], ksf, kf) + bb], v3 = Vt[entry_base(mat[q + 3], ksf, kf) + bb];
-                    m &= (vm_t)(v0 & v1 & v2 & v3);
-                }
-                for (; q < nm; ++q) m &= Vt[entry_base(mat[q], ksf, kf) + bb];
-                if (on) cm[f * K + b] = m;
-                const unsigned long long bal = __ballot(on && m != 0);
-                E |= ((G == 64) ? bal : ((bal >> (g * G)) & ((1ull << G) - 1ull))) << b0;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            todo[f] = E;
-            F.z |= F_EXPANDED | (E ? F_ANY : 0);
-            frm[f] = F;
-            continue;
-        }
-        const uint64_t left = todo[f];
-        if (left) { // descend into the next existing candidate child (tree.py:94-97)
-            const int b = __ffsll((unsigned long long)left) - 1;
-            todo[f] = left & (left - 1);
-            // parent + self + accumulated pair (tree.py:38-41)
-            const double t = tot[nm * G + c] + (double)St[(size_t)(ksf + b) * G + c] + pair_sum<G>(Pt, mat, nm, ksf, kf, b, c);
-            tot[(nm + 1) * G + c] = t;
-            msk[nm + 1] = cm[f * K + b];
-            // entry(this match, level f', b') = rowbase[f] + k_f * (ksum[f'] - ksum[f + 1]) + b * k_f' + b'
-            mat[nm] = make_int2((int)hrow[f] - kf * (int)hksum[f + 1], kf | (b << 8) | (f << 16));
-            ++f;
-            frm[f] = make_uchar4(0, 0, F_MATCHED, (unsigned char)(nm + 1));
-            continue;
-        }
-        if (!(F.z & F_SKIP)) { // skip child (tree.py:98-101)
-            F.z |= F_SKIP;
-            frm[f] = F;
-            if (!(F.z & F_ANY) || (nm + F.y) < 5) {
-                ++f;
-                frm[f] = make_uchar4(0, 0, 0, (unsigned char)nm);
+    }
+
+    // ---- combine the groups' per-conformer maxima; lanes of group 0 end up with the wave's maxima
+#pragma unroll
+    for (int d = G; d < 64; d <<= 1) {
+        const double o = __shfl_xor(best, d);
+        best = o > best ? o : best;
+    }
+    if (lane == 0) {
+        atomicAdd(p.nsteps, nsteps);
+        atomicAdd(p.nsteps + 1, total_iters);
+    }
+    if (TASKS || exported) { // split ligand: combine across waves, score comes from finalize_kernel
+        if (g == 0 && best > 0.0) atomicMax(&p.bestbuf[(size_t)li * G + c], (unsigned long long)__double_as_longlong(best));
+        if (!TASKS && lane == 0) p.deferred[li] = 1;
+    } else { // mean over conformers (graph_match.py:109); idle lanes hold 0
+        C = __shfl(C, 0);
+        double s = best;
+#pragma unroll
+        for (int d = 1; d < G; d <<= 1) s += __shfl_xor(s, d);
+        if (lane == 0) p.scores[li] = (float)(s / (double)C);
+    }
+}
+
+template <int G, bool TASKS>
+__global__ __launch_bounds__(64) void tree_kernel(TreeParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    for (;;) {
+        uint32_t nx = 0;
+        if (lane == 0) nx = atomicAdd(p.counter, 1u); // dynamic fetch of the next job
+
+        nx = __builtin_amdgcn_readfirstlane(nx);
+        if (nx >= p.count) break;
+        const TaskHeader *task = nullptr;
+        uint32_t li = nx;
+        if (TASKS) {
+            task = reinterpret_cast<const TaskHeader *>(p.queue + (size_t)(p.task_lo + nx) * task_bytes<G>());
+            li = task->lig;
+        } else {
+            if (p.status[li] != PMX_LIGAND_OK) {
+                if (lane == 0) p.scores[li] = __builtin_nanf("");
                 continue;
             }
         }
-        // all children done: return max_num_matches + matched (tree.py:102)
-        const unsigned char ret = (unsigned char)(F.y + (matched ? 1 : 0));
-        --f;
-        if (f >= f0) {
-            uchar4 Pf = frm[f];
-            Pf.y = Pf.y > ret ? Pf.y : ret;
-            frm[f] = Pf;
+        const uint64_t off = p.taboff[li];
+        const uint64_t bytes = p.taboff[li + 1] - off;
+        if (bytes == 0) { // no ligand cluster has a candidate (graph_match.py:95-99)
+            if (!TASKS && lane == 0) p.scores[li] = 0.f;
+            continue;
         }
+        // previous job's LDS reads are complete (same wave, program order); stage and walk
+        if (bytes - sizeof(TabHeader) <= p.tabcap)
+            run_job<G, TASKS, true>(p, smem, li, task, p.arena + off);
+        else
+            run_job<G, TASKS, false>(p, smem, li, task, p.arena + off);
     }
 }
 
