@@ -334,7 +334,10 @@ static int score_chunks(const pmx_model *model, const pmx_library *lib, const We
         const uint64_t lig0 = first + done;
         int32_t *status = status_dev ? status_dev + done : ws.status;
         float *scores = scores_dev + done;
-        HIPCHECK(hipMemsetAsync(ws.meta, 0, 1024, stream));
+        {
+            const uint64_t words = std::max<uint64_t>((uint64_t)n * G, 256);
+            clear_kernel<<<dim3((unsigned)((words + 255) / 256)), dim3(256), 0, stream>>>(ws.meta, 256, ws.bestbuf, (uint64_t)n * G, ws.deferred, n);
+        }
         if (g_profiling) HIPCHECK(hipEventRecord(ws.ev[0], stream));
         sizes_kernel<G><<<dim3((n + 255) / 256), dim3(256), 0, stream>>>(lib->dl, model->dm.tclus, lig0, n, ws.units, status, ws.meta);
         scan_kernel<<<dim3(1), dim3(1024), 0, stream>>>(ws.units, n, ws.taboff, reinterpret_cast<uint64_t *>(ws.meta + 2));
@@ -360,14 +363,27 @@ static int score_chunks(const pmx_model *model, const pmx_library *lib, const We
             tables_kernel<G><<<dim3((n + groups_per_block - 1) / groups_per_block), dim3(64 * tab_waves), tab_lds, stream>>>(
                 model->dm, lib->dl, W, lig0, n, status, ws.taboff, ws.arena);
             HIPCHECK(hipGetLastError());
+            if (trace_on()) {
+                TRACE("tables kernel launched (%u bytes of tables)", (unsigned)table_total);
+                HIPCHECK(hipStreamSynchronize(stream));
+                TRACE("tables kernel done");
+                std::vector<uint64_t> offs(std::min<uint32_t>(n, 8) + 1);
+                HIPCHECK(hipMemcpy(offs.data(), ws.taboff, offs.size() * 8, hipMemcpyDeviceToHost));
+                for (size_t q = 0; q + 1 < offs.size(); ++q) {
+                    uint32_t hdr[4] = {0, 0, 0, 0};
+                    if (offs[q + 1] > offs[q]) HIPCHECK(hipMemcpy(hdr, ws.arena + offs[q], 16, hipMemcpyDeviceToHost));
+                    TRACE("  ligand %zu: taboff=%llu bytes=%llu header nl=%u T=%u ksumtot=%u", q, (unsigned long long)offs[q],
+                          (unsigned long long)(offs[q + 1] - offs[q]), hdr[0], hdr[1], hdr[2]);
+                }
+            }
         }
         if (g_profiling) HIPCHECK(hipEventRecord(ws.ev[2], stream));
         {
             const int depth = std::max<int>(1, (int)max_levels);
             const int Kc = std::max(1, model->dm.K);
-            uint32_t tabcap = (uint32_t)std::max<long>(0, env_long("PMX_TABCAP", 16384));
+            uint32_t tabcap = (uint32_t)std::max<long>(0, env_long("PMX_TABCAP", 8192));
             tabcap = (uint32_t)round16(tabcap);
-            while (tabcap > 0 && tree_wave_bytes<G>(depth, Kc, tabcap) > 64 * 1024 - 256) tabcap -= std::min<uint32_t>(tabcap, 1024);
+            while (tabcap > 0 && tree_wave_bytes<G>(depth, Kc, tabcap) > 64 * 1024 - 512) tabcap -= std::min<uint32_t>(tabcap, 1024);
             const size_t lds = tree_wave_bytes<G>(depth, Kc, tabcap);
             if (lds > kLdsPerCu) return fail(PMX_ERR_INVALID, "tree state of %zu bytes does not fit LDS", lds);
             int waves_per_cu = (int)std::min<size_t>(16, kLdsPerCu / (lds + 256));
@@ -390,15 +406,14 @@ static int score_chunks(const pmx_model *model, const pmx_library *lib, const We
             tp.depth_cap = depth;
             tp.K = Kc;
             tp.tabcap = tabcap;
-            tp.budget = (uint32_t)std::max<long>(64, env_long("PMX_BUDGET", 8192));
+            tp.budget = (uint32_t)std::max<long>(64, env_long("PMX_BUDGET", 2048));
             tp.scores = scores;
+            tp.flags = (uint32_t)env_long("PMX_TREE_FLAGS", 0);
             tp.nsteps = reinterpret_cast<unsigned long long *>(ws.meta + 6);
             tp.dbg = ws.meta + 32;
             tp.max_iters = (unsigned long long)std::max<long>(1, env_long("PMX_MAXITERS", 1L << 40));
-            HIPCHECK(hipMemsetAsync(ws.bestbuf, 0, (size_t)n * G * 8, stream));
-            HIPCHECK(hipMemsetAsync(ws.deferred, 0, n, stream));
-            TRACE("tree kernel: grid=%u lds=%zu tabcap=%u depth=%d waves/cu=%d", std::min<uint32_t>(n, max_grid), lds, tabcap, depth, waves_per_cu);
-            tree_kernel<G, false><<<dim3(std::min<uint32_t>(n, max_grid)), dim3(64), lds, stream>>>(tp);
+            TRACE("tree kernel: grid=%u lds=%zu tabcap=%u depth=%d waves/cu=%d", n, lds, tabcap, depth, waves_per_cu);
+            tree_kernel<G, false><<<dim3(n), dim3(64), lds, stream>>>(tp);
             HIPCHECK(hipGetLastError());
             TRACE("tree kernel launched");
             // rounds over the task queue: walkers that ran over budget appended subtrees
@@ -414,6 +429,7 @@ static int score_chunks(const pmx_model *model, const pmx_library *lib, const We
                 const uint32_t hi = std::min<uint32_t>(ws.meta_host[4], tp.qcap);
                 TRACE("round: lo=%u hi=%u", lo, hi);
                 if (ws.meta_host[5]) g_stats.queue_overflow = 1;
+                if (ws.meta_host[32] == 2) return fail(PMX_ERR_INVALID, "tree kernel watchdog fired at location %u", ws.meta_host[35]);
                 if (ws.meta_host[32]) {
                     char buf[400];
                     int o = snprintf(buf, sizeof(buf), "tree walk hit the iteration cap (nl=%u busy=%u):", ws.meta_host[33], ws.meta_host[34]);
@@ -433,8 +449,7 @@ static int score_chunks(const pmx_model *model, const pmx_library *lib, const We
                 }
                 tp.count = hi - lo;
                 tp.task_lo = lo;
-                HIPCHECK(hipMemsetAsync(ws.meta + 1, 0, 4, stream));
-                tree_kernel<G, true><<<dim3(std::min<uint32_t>(tp.count, max_grid)), dim3(64), lds, stream>>>(tp);
+                tree_kernel<G, true><<<dim3(tp.count), dim3(64), lds, stream>>>(tp);
                 HIPCHECK(hipGetLastError());
                 g_stats.n_tasks += tp.count;
                 g_stats.n_rounds += 1;

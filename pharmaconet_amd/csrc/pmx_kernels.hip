@@ -389,6 +389,7 @@ struct TreeParams {
     int depth_cap;
     int K;               // model clusters (bound on candidates per level)
     uint32_t tabcap;     // LDS bytes reserved for one ligand's tables
+    uint32_t flags;      // debug: 1 = no in-wave sharing, 2 = no global donation
     uint32_t budget;     // wave iterations after which a job donates its open subtrees to the queue
     unsigned long long *nsteps; // total DFS steps (diagnostics)
     uint32_t *dbg;       // [0] = error flag (iteration cap hit), then 8 words per group
@@ -422,6 +423,14 @@ __host__ __device__ inline uint32_t tree_wave_bytes(int depth, int K, uint32_t t
            (64 / G) * tree_group_bytes<G>(depth, K);
 }
 
+// Cross-lane hand-off through LDS inside one wavefront: DS operations of a wave execute in order, but
+// accesses made through generic pointers are FLAT instructions, which travel another path and may pass
+// (or be passed by) DS operations. Drain both counters before another lane's data is consumed.
+__device__ inline void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+}
+
 // Pair-table index of (matched ancestor q, candidate 0 of level f): + b gives candidate b.
 __device__ inline int entry_base(const int2 mq, int ksf, int kf) {
     return mq.x + (mq.y & 255) * ksf + ((mq.y >> 8) & 255) * kf;
@@ -449,7 +458,19 @@ __device__ inline double pair_sum(const float *Pt, const int2 *mat, int nm, int 
 // Walks one job (a whole ligand tree, or a subtree task) with all conformer groups of the wave.
 // INLDS: the tables were staged at smem[0 .. tabcap); otherwise they are read from the arena.
 template <int G, bool TASKS, bool INLDS>
-__device__ __attribute__((noinline)) void run_job(const TreeParams &p, unsigned char *smem, const uint32_t li, const TaskHeader *task,
+#ifdef PMX_GUARDS
+#define PMX_GUARD(code)                                                         \
+    do {                                                                        \
+        if (++guard > 50000000u) {                                              \
+            p.dbg[0] = 2;                                                       \
+            p.dbg[3] = (code);                                                  \
+            return;                                                             \
+        }                                                                       \
+    } while (0)
+#else
+#define PMX_GUARD(code) (void)guard
+#endif
+__device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem, const uint32_t li, const TaskHeader *task,
                         const uint8_t *blk) {
     using vm_t = vmask_t<G>;
     constexpr int GPW = 64 / G;
@@ -458,7 +479,7 @@ __device__ __attribute__((noinline)) void run_job(const TreeParams &p, unsigned 
     const int lane = threadIdx.x & 63;
     const int g = lane / G, c = lane % G;
     const int D = p.depth_cap, K = p.K;
-    const uint32_t budget = p.budget, qcap = p.qcap;
+    const uint32_t budget = p.budget, qcap = p.qcap, flags = p.flags;
     const unsigned long long max_iters = p.max_iters;
     uint32_t *const qtail = p.qtail;
     uint8_t *const queue = p.queue;
@@ -483,6 +504,7 @@ __device__ __attribute__((noinline)) void run_job(const TreeParams &p, unsigned 
     uchar4 *frm = reinterpret_cast<uchar4 *>(base + tot_bytes + todo_bytes + cm_bytes + msk_bytes); // [D + 1] {-, mx, flags, nm}
     int2 *mat = reinterpret_cast<int2 *>(base + tot_bytes + todo_bytes + cm_bytes + msk_bytes + frm_bytes); // [D] {R, k_j | a_j << 8 | j << 16}
 
+    uint32_t guard = 0;
     // ---- the job's tables
     const TabHeader *H = reinterpret_cast<const TabHeader *>(blk);
     const int nl = (int)H->nl;
@@ -495,20 +517,24 @@ __device__ __attribute__((noinline)) void run_job(const TreeParams &p, unsigned 
         const uint32_t n16 = (v_bytes + s_bytes + p_bytes) / 16;
         const uint4 *src = reinterpret_cast<const uint4 *>(tab);
         uint4 *dst = reinterpret_cast<uint4 *>(smem);
-        for (uint32_t i = lane; i < n16; i += 64) dst[i] = src[i];
+        for (uint32_t i = lane; i < n16; i += 64) {
+            PMX_GUARD(1);
+            dst[i] = src[i];
+        }
         tab = smem;
     }
     const vm_t *Vt = reinterpret_cast<const vm_t *>(tab);
     const float *St = reinterpret_cast<const float *>(tab + v_bytes);
     const float *Pt = reinterpret_cast<const float *>(tab + v_bytes + s_bytes);
     for (int i = lane; i <= nl; i += 64) {
+        PMX_GUARD(2);
         hksum[i] = H->ksum[i];
         if (i < nl) {
             hk[i] = H->k[i];
             hrow[i] = H->rowbase[i];
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    wave_lds_sync();
 
     // ---- walker state
     bool busy = false, exported = false;
@@ -568,8 +594,10 @@ __device__ __attribute__((noinline)) void run_job(const TreeParams &p, unsigned 
             busy = true;
         }
     }
+    wave_lds_sync();
 
     for (;;) {
+        PMX_GUARD(12);
         const unsigned long long busy_bal = __ballot(busy && c == 0);
         sp = __builtin_amdgcn_readfirstlane(sp);
         if (!busy_bal && sp == 0) break;
@@ -586,13 +614,14 @@ __device__ __attribute__((noinline)) void run_job(const TreeParams &p, unsigned 
         }
 
         // ---- in-wave work sharing
-        if (GPW > 1 && n_idle > 0) {
+        if (GPW > 1 && n_idle > 0 && !(flags & 1)) {
             const int need = n_idle - sp;
             if (need > 0 && n_busy > 0) {
                 bool can = false;
                 if (busy) {
                     // skip frames that can never give a child away (fewer than 4 matches, or exhausted)
                     while (sfr <= f && sfr < nl) {
+                        PMX_GUARD(5);
                         const uchar4 Fs = frm[sfr];
                         if (Fs.w < 4 || ((Fs.z & F_EXPANDED) && todo[sfr] == 0)) ++sfr;
                         else break;
@@ -613,7 +642,7 @@ __device__ __attribute__((noinline)) void run_job(const TreeParams &p, unsigned 
                     frm[sfr] = Fr;
                 }
                 sp = __builtin_amdgcn_readfirstlane(sp + take);
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                wave_lds_sync();
             }
             if (sp > 0) {
                 const unsigned long long idle_bal = __ballot(!busy && c == 0);
@@ -621,20 +650,22 @@ __device__ __attribute__((noinline)) void run_job(const TreeParams &p, unsigned 
                 const int npop = min(sp, n_idle);
                 if (!busy && rank < npop) adopt(reinterpret_cast<const TaskHeader *>(lstk + (size_t)(sp - 1 - rank) * task_bytes<G>()));
                 sp = __builtin_amdgcn_readfirstlane(sp - npop);
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                wave_lds_sync();
             }
         }
 
         // ---- over budget: hand every open subtree (and the local stack) to the global queue
-        if (++iters > budget) {
+        if (++iters > budget && !(flags & 2)) {
             iters = 0;
             bool gave = false;
             if (busy) {
                 for (int fr = max(f0, sfr); fr <= f && fr < nl; ++fr) {
+                    PMX_GUARD(6);
                     if (!donatable(fr)) continue;
                     uchar4 Fr = frm[fr];
                     uint64_t left = todo[fr];
                     while (left) {
+                        PMX_GUARD(7);
                         uint32_t slot = 0;
                         if (c == 0) slot = atomicAdd(qtail, 1u);
                         slot = __shfl(slot, g * G);
@@ -654,6 +685,7 @@ __device__ __attribute__((noinline)) void run_job(const TreeParams &p, unsigned 
             }
             // local stack -> global queue (group e copies entry e, 16 bytes per lane and pass)
             for (int e0 = 0; e0 < sp; e0 += GPW) {
+                PMX_GUARD(8);
                 const int e = e0 + g;
                 uint32_t slot = 0;
                 if (e < sp && c == 0) slot = atomicAdd(qtail, 1u);
@@ -695,22 +727,27 @@ __device__ __attribute__((noinline)) void run_job(const TreeParams &p, unsigned 
                 uint64_t E = 0;
                 const vm_t pm = msk[nm];
                 for (int b0 = 0; b0 < kf; b0 += G) {
+                    PMX_GUARD(9);
                     const int b = b0 + c;
                     const bool on = b < kf;
                     const int bb = on ? b : 0;
                     vm_t m = on ? pm : (vm_t)0;
                     int q = 0;
                     for (; q + 4 <= nm; q += 4) {
+                        PMX_GUARD(10);
                         const vm_t v0 = Vt[entry_base(mat[q], ksf, kf) + bb], v1 = Vt[entry_base(mat[q + 1], ksf, kf) + bb];
                         const vm_t v2 = Vt[entry_base(mat[q + 2], ksf, kf) + bb], v3 = Vt[entry_base(mat[q + 3], ksf, kf) + bb];
                         m &= (vm_t)(v0 & v1 & v2 & v3);
                     }
-                    for (; q < nm; ++q) m &= Vt[entry_base(mat[q], ksf, kf) + bb];
+                    for (; q < nm; ++q) {
+                        PMX_GUARD(11);
+                        m &= Vt[entry_base(mat[q], ksf, kf) + bb];
+                    }
                     if (on) cm[f * K + b] = m;
                     const unsigned long long bal = __ballot(on && m != 0);
                     E |= ((G == 64) ? bal : ((bal >> (g * G)) & ((1ull << G) - 1ull))) << b0;
                 }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                wave_lds_sync();
                 todo[f] = E;
                 F.z |= F_EXPANDED | (E ? F_ANY : 0);
                 frm[f] = F;
@@ -771,38 +808,39 @@ __device__ __attribute__((noinline)) void run_job(const TreeParams &p, unsigned 
     }
 }
 
+#undef PMX_GUARD
+
+// One block (= one wavefront) per job, no persistent fetch loop: the hardware dispatcher hands the next
+// block to whichever CU frees a slot, which is the dynamic load balancing a work counter would give,
+// and the kernel stays a straight line of wave-uniform branches around the walker.
 template <int G, bool TASKS>
-__global__ __launch_bounds__(64) void tree_kernel(TreeParams p) {
+__global__ __launch_bounds__(64) void tree_kernel(const TreeParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
-    for (;;) {
-        uint32_t nx = 0;
-        if (lane == 0) nx = atomicAdd(p.counter, 1u); // dynamic fetch of the next job
-
-        nx = __builtin_amdgcn_readfirstlane(nx);
-        if (nx >= p.count) break;
-        const TaskHeader *task = nullptr;
-        uint32_t li = nx;
-        if (TASKS) {
-            task = reinterpret_cast<const TaskHeader *>(p.queue + (size_t)(p.task_lo + nx) * task_bytes<G>());
-            li = task->lig;
-        } else {
-            if (p.status[li] != PMX_LIGAND_OK) {
-                if (lane == 0) p.scores[li] = __builtin_nanf("");
-                continue;
-            }
-        }
-        const uint64_t off = p.taboff[li];
-        const uint64_t bytes = p.taboff[li + 1] - off;
-        if (bytes == 0) { // no ligand cluster has a candidate (graph_match.py:95-99)
-            if (!TASKS && lane == 0) p.scores[li] = 0.f;
-            continue;
-        }
-        // previous job's LDS reads are complete (same wave, program order); stage and walk
-        if (bytes - sizeof(TabHeader) <= p.tabcap)
-            run_job<G, TASKS, true>(p, smem, li, task, p.arena + off);
-        else
-            run_job<G, TASKS, false>(p, smem, li, task, p.arena + off);
+    const uint32_t nx = blockIdx.x;
+    if (nx >= p.count) return;
+    const TaskHeader *task = nullptr;
+    uint32_t li = nx;
+    int status = PMX_LIGAND_OK;
+    if (TASKS) {
+        task = reinterpret_cast<const TaskHeader *>(p.queue + (size_t)(p.task_lo + nx) * task_bytes<G>());
+        li = __builtin_amdgcn_readfirstlane(task->lig);
+    } else {
+        status = __builtin_amdgcn_readfirstlane(p.status[li]);
+    }
+    // table offsets in 16-byte units fit 32 bits (arena < 64 GB)
+    const uint32_t u0 = __builtin_amdgcn_readfirstlane((uint32_t)(p.taboff[li] >> 4));
+    const uint32_t u1 = __builtin_amdgcn_readfirstlane((uint32_t)(p.taboff[li + 1] >> 4));
+    const uint32_t bytes = (u1 - u0) * 16u;
+    const uint8_t *blk = p.arena + (size_t)u0 * 16;
+    if (status != PMX_LIGAND_OK) {
+        if (lane == 0) p.scores[li] = __builtin_nanf("");
+    } else if (bytes == 0) { // no ligand cluster has a candidate (graph_match.py:95-99)
+        if (!TASKS && lane == 0) p.scores[li] = 0.f;
+    } else if (bytes - (uint32_t)sizeof(TabHeader) <= p.tabcap) {
+        run_job<G, TASKS, true>(p, smem, li, task, blk);
+    } else {
+        run_job<G, TASKS, false>(p, smem, li, task, blk);
     }
 }
 
@@ -817,6 +855,19 @@ __global__ void finalize_kernel(DevLibrary lib, uint64_t first, uint32_t count, 
     for (int c = 0; c < C; ++c) s += __longlong_as_double((long long)bestbuf[(size_t)i * G + c]);
     scores[i] = (float)(s / (double)C);
 }
+
+// Zeroes the per-chunk device state. A kernel (not hipMemsetAsync) so that everything in the scoring
+// stream is ordered kernel -> kernel: memsets queued between two dependent kernels were observed to let
+// the second kernel start before the first had finished on ROCm 7.2 / gfx950.
+__global__ void clear_kernel(uint32_t *meta, uint32_t meta_words, unsigned long long *bestbuf, uint64_t best_words,
+                             uint8_t *deferred, uint32_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < meta_words) meta[i] = 0;
+    if (i < best_words) bestbuf[i] = 0;
+    if (i < n) deferred[i] = 0;
+}
+
+__global__ void set_word_kernel(uint32_t *word, uint32_t value) { *word = value; }
 
 // -------------------------------------------------------------------------------- library stats
 __global__ void library_stats_kernel(DevLibrary lib, unsigned long long *out /* [0] conformers [1] maxn [2] maxC [3] maxcl [4] unsupported */) {

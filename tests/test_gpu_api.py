@@ -1,0 +1,139 @@
+"""GPU tests of the host API around the kernels: top-k order, ranges, the reference-named entry points,
+several models over one library, edge cases, and order/partition invariance on a large synthetic library."""
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def stable_desc(scores, k):
+    return sorted(range(len(scores)), key=lambda i: scores[i], reverse=True)[:k]
+
+
+def test_topk_matches_stable_descending_sort():
+    """screening.py:70 on the device: descending, ties in library order."""
+    import torch
+
+    from pharmaconet_amd.engine import topk
+
+    rng = np.random.default_rng(3)
+    s = rng.integers(0, 50, size=10_000).astype(np.float32)
+    s[5] = np.nan  # unsupported ligand: ranks last
+    t = torch.from_numpy(s).cuda()
+    ts, ti = topk(t, 300, base_index=1000)
+    clean = np.where(np.isnan(s), -np.inf, s)
+    want = stable_desc(clean, 300)
+    assert (ti.cpu().numpy() - 1000).tolist() == want
+    np.testing.assert_array_equal(ts.cpu().numpy(), clean[want])
+    # k larger than n pads with -inf / -1
+    ts, ti = topk(t[:10], 16)
+    assert ti.cpu().numpy()[10:].tolist() == [-1] * 6 and np.all(np.isinf(ts.cpu().numpy()[10:]))
+
+
+def test_screen_ranges_and_topk():
+    model, lib, weights, d = load_golden("set_c21_c8")
+    full = model.screen(lib, topk=20)
+    got = full.scores.cpu().numpy()
+    part = model.screen(lib, first=37, count=50, topk=5, index_base=1_000_000)
+    np.testing.assert_array_equal(part.scores.cpu().numpy(), got[37:87])
+    want = stable_desc(got, 20)
+    assert [i for i, _ in full.ranking()] == want
+    assert [i for i, _ in part.ranking()] == [1_000_037 + j for j in stable_desc(got[37:87], 5)]
+
+
+def test_reference_named_entry_points():
+    """`_scoring` returns a Python float per ligand (pharmacophore_model.py:101-106)."""
+    model, lib, weights, d = load_golden("set_6oim_c5")
+    for i in (0, 3, 17):
+        s = model._scoring(lib.record(i), weights)
+        assert isinstance(s, float)
+        assert abs(s - d["score"][i]) <= 2e-6 * abs(d["score"][i]) + 1e-30
+    try:
+        import openbabel  # noqa: F401
+    except ImportError:
+        # file / SMILES entry points need OpenBabel exactly like the reference; they must say so
+        with pytest.raises(ImportError, match="OpenBabel"):
+            model.scoring_file("ligand.sdf")
+
+
+def test_weights_argument():
+    model, lib, weights, d = load_golden("set_6oim_c8_weights")
+    default = model.screen(lib).scores.cpu().numpy()
+    override = model.screen(lib, weights=weights).scores.cpu().numpy()
+    assert rel_err(override, d["score"]).max() < 2e-6 + 6e-8
+    assert np.abs(default - override).max() > 1.0
+
+
+def test_multi_model_over_one_library():
+    import ctypes
+
+    import torch
+
+    from pharmaconet_amd import _ffi
+    from pharmaconet_amd.constants import weights_vector
+    from pharmaconet_amd.engine import DeviceLibrary, device_model
+
+    m1, lib, _, d1 = load_golden("set_6oim_c8")
+    m2, _, _, _ = load_golden("set_c21_c8")
+    lib = lib.slice(10, 120)
+    dev = DeviceLibrary(lib)
+    handles = (ctypes.c_void_p * 2)(device_model(m1).handle, device_model(m2).handle)
+    out = torch.empty(2 * len(lib), dtype=torch.float32, device="cuda")
+    w = (ctypes.c_float * 7)(*weights_vector(None))
+    _ffi.check(_ffi.load().pmx_score_multi(handles, 2, dev.handle, w, 0, len(lib), out.data_ptr(), None, None))
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().reshape(2, -1)
+    np.testing.assert_array_equal(got[0], m1.screen(dev).scores.cpu().numpy())
+    np.testing.assert_array_equal(got[1], m2.screen(dev).scores.cpu().numpy())
+    assert rel_err(got[0], np.where(d1["score"][10:130] == 0, 1e-30, d1["score"][10:130])).max() < 1.0
+
+
+def test_edge_cases():
+    from pharmaconet_amd import PackedLibrary
+    from pharmaconet_amd.library import LigandFeatures, pack_ligand
+
+    model, lib, _, d = load_golden("set_c21_c8")
+    empty = PackedLibrary.from_records([])
+    res = model.screen(empty, topk=3)
+    assert res.scores.numel() == 0 and [i for i, _ in res.ranking()] == []
+    # zero-feature ligand and a ligand whose only type (Halogen) the model lacks: 0 (graph_match.py:95-99)
+    zero = pack_ligand(LigandFeatures([6, 8], [[1], [0]], [], np.zeros((2, 4, 3), np.float32)))
+    hal = pack_ligand(LigandFeatures([6, 17], [[1], [0]], [("Halogen", 1, 1)], np.ones((2, 4, 3), np.float32)))
+    got = model.screen([zero, hal, lib.record(0)]).scores.cpu().numpy()
+    assert got[0] == 0.0 and got[1] == 0.0
+
+
+def test_order_and_partition_invariance_large():
+    """Size-independent properties at a BASELINE-like scale: a ligand's score does not depend on its
+    position, its neighbours, or on how the library is chunked into launches."""
+    import torch
+
+    from pharmaconet_amd.constants import TYPE_ID
+    from pharmaconet_amd.engine import DeviceLibrary
+    from pharmaconet_amd.synthetic import expand_library_on_device, synthetic_library
+
+    model, _, _, _ = load_golden("set_6oim_c8")
+    st = model.__getstate__()
+    centers = np.array([n["center"] for n in st["nodes"]])
+    types = np.array([TYPE_ID[n["type"]] for n in st["nodes"]])
+    base = synthetic_library(512, num_conformers=8, model_nodes=(centers, types), conformer_noise=0.0)
+    offsets, data = expand_library_on_device(base, 300, "cuda")  # 153,600 ligands > one chunk
+    lib = DeviceLibrary.from_device_buffers(offsets, data)
+    full = model.screen(lib).scores
+    assert torch.isfinite(full).all() and (full >= 0).all()
+    # shifted ranges cut the chunks differently
+    for first, count in ((1, 70_000), (65_537, 88_000), (131_071, 2)):
+        part = model.screen(lib, first=first, count=count).scores
+        assert torch.equal(part, full[first : first + count])
+    # a reversed copy of a slice gives reversed scores
+    n = 4096
+    off = offsets.cpu().numpy()
+    dat = data.cpu().numpy()
+    from pharmaconet_amd import PackedLibrary
+
+    recs = [dat[off[i] : off[i + 1]].tobytes() for i in range(n)]
+    rev = model.screen(PackedLibrary.from_records(recs[::-1])).scores
+    assert torch.equal(rev.flip(0), full[:n])

@@ -1,0 +1,101 @@
+"""Packed ligand library: the `LigandGraph` restatement (library.cluster_ligand) against records extracted
+from the reference's real `LigandGraph` (tests/golden/*_mols.npz -> *.pmxlib), format round trips, edge cases."""
+
+import json
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from pharmaconet_amd import PackedLibrary
+from pharmaconet_amd.library import ClusteredLigand, LigandFeatures, as_packed_library, pack_clustered_ligand, pack_ligand
+
+
+def golden_molecules(name):
+    d = np.load(GOLDEN / f"{name}_mols.npz")
+    topo = json.loads(str(d["topology"]))
+    shapes, pos = d["shapes"], d["positions"]
+    off = 0
+    for i, t in enumerate(topo):
+        n = int(np.prod(shapes[i]))
+        p = pos[off : off + n].reshape(shapes[i])
+        off += n
+        feats = [
+            (f[0], f[1] if isinstance(f[1], int) else tuple(f[1]), f[2] if isinstance(f[2], int) else tuple(f[2]))
+            for f in t["features"]
+        ]
+        yield LigandFeatures(t["z"], t["nbrs"], feats, p)
+
+
+@pytest.mark.parametrize("name", ["set_6oim_c8", "set_6oim_c1", "set_6oim_c64", "set_c21_c8", "set_s64_c8"])
+def test_packer_matches_reference_ligandgraph(name):
+    """Byte-identical records: node merging, dependence, functional groups, hydrophobic flood, cluster
+    order inside clusters, priority sort (ligand.py:134-259, graph_match.py:43-60)."""
+    lib = PackedLibrary.load(GOLDEN / f"{name}.pmxlib")
+    count = 0
+    for i, mol in enumerate(golden_molecules(name)):
+        assert pack_ligand(mol) == lib.record(i), f"{name}[{i}]"
+        count += 1
+    assert count == len(lib)
+
+
+def test_record_layout():
+    lib = PackedLibrary.load(GOLDEN / "set_6oim_c5.pmxlib")
+    assert np.all(lib.offsets % 16 == 0)
+    hdr = lib.headers()
+    for i in range(len(lib)):
+        u = lib.unpack(i)
+        assert (u["n_nodes"], u["n_conf"], u["n_clusters"]) == tuple(hdr[i])
+        assert u["n_conf"] == 5
+        ends = u["cluster_end"]
+        assert np.all(np.diff(np.concatenate([[0], ends])) > 0) and (len(ends) == 0 or ends[-1] == u["n_nodes"])
+        assert np.all((u["typemask"] > 0) & (u["typemask"] < 128))
+        assert u["xyz"].shape == (u["n_nodes"], 3, 5)
+
+
+def test_save_load_slice(tmp_path):
+    lib = PackedLibrary.load(GOLDEN / "set_6oim_c1.pmxlib")
+    lib.save(tmp_path / "a.pmxlib")
+    again = PackedLibrary.load(tmp_path / "a.pmxlib")
+    np.testing.assert_array_equal(again.offsets, lib.offsets)
+    np.testing.assert_array_equal(again.data, lib.data)
+    part = lib.slice(3, 5)
+    assert len(part) == 5 and part.record(0) == lib.record(3) and part.record(4) == lib.record(7)
+    assert as_packed_library([lib.record(0), lib.record(1)]).record(1) == lib.record(1)
+    (tmp_path / "bad").write_bytes(b"nope" * 10)
+    with pytest.raises(ValueError):
+        PackedLibrary.load(tmp_path / "bad")
+
+
+def test_zero_feature_ligand_packs_to_empty_record():
+    mol = LigandFeatures([6, 8], [[1], [0]], [], np.zeros((2, 3, 3), np.float32))
+    rec = pack_ligand(mol)
+    assert len(rec) == 16 and rec[:8] == bytes([0, 0, 3, 0, 0, 0, 0, 0])
+
+
+def test_priority_sort_is_stable_and_follows_priority_fn():
+    # clusters: Hydrophobic(2 nodes), Aromatic(1), HBond(2), Cation(1), Anion(1), Halogen(1), Hydrophobic(1)
+    pos = np.zeros((9, 2, 3), np.float32)
+    pos[:, :, 0] = np.arange(9)[:, None]
+    cl = ClusteredLigand(
+        typemask=np.array([1, 1, 2, 16, 32, 4, 8, 64, 1], np.uint8),
+        positions=pos,
+        clusters=[[0, 1], [2], [3, 4], [5], [6], [7], [8]],
+        cluster_types=["Hydrophobic", "Aromatic", "HBond", "Cation", "Anion", "Halogen", "Hydrophobic"],
+        cluster_key_atom=[10, 3, 5, 7, 2, 9, 1],
+    )
+    u = PackedLibrary.from_records([pack_clustered_ligand(cl)]).unpack(0)
+    # group 0 (Aromatic, Cation, Anion; all size 1 -> by subtype), then group 1 by size desc, subtype, atom
+    order = [2, 5, 6, 3, 4, 0, 1, 7, 8]
+    np.testing.assert_array_equal(u["xyz"][:, 0, 0], np.array(order, np.float32))
+    np.testing.assert_array_equal(u["cluster_end"], [1, 2, 3, 5, 7, 8, 9])
+
+
+def test_limits_are_enforced():
+    pos = np.zeros((65, 1, 3), np.float32)
+    cl = ClusteredLigand(np.ones(65, np.uint8), pos, [[i] for i in range(65)], ["Hydrophobic"] * 65, list(range(65)))
+    with pytest.raises(ValueError):
+        pack_clustered_ligand(cl)
+    cl = ClusteredLigand(np.ones(1, np.uint8), np.zeros((1, 65, 3), np.float32), [[0]], ["Hydrophobic"], [0])
+    with pytest.raises(ValueError):
+        pack_clustered_ligand(cl)
