@@ -151,7 +151,8 @@ def main():
     for _ in range(args.warmup):
         step()
     engine.set_profiling(True)  # HIP events around each kernel launch of the timed steps
-    ms_tree = ms_tables = ms_sizes = 0.0
+    ms_tree = ms_tables = ms_sizes = ms_tasks = 0.0
+    n_tasks = n_steps = n_iters = 0
     launches = 0
     table_bytes = 0
     barrier()
@@ -162,6 +163,10 @@ def main():
         ms_tree += st["ms_tree"]
         ms_tables += st["ms_tables"]
         ms_sizes += st["ms_sizes"]
+        ms_tasks += st["ms_tasks"]
+        n_tasks += st["n_tasks"]
+        n_steps += st["n_steps"]
+        n_iters += st["n_iters"]
         launches += st["n_chunks"]
         table_bytes += st["table_bytes"]
         log(f"[rank {rank}] step stats: {st}")
@@ -204,7 +209,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "tree_kernel",
+                "kernel": "tree_kernel<G,false> (one wavefront per ligand)",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -213,7 +218,10 @@ def main():
                 "algorithmic_bytes_per_ligand": alg_bytes_per_ligand,
                 "ligands_per_launch": ligands_per_launch,
                 "kernel_ms_per_launch": {"sizes+scan": ms_sizes / max(launches, 1), "tables_kernel": ms_tables / max(launches, 1),
-                                         "tree_kernel": tree_ms_per_launch},
+                                         "tree_kernel": tree_ms_per_launch, "tree_kernel_task_rounds": ms_tasks / max(launches, 1)},
+                "tree_steps_per_ligand": n_steps / max(n_lig * args.steps, 1),
+                "busy_conformer_groups_per_wave": n_steps / max(n_iters, 1),
+                "subtree_tasks_per_ligand": n_tasks / max(n_lig * args.steps, 1),
                 "intermediate_table_bytes_per_ligand": table_bytes / max(n_lig * args.steps, 1),
             },
         }

@@ -125,7 +125,7 @@ int pmx_topk(const float *scores_dev, const uint64_t *index_dev, uint64_t n, uin
 
 /* Timing / diagnostics of the last pmx_score on this thread: kernel-time split measured with HIP events. */
 typedef struct {
-    double ms_sizes, ms_tables, ms_tree, ms_total;
+    double ms_sizes, ms_tables, ms_tree, ms_tasks, ms_total; /* sizes+scan | tables_kernel | tree_kernel per ligand | task rounds */
     uint64_t table_bytes;   /* bytes of intermediate pair-score tables written for the call */
     uint64_t n_chunks;
     uint64_t n_tasks;        /* subtrees handed to the task queue by over-budget tree walkers */
@@ -133,6 +133,8 @@ typedef struct {
     uint64_t queue_overflow; /* 1 if the task queue filled up (results stay exact; raise PMX_TASKQ_MB) */
     uint64_t n_steps;        /* tree-search steps (frame expansions, descents, leaf visits, returns) */
     uint64_t n_iters;        /* wavefront iterations of the tree kernels (n_steps / n_iters = busy conformer groups per wave) */
+    uint64_t max_iters_ligand; /* wavefront iterations of the longest per-ligand job / task job (tail diagnostics) */
+    uint64_t max_iters_task;
     uint64_t n_steps_first;  /* of which in the first (per-ligand) tree kernel of the first chunk with tasks */
 } pmx_score_stats;
 int pmx_score_stats_get(pmx_score_stats *out);

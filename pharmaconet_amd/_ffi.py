@@ -56,6 +56,7 @@ class ScoreStats(ctypes.Structure):
         ("ms_sizes", ctypes.c_double),
         ("ms_tables", ctypes.c_double),
         ("ms_tree", ctypes.c_double),
+        ("ms_tasks", ctypes.c_double),
         ("ms_total", ctypes.c_double),
         ("table_bytes", ctypes.c_uint64),
         ("n_chunks", ctypes.c_uint64),
@@ -64,6 +65,8 @@ class ScoreStats(ctypes.Structure):
         ("queue_overflow", ctypes.c_uint64),
         ("n_steps", ctypes.c_uint64),
         ("n_iters", ctypes.c_uint64),
+        ("max_iters_ligand", ctypes.c_uint64),
+        ("max_iters_task", ctypes.c_uint64),
         ("n_steps_first", ctypes.c_uint64),
     ]
 

@@ -243,7 +243,7 @@ struct Workspace {
     unsigned long long *bestbuf = nullptr; // [chunk_cap][64] per-conformer maxima of split ligands
     uint8_t *deferred = nullptr;           // [chunk_cap]
     int num_cu = 0;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 static std::map<int, Workspace> g_ws;
 static std::mutex g_mu;
@@ -288,7 +288,7 @@ static int ensure_workspace(int device, Workspace **out) {
         for (auto &ev : w.ev) HIPCHECK(hipEventCreate(&ev));
     }
     if (!w.queue) {
-        w.queue_bytes = (size_t)std::max<long>(16, env_long("PMX_TASKQ_MB", 1024)) << 20;
+        w.queue_bytes = (size_t)std::max<long>(16, env_long("PMX_TASKQ_MB", 4096)) << 20;
         HIPCHECK(hipMalloc((void **)&w.queue, w.queue_bytes));
     }
     *out = &w;
@@ -381,14 +381,13 @@ static int score_chunks(const pmx_model *model, const pmx_library *lib, const We
         {
             const int depth = std::max<int>(1, (int)max_levels);
             const int Kc = std::max(1, model->dm.K);
-            uint32_t tabcap = (uint32_t)std::max<long>(0, env_long("PMX_TABCAP", 8192));
+            uint32_t tabcap = (uint32_t)std::max<long>(0, env_long("PMX_TABCAP", 0));
             tabcap = (uint32_t)round16(tabcap);
             while (tabcap > 0 && tree_wave_bytes<G>(depth, Kc, tabcap) > 64 * 1024 - 512) tabcap -= std::min<uint32_t>(tabcap, 1024);
             const size_t lds = tree_wave_bytes<G>(depth, Kc, tabcap);
             if (lds > kLdsPerCu) return fail(PMX_ERR_INVALID, "tree state of %zu bytes does not fit LDS", lds);
             int waves_per_cu = (int)std::min<size_t>(16, kLdsPerCu / (lds + 256));
             waves_per_cu = std::max(1, waves_per_cu);
-            const uint32_t max_grid = (uint32_t)(ws.num_cu * waves_per_cu);
             TreeParams tp;
             tp.arena = ws.arena;
             tp.taboff = ws.taboff;
@@ -408,6 +407,7 @@ static int score_chunks(const pmx_model *model, const pmx_library *lib, const We
             tp.tabcap = tabcap;
             tp.budget = (uint32_t)std::max<long>(64, env_long("PMX_BUDGET", 2048));
             tp.scores = scores;
+            tp.min_levels = (uint32_t)std::max<long>(0, env_long("PMX_MIN_LEVELS", 4));
             tp.flags = (uint32_t)env_long("PMX_TREE_FLAGS", 0);
             tp.nsteps = reinterpret_cast<unsigned long long *>(ws.meta + 6);
             tp.dbg = ws.meta + 32;
@@ -416,6 +416,7 @@ static int score_chunks(const pmx_model *model, const pmx_library *lib, const We
             tree_kernel<G, false><<<dim3(n), dim3(64), lds, stream>>>(tp);
             HIPCHECK(hipGetLastError());
             TRACE("tree kernel launched");
+            if (g_profiling) HIPCHECK(hipEventRecord(ws.ev[3], stream));
             // rounds over the task queue: walkers that ran over budget appended subtrees
             uint32_t lo = 0;
             for (;;) {
@@ -445,6 +446,10 @@ static int score_chunks(const pmx_model *model, const pmx_library *lib, const We
                     g_stats.n_steps += ns;
                     std::memcpy(&ns, ws.meta_host + 8, 8);
                     g_stats.n_iters += ns;
+                    std::memcpy(&ns, ws.meta_host + 10, 8);
+                    g_stats.max_iters_ligand = std::max<uint64_t>(g_stats.max_iters_ligand, ns);
+                    std::memcpy(&ns, ws.meta_host + 12, 8);
+                    g_stats.max_iters_task = std::max<uint64_t>(g_stats.max_iters_task, ns);
                     break;
                 }
                 tp.count = hi - lo;
@@ -461,16 +466,18 @@ static int score_chunks(const pmx_model *model, const pmx_library *lib, const We
             }
         }
         if (g_profiling) {
-            HIPCHECK(hipEventRecord(ws.ev[3], stream));
-            HIPCHECK(hipEventSynchronize(ws.ev[3]));
-            float a = 0, b = 0, c = 0;
+            HIPCHECK(hipEventRecord(ws.ev[4], stream));
+            HIPCHECK(hipEventSynchronize(ws.ev[4]));
+            float a = 0, b = 0, c = 0, d = 0;
             HIPCHECK(hipEventElapsedTime(&a, ws.ev[0], ws.ev[1]));
             HIPCHECK(hipEventElapsedTime(&b, ws.ev[1], ws.ev[2]));
             HIPCHECK(hipEventElapsedTime(&c, ws.ev[2], ws.ev[3]));
+            HIPCHECK(hipEventElapsedTime(&d, ws.ev[3], ws.ev[4]));
             g_stats.ms_sizes += a;
             g_stats.ms_tables += b;
             g_stats.ms_tree += c;
-            g_stats.ms_total += a + b + c;
+            g_stats.ms_tasks += d;
+            g_stats.ms_total += a + b + c + d;
         }
         g_stats.table_bytes += table_total;
         g_stats.n_chunks += 1;
@@ -522,12 +529,15 @@ extern "C" int pmx_score_multi(const pmx_model *const *models, int n_models, con
         acc.ms_sizes += g_stats.ms_sizes;
         acc.ms_tables += g_stats.ms_tables;
         acc.ms_tree += g_stats.ms_tree;
+        acc.ms_tasks += g_stats.ms_tasks;
         acc.ms_total += g_stats.ms_total;
         acc.table_bytes += g_stats.table_bytes;
         acc.n_chunks += g_stats.n_chunks;
         acc.n_tasks += g_stats.n_tasks;
         acc.n_steps += g_stats.n_steps;
         acc.n_iters += g_stats.n_iters;
+        acc.max_iters_ligand = std::max(acc.max_iters_ligand, g_stats.max_iters_ligand);
+        acc.max_iters_task = std::max(acc.max_iters_task, g_stats.max_iters_task);
         acc.n_steps_first += g_stats.n_steps_first;
         acc.n_rounds += g_stats.n_rounds;
         acc.queue_overflow |= g_stats.queue_overflow;

@@ -389,6 +389,7 @@ struct TreeParams {
     int depth_cap;
     int K;               // model clusters (bound on candidates per level)
     uint32_t tabcap;     // LDS bytes reserved for one ligand's tables
+    uint32_t min_levels; // in export mode only subtrees with at least this many levels below their root are queued
     uint32_t flags;      // debug: 1 = no in-wave sharing, 2 = no global donation
     uint32_t budget;     // wave iterations after which a job donates its open subtrees to the queue
     unsigned long long *nsteps; // total DFS steps (diagnostics)
@@ -479,7 +480,7 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
     const int lane = threadIdx.x & 63;
     const int g = lane / G, c = lane % G;
     const int D = p.depth_cap, K = p.K;
-    const uint32_t budget = p.budget, qcap = p.qcap, flags = p.flags;
+    const uint32_t budget = p.budget, qcap = p.qcap, flags = p.flags, min_levels = p.min_levels;
     const unsigned long long max_iters = p.max_iters;
     uint32_t *const qtail = p.qtail;
     uint8_t *const queue = p.queue;
@@ -537,7 +538,7 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
     wave_lds_sync();
 
     // ---- walker state
-    bool busy = false, exported = false;
+    bool busy = false, exported = false, export_mode = false;
     int f = -1, f0 = 0, sfr = 1 << 20, sp = 0, C = 1;
     uint32_t iters = 0;
     unsigned long long nsteps = 0, total_iters = 0;
@@ -702,6 +703,9 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
                 }
             }
             if (__ballot(gave)) exported = true;
+            // From now on children that may be given away (>= 5 matches) go straight to the queue when the
+            // walker reaches them, so this wave only finishes the part of the tree it cannot split.
+            export_mode = true;
             // entries that did not fit stay on the local stack only if the queue was full; keep them
             if (!__builtin_amdgcn_readfirstlane((int)qtail[1])) sp = 0;
         }
@@ -757,6 +761,22 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
                     const int kf = hk[f], ksf = hksum[f];
                     const int b = __ffsll((unsigned long long)left) - 1;
                     todo[f] = left & (left - 1);
+                    bool handed_over = false;
+                    if (export_mode && nm >= 4 && nl - (f + 1) >= (int)min_levels) {
+                        uint32_t slot = 0;
+                        if (c == 0) slot = atomicAdd(qtail, 1u);
+                        slot = __shfl(slot, g * G);
+                        if (slot < qcap) {
+                            describe(reinterpret_cast<TaskHeader *>(queue + (size_t)slot * task_bytes<G>()), f, nm, b, cm[f * K + b]);
+                            F.y = F.y > 1 ? F.y : 1; // the child given away returns at least 1
+                            frm[f] = F;
+                            exported = true;
+                            handed_over = true;
+                        } else if (c == 0) {
+                            qtail[1] = 1; // queue full: walk it here
+                        }
+                    }
+                    if (!handed_over) {
                     // parent + self + accumulated pair (tree.py:38-41)
                     const double t = tot[nm * G + c] + (double)St[(size_t)(ksf + b) * G + c] + pair_sum<G>(Pt, mat, nm, ksf, kf, b, c);
                     tot[(nm + 1) * G + c] = t;
@@ -766,6 +786,7 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
                     ++f;
                     frm[f] = make_uchar4(0, 0, F_MATCHED, (unsigned char)(nm + 1));
                     if (f < sfr) sfr = f;
+                    }
                 } else if (!(F.z & F_SKIP) && (!(F.z & F_ANY) || (nm + F.y) < 5)) { // skip child (tree.py:98-101)
                     F.z |= F_SKIP;
                     frm[f] = F;
@@ -795,7 +816,9 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
     if (lane == 0) {
         atomicAdd(p.nsteps, nsteps);
         atomicAdd(p.nsteps + 1, total_iters);
+        atomicMax(p.nsteps + (TASKS ? 3 : 2), total_iters); // longest job of the launch (tail diagnostics)
     }
+    exported = __ballot(exported) != 0;
     if (TASKS || exported) { // split ligand: combine across waves, score comes from finalize_kernel
         if (g == 0 && best > 0.0) atomicMax(&p.bestbuf[(size_t)li * G + c], (unsigned long long)__double_as_longlong(best));
         if (!TASKS && lane == 0) p.deferred[li] = 1;
