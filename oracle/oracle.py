@@ -47,9 +47,21 @@ RESULT_DTYPE = np.dtype(
 
 
 def build(force: bool = False) -> Path:
+    import fcntl
+
     src = HERE / "pmx_oracle.c"
-    if force or not LIB_PATH.exists() or LIB_PATH.stat().st_mtime < src.stat().st_mtime:
-        subprocess.run(["make", "-C", str(HERE), "-B", "libpmx_oracle.so"], check=True, capture_output=True)
+
+    def stale():
+        return force or not LIB_PATH.exists() or LIB_PATH.stat().st_mtime < src.stat().st_mtime
+
+    if stale():
+        with open(HERE / ".build.lock", "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            try:
+                if stale():
+                    subprocess.run(["make", "-C", str(HERE), "-B", "libpmx_oracle.so"], check=True, capture_output=True)
+            finally:
+                fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
 
 

@@ -47,6 +47,20 @@ def _stale() -> bool:
 def build_native(force: bool = False, verbose: bool = False) -> Path:
     if not force and not _stale():
         return LIB
+    import fcntl
+
+    # several ranks may call build() at once (bench.py under torchrun): build under a lock, re-check after
+    with open(PKG / ".build.lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not _stale():
+                return LIB
+            return _build(verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build(verbose: bool) -> Path:
     cc = hipcc()
     objs = []
     for src in SOURCES:
@@ -57,10 +71,12 @@ def build_native(force: bool = False, verbose: bool = False) -> Path:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
         objs.append(str(obj))
-    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", str(LIB)]
+    tmp = LIB.with_suffix(".so.tmp")
+    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", str(tmp)]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
+    os.replace(tmp, LIB)
     return LIB
 
 

@@ -388,7 +388,7 @@ struct TreeParams {
     uint8_t *deferred;           // [chunk] ligand was split: score comes from bestbuf
     int depth_cap;
     int K;               // model clusters (bound on candidates per level)
-    uint32_t tabcap;     // LDS bytes reserved for one ligand's tables
+    uint32_t tabcap;     // LDS bytes reserved for one ligand's validity-mask table (0 = read it from the arena)
     uint32_t min_levels; // in export mode only subtrees with at least this many levels below their root are queued
     uint32_t flags;      // debug: 1 = no in-wave sharing, 2 = no global donation
     uint32_t budget;     // wave iterations after which a job donates its open subtrees to the queue
@@ -442,15 +442,19 @@ template <int G>
 __device__ inline double pair_sum(const float *Pt, const int2 *mat, int nm, int ksf, int kf, int b, int c) {
     double pair = 0.0;
     int q = 0;
+    for (; q + 8 <= nm; q += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = Pt[(size_t)(entry_base(mat[q + u], ksf, kf) + b) * G + c];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) pair += (double)v[u];
+    }
     for (; q + 4 <= nm; q += 4) {
-        const int i0 = entry_base(mat[q], ksf, kf) + b, i1 = entry_base(mat[q + 1], ksf, kf) + b;
-        const int i2 = entry_base(mat[q + 2], ksf, kf) + b, i3 = entry_base(mat[q + 3], ksf, kf) + b;
-        const float p0 = Pt[(size_t)i0 * G + c], p1 = Pt[(size_t)i1 * G + c];
-        const float p2 = Pt[(size_t)i2 * G + c], p3 = Pt[(size_t)i3 * G + c];
-        pair += (double)p0;
-        pair += (double)p1;
-        pair += (double)p2;
-        pair += (double)p3;
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = Pt[(size_t)(entry_base(mat[q + u], ksf, kf) + b) * G + c];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) pair += (double)v[u];
     }
     for (; q < nm; ++q) pair += (double)Pt[(size_t)(entry_base(mat[q], ksf, kf) + b) * G + c];
     return pair;
@@ -514,17 +518,18 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
     const uint32_t s_bytes = (uint32_t)round16(uint64_t(ksumtot) * G * 4);
     const uint32_t p_bytes = (uint32_t)round16(uint64_t(T) * G * 4);
     const unsigned char *tab = blk + sizeof(TabHeader);
-    if (INLDS) {
-        const uint32_t n16 = (v_bytes + s_bytes + p_bytes) / 16;
+    (void)p_bytes;
+    const vm_t *Vt = reinterpret_cast<const vm_t *>(tab);
+    if (INLDS) { // the validity masks (1 byte per pair entry at G <= 8) are small and read by every expansion
+        const uint32_t n16 = v_bytes / 16;
         const uint4 *src = reinterpret_cast<const uint4 *>(tab);
         uint4 *dst = reinterpret_cast<uint4 *>(smem);
         for (uint32_t i = lane; i < n16; i += 64) {
             PMX_GUARD(1);
             dst[i] = src[i];
         }
-        tab = smem;
+        Vt = reinterpret_cast<const vm_t *>(smem);
     }
-    const vm_t *Vt = reinterpret_cast<const vm_t *>(tab);
     const float *St = reinterpret_cast<const float *>(tab + v_bytes);
     const float *Pt = reinterpret_cast<const float *>(tab + v_bytes + s_bytes);
     for (int i = lane; i <= nl; i += 64) {
@@ -580,6 +585,43 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
     auto donatable = [&](int fr) -> bool {
         const uchar4 Fr = frm[fr];
         return Fr.w >= 4 && (Fr.z & F_EXPANDED) && todo[fr] != 0;
+    };
+
+    // Enter frame fr: evaluate every candidate of level fr against the matched ancestors (tree.py:78-84);
+    // lane c takes candidates c, c + G, ...; mask(b) = mask(parent) & AND_q V[entry(q, fr, b)].
+    auto expand = [&](int fr) {
+        uchar4 Fr = frm[fr];
+        const int nmr = Fr.w;
+        const int kr = hk[fr], ksr = hksum[fr];
+        uint64_t E = 0;
+        const vm_t pm = msk[nmr];
+        for (int b0 = 0; b0 < kr; b0 += G) {
+            const int b = b0 + c;
+            const bool on = b < kr;
+            const int bb = on ? b : 0;
+            vm_t m = on ? pm : (vm_t)0;
+            int q = 0;
+            for (; q + 8 <= nmr; q += 8) {
+                vm_t v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = Vt[entry_base(mat[q + u], ksr, kr) + bb];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) m &= v[u];
+            }
+            for (; q + 4 <= nmr; q += 4) {
+                const vm_t v0 = Vt[entry_base(mat[q], ksr, kr) + bb], v1 = Vt[entry_base(mat[q + 1], ksr, kr) + bb];
+                const vm_t v2 = Vt[entry_base(mat[q + 2], ksr, kr) + bb], v3 = Vt[entry_base(mat[q + 3], ksr, kr) + bb];
+                m &= (vm_t)(v0 & v1 & v2 & v3);
+            }
+            for (; q < nmr; ++q) m &= Vt[entry_base(mat[q], ksr, kr) + bb];
+            if (on) cm[fr * K + b] = m;
+            const unsigned long long bal = __ballot(on && m != 0);
+            E |= ((G == 64) ? bal : ((bal >> (g * G)) & ((1ull << G) - 1ull))) << b0;
+        }
+        wave_lds_sync();
+        todo[fr] = E;
+        Fr.z |= F_EXPANDED | (E ? F_ANY : 0);
+        frm[fr] = Fr;
     };
 
     if (g == 0) {
@@ -710,97 +752,87 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
             if (!__builtin_amdgcn_readfirstlane((int)qtail[1])) sp = 0;
         }
 
-        // ---- one DFS step per busy group
+        // ---- one DFS step per busy group: advance to (and through) the next frame expansion.
+        // Leaf children are consumed inside their parent's step; a step ends when a new frame has been
+        // entered and its candidates evaluated, or when the group's subtree is finished.
         if (busy) {
-            uchar4 F = frm[f];
-            const int nm = F.w;
-            const bool matched = F.z & F_MATCHED;
-            if (f == nl) { // leaf (tree.py:103-104): per-conformer maximum (graph_match.py:105-108)
-                const double t = tot[nm * G + c];
-                if (((msk[nm] >> c) & 1) && t > best) best = t;
-                --f;
-                if (f >= f0) {
-                    uchar4 Pf = frm[f];
-                    const unsigned char ret = matched ? 1 : 0;
-                    Pf.y = Pf.y > ret ? Pf.y : ret;
-                    frm[f] = Pf;
-                }
-            } else if (!(F.z & F_EXPANDED)) {
-                // evaluate every candidate of level f against the matched ancestors (tree.py:78-84)
-                const int kf = hk[f], ksf = hksum[f];
-                uint64_t E = 0;
-                const vm_t pm = msk[nm];
-                for (int b0 = 0; b0 < kf; b0 += G) {
-                    PMX_GUARD(9);
-                    const int b = b0 + c;
-                    const bool on = b < kf;
-                    const int bb = on ? b : 0;
-                    vm_t m = on ? pm : (vm_t)0;
-                    int q = 0;
-                    for (; q + 4 <= nm; q += 4) {
-                        PMX_GUARD(10);
-                        const vm_t v0 = Vt[entry_base(mat[q], ksf, kf) + bb], v1 = Vt[entry_base(mat[q + 1], ksf, kf) + bb];
-                        const vm_t v2 = Vt[entry_base(mat[q + 2], ksf, kf) + bb], v3 = Vt[entry_base(mat[q + 3], ksf, kf) + bb];
-                        m &= (vm_t)(v0 & v1 & v2 & v3);
-                    }
-                    for (; q < nm; ++q) {
-                        PMX_GUARD(11);
-                        m &= Vt[entry_base(mat[q], ksf, kf) + bb];
-                    }
-                    if (on) cm[f * K + b] = m;
-                    const unsigned long long bal = __ballot(on && m != 0);
-                    E |= ((G == 64) ? bal : ((bal >> (g * G)) & ((1ull << G) - 1ull))) << b0;
-                }
-                wave_lds_sync();
-                todo[f] = E;
-                F.z |= F_EXPANDED | (E ? F_ANY : 0);
-                frm[f] = F;
+            if (f < nl && !(frm[f].z & F_EXPANDED)) {
+                expand(f); // first step of a root (whole tree or adopted subtree)
             } else {
-                const uint64_t left = todo[f];
-                if (left) { // descend into the next existing candidate child (tree.py:94-97)
-                    const int kf = hk[f], ksf = hksum[f];
-                    const int b = __ffsll((unsigned long long)left) - 1;
-                    todo[f] = left & (left - 1);
-                    bool handed_over = false;
-                    if (export_mode && nm >= 4 && nl - (f + 1) >= (int)min_levels) {
-                        uint32_t slot = 0;
-                        if (c == 0) slot = atomicAdd(qtail, 1u);
-                        slot = __shfl(slot, g * G);
-                        if (slot < qcap) {
-                            describe(reinterpret_cast<TaskHeader *>(queue + (size_t)slot * task_bytes<G>()), f, nm, b, cm[f * K + b]);
-                            F.y = F.y > 1 ? F.y : 1; // the child given away returns at least 1
-                            frm[f] = F;
-                            exported = true;
-                            handed_over = true;
-                        } else if (c == 0) {
-                            qtail[1] = 1; // queue full: walk it here
-                        }
-                    }
-                    if (!handed_over) {
-                    // parent + self + accumulated pair (tree.py:38-41)
-                    const double t = tot[nm * G + c] + (double)St[(size_t)(ksf + b) * G + c] + pair_sum<G>(Pt, mat, nm, ksf, kf, b, c);
-                    tot[(nm + 1) * G + c] = t;
-                    msk[nm + 1] = cm[f * K + b];
-                    // entry(this match, level f', b') = rowbase[f] + k_f * (ksum[f'] - ksum[f + 1]) + b * k_f' + b'
-                    mat[nm] = make_int2((int)hrow[f] - kf * (int)hksum[f + 1], kf | (b << 8) | (f << 16));
-                    ++f;
-                    frm[f] = make_uchar4(0, 0, F_MATCHED, (unsigned char)(nm + 1));
-                    if (f < sfr) sfr = f;
-                    }
-                } else if (!(F.z & F_SKIP) && (!(F.z & F_ANY) || (nm + F.y) < 5)) { // skip child (tree.py:98-101)
-                    F.z |= F_SKIP;
-                    frm[f] = F;
-                    ++f;
-                    frm[f] = make_uchar4(0, 0, 0, (unsigned char)nm);
-                    if (f < sfr) sfr = f;
-                } else { // all children done: return max_num_matches + matched (tree.py:102)
-                    const unsigned char ret = (unsigned char)(F.y + (matched ? 1 : 0));
-                    --f;
-                    if (f >= f0) {
+                for (;;) {
+                    PMX_GUARD(13);
+                    uchar4 F = frm[f];
+                    const int nm = F.w;
+                    const bool matched = F.z & F_MATCHED;
+                    if (f == nl) { // a subtree root that is itself a leaf (tree.py:103-104)
+                        const double t = tot[nm * G + c];
+                        if (((msk[nm] >> c) & 1) && t > best) best = t;
+                        --f;
+                        if (f < f0) break;
                         uchar4 Pf = frm[f];
+                        const unsigned char ret = matched ? 1 : 0;
                         Pf.y = Pf.y > ret ? Pf.y : ret;
                         frm[f] = Pf;
+                        continue;
                     }
+                    const uint64_t left = todo[f];
+                    if (left) { // next existing candidate child (tree.py:94-97)
+                        const int kf = hk[f], ksf = hksum[f];
+                        const int b = __ffsll((unsigned long long)left) - 1;
+                        todo[f] = left & (left - 1);
+                        if (export_mode && nm >= 4 && nl - (f + 1) >= (int)min_levels) {
+                            uint32_t slot = 0;
+                            if (c == 0) slot = atomicAdd(qtail, 1u);
+                            slot = __shfl(slot, g * G);
+                            if (slot < qcap) {
+                                describe(reinterpret_cast<TaskHeader *>(queue + (size_t)slot * task_bytes<G>()), f, nm, b, cm[f * K + b]);
+                                F.y = F.y > 1 ? F.y : 1; // the child given away returns at least 1
+                                frm[f] = F;
+                                exported = true;
+                                continue;
+                            }
+                            if (c == 0) qtail[1] = 1; // queue full: walk it here
+                        }
+                        const vm_t m = cm[f * K + b];
+                        // parent + self + accumulated pair (tree.py:38-41)
+                        const double t = tot[nm * G + c] + (double)St[(size_t)(ksf + b) * G + c] + pair_sum<G>(Pt, mat, nm, ksf, kf, b, c);
+                        if (f + 1 == nl) { // the child is a leaf: per-conformer maximum (graph_match.py:105-108), returns 1
+                            if (((m >> c) & 1) && t > best) best = t;
+                            F.y = F.y > 1 ? F.y : 1;
+                            frm[f] = F;
+                            continue;
+                        }
+                        tot[(nm + 1) * G + c] = t;
+                        msk[nm + 1] = m;
+                        // entry(this match, level f', b') = rowbase[f] + k_f * (ksum[f'] - ksum[f + 1]) + b * k_f' + b'
+                        mat[nm] = make_int2((int)hrow[f] - kf * (int)hksum[f + 1], kf | (b << 8) | (f << 16));
+                        ++f;
+                        frm[f] = make_uchar4(0, 0, F_MATCHED, (unsigned char)(nm + 1));
+                        if (f < sfr) sfr = f;
+                        expand(f);
+                        break;
+                    }
+                    if (!(F.z & F_SKIP) && (!(F.z & F_ANY) || (nm + F.y) < 5)) { // skip child (tree.py:98-101)
+                        F.z |= F_SKIP;
+                        frm[f] = F;
+                        if (f + 1 == nl) { // a skip leaf carries this node's totals (tree.py:42-43) and returns 0
+                            const double t = tot[nm * G + c];
+                            if (((msk[nm] >> c) & 1) && t > best) best = t;
+                            continue;
+                        }
+                        ++f;
+                        frm[f] = make_uchar4(0, 0, 0, (unsigned char)nm);
+                        if (f < sfr) sfr = f;
+                        expand(f);
+                        break;
+                    }
+                    // all children done: return max_num_matches + matched (tree.py:102)
+                    const unsigned char ret = (unsigned char)(F.y + (matched ? 1 : 0));
+                    --f;
+                    if (f < f0) break;
+                    uchar4 Pf = frm[f];
+                    Pf.y = Pf.y > ret ? Pf.y : ret;
+                    frm[f] = Pf;
                 }
             }
             if (f < f0) busy = false;
@@ -860,7 +892,7 @@ __global__ __launch_bounds__(64) void tree_kernel(const TreeParams p) {
         if (lane == 0) p.scores[li] = __builtin_nanf("");
     } else if (bytes == 0) { // no ligand cluster has a candidate (graph_match.py:95-99)
         if (!TASKS && lane == 0) p.scores[li] = 0.f;
-    } else if (bytes - (uint32_t)sizeof(TabHeader) <= p.tabcap) {
+    } else if ((uint32_t)round16((uint64_t)__builtin_amdgcn_readfirstlane(reinterpret_cast<const TabHeader *>(blk)->T) * sizeof(vmask_t<G>)) <= p.tabcap) {
         run_job<G, TASKS, true>(p, smem, li, task, blk);
     } else {
         run_job<G, TASKS, false>(p, smem, li, task, blk);
