@@ -323,6 +323,8 @@ static int score_chunks(const pmx_model *model, const pmx_library *lib, const We
     if (!attr_set) {
         HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&tables_kernel<G>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));
+        HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&tables_kernel_v2<G>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));
         HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&tree_kernel<G, false>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));
         HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&tree_kernel<G, true>),
@@ -359,9 +361,20 @@ static int score_chunks(const pmx_model *model, const pmx_library *lib, const We
         }
         if (g_profiling) HIPCHECK(hipEventRecord(ws.ev[1], stream));
         if (table_total > 0) {
-            const uint32_t groups_per_block = tab_waves * GPW;
-            tables_kernel<G><<<dim3((n + groups_per_block - 1) / groups_per_block), dim3(64 * tab_waves), tab_lds, stream>>>(
-                model->dm, lib->dl, W, lig0, n, status, ws.taboff, ws.arena);
+            static const bool force_v1 = std::getenv("PMX_TABLES_V1") != nullptr;
+            const size_t model_lds = (size_t)Nm * Nm * sizeof(float4) + 64 * 8 + 128 * 8;
+            int v2_waves = 0; // waves (= ligands) per block that fit the 160 KB of LDS next to the model tables
+            if (model_lds + tables_v2_wave_bytes<G>() + 1024 <= kLdsPerCu)
+                v2_waves = (int)std::min<size_t>(tab_waves, (kLdsPerCu - 1024 - model_lds) / tables_v2_wave_bytes<G>());
+            if (force_v1 || v2_waves < 1) {
+                const uint32_t groups_per_block = tab_waves * GPW;
+                tables_kernel<G><<<dim3((n + groups_per_block - 1) / groups_per_block), dim3(64 * tab_waves), tab_lds, stream>>>(
+                    model->dm, lib->dl, W, lig0, n, status, ws.taboff, ws.arena);
+            } else {
+                const size_t lds2 = model_lds + (size_t)v2_waves * tables_v2_wave_bytes<G>();
+                tables_kernel_v2<G><<<dim3((n + v2_waves - 1) / v2_waves), dim3(64 * v2_waves), lds2, stream>>>(
+                    model->dm, lib->dl, W, lig0, n, status, ws.taboff, ws.arena);
+            }
             HIPCHECK(hipGetLastError());
             if (trace_on()) {
                 TRACE("tables kernel launched (%u bytes of tables)", (unsigned)table_total);
@@ -407,6 +420,7 @@ static int score_chunks(const pmx_model *model, const pmx_library *lib, const We
             tp.tabcap = tabcap;
             tp.budget = (uint32_t)std::max<long>(64, env_long("PMX_BUDGET", 2048));
             tp.scores = scores;
+            tp.share_levels = (uint32_t)std::max<long>(0, env_long("PMX_SHARE_LEVELS", 1));
             tp.min_levels = (uint32_t)std::max<long>(0, env_long("PMX_MIN_LEVELS", 4));
             tp.flags = (uint32_t)env_long("PMX_TREE_FLAGS", 0);
             tp.nsteps = reinterpret_cast<unsigned long long *>(ws.meta + 6);

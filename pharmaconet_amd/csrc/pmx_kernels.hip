@@ -105,6 +105,14 @@ __global__ void scan_kernel(const uint32_t *units, uint32_t count, uint64_t *tab
     }
 }
 
+// Cross-lane hand-off through LDS inside one wavefront: DS operations of a wave execute in order, but
+// accesses made through generic pointers are FLAT instructions, which travel another path and may pass
+// (or be passed by) DS operations. Drain both counters before another lane's data is consumed.
+__device__ inline void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+}
+
 // ---------------------------------------------------------------------------------- tables_kernel
 struct GroupLevels { // per conformer group, in LDS
     uint64_t cand[PMX_MAX_LEVELS];
@@ -325,6 +333,215 @@ __global__ __launch_bounds__(256) void tables_kernel(DevModel M, DevLibrary lib,
     }
 }
 
+// ------------------------------------------------------------------------------- tables_kernel_v2
+// Same tables as tables_kernel, organised for lane utilisation: ONE wavefront per ligand. Within a pair of
+// ligand clusters (i, j) the work is the flat list of items (entry (a, b), ligand node u, ligand node v);
+// the wave's 64 / G lane groups ("slots") take consecutive items, lane c of a slot its conformer c, and
+// add the item's likelihood and fail flag into per-entry LDS accumulators (ds_add). Consecutive items
+// share (a, b) and so have the same number of model node pairs: the slots of a wave stay balanced, and
+// all lanes walk the same ligand, so there is no divergence between ligands.
+constexpr int kTabEntryChunk = 64; // entries accumulated in LDS at a time
+
+struct WaveLevels { // per wave, in LDS
+    uint64_t cand[PMX_MAX_LEVELS];
+    uint8_t start[PMX_MAX_LEVELS];
+    uint8_t end[PMX_MAX_LEVELS];
+    uint8_t k[PMX_MAX_LEVELS];
+    uint8_t pad[4];
+    uint8_t candlist[PMX_MAX_LEVELS][PMX_MAX_MODEL_CLUSTERS]; // slot -> model cluster id
+};
+static_assert(sizeof(WaveLevels) % 16 == 0, "WaveLevels alignment");
+
+template <int G>
+__host__ __device__ constexpr uint32_t tables_v2_wave_bytes() {
+    return sizeof(WaveLevels) + kTabEntryChunk * G * 8;
+}
+
+template <int G>
+__global__ __launch_bounds__(256) void tables_kernel_v2(DevModel M, DevLibrary lib, Weights W, uint64_t first, uint32_t count,
+                                                        const int32_t *status, const uint64_t *taboff, uint8_t *arena) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int GPW = 64 / G; // slots per wave
+    const int Nm = M.Nm;
+    float4 *tab = reinterpret_cast<float4 *>(smem);
+    uint64_t *cnodes = reinterpret_cast<uint64_t *>(smem + (size_t)Nm * Nm * sizeof(float4));
+    uint64_t *tnodes = cnodes + 64;
+    unsigned char *wave_base = reinterpret_cast<unsigned char *>(tnodes + 128) + (size_t)(threadIdx.x >> 6) * tables_v2_wave_bytes<G>();
+    WaveLevels &WL = *reinterpret_cast<WaveLevels *>(wave_base);
+    float *acc_score = reinterpret_cast<float *>(wave_base + sizeof(WaveLevels)); // [kTabEntryChunk][G]
+    unsigned *acc_fail = reinterpret_cast<unsigned *>(acc_score + kTabEntryChunk * G);
+
+    for (int i = threadIdx.x; i < Nm * Nm; i += blockDim.x) {
+        float4 e = M.edge[i];
+        const float wm = W.w[M.node_type[i / Nm]], wn = W.w[M.node_type[i % Nm]];
+        e.w = (wm * wn) / e.w; // weights / stds (match_utils.py:65)
+        tab[i] = e;
+    }
+    for (int i = threadIdx.x; i < 64; i += blockDim.x) cnodes[i] = M.cnodes[i];
+    for (int i = threadIdx.x; i < 128; i += blockDim.x) tnodes[i] = M.tnodes[i];
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int s = lane / G, c = lane % G;
+    const uint64_t gid = (uint64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6); // ligand of this wave
+    if (gid >= count) return;
+    if (status[gid] != PMX_LIGAND_OK) return;
+    const uint64_t off = taboff[gid];
+    if (taboff[gid + 1] == off) return;
+
+    const Record r = parse_record(lib.data + lib.offsets[first + gid]);
+    const int C = r.C;
+    const int cc = c < C ? c : C - 1;
+    const bool lane_live = c < C;
+    const unsigned long long slot_mask = (G == 64) ? ~0ull : (((1ull << G) - 1ull) << (s * G));
+    const Levels L = scan_levels(r, M.tclus, [&](int lev, int start, int end, uint64_t cand, uint32_t k) {
+        WL.cand[lev] = cand;
+        WL.start[lev] = (uint8_t)start;
+        WL.end[lev] = (uint8_t)end;
+        WL.k[lev] = (uint8_t)k;
+    });
+    const int nl = L.nl;
+    for (int lev = 0; lev < nl; ++lev) { // candidate slot -> cluster id
+        uint64_t cand = WL.cand[lev];
+        for (int q = 0; cand; cand &= cand - 1, ++q) WL.candlist[lev][q] = (uint8_t)(__ffsll((unsigned long long)cand) - 1);
+    }
+    for (int i = lane; i < kTabEntryChunk * G; i += 64) {
+        acc_score[i] = 0.f;
+        acc_fail[i] = 0u;
+    }
+
+    uint8_t *blk = arena + off;
+    TabHeader *H = reinterpret_cast<TabHeader *>(blk);
+    vmask_t<G> *Vt = reinterpret_cast<vmask_t<G> *>(blk + sizeof(TabHeader));
+    float *St = reinterpret_cast<float *>(blk + sizeof(TabHeader) + round16(uint64_t(L.T) * sizeof(vmask_t<G>)));
+    float *Pt = St + round16(uint64_t(L.ksumtot) * G * 4) / 4;
+    H->nl = (uint32_t)nl;
+    H->T = L.T;
+    H->ksumtot = L.ksumtot;
+    H->pad = 0;
+    {
+        uint32_t ks = 0, rb = 0;
+        for (int i = 0; i < nl; ++i) {
+            const uint32_t k = WL.k[i];
+            H->k[i] = (uint8_t)k;
+            H->ksum[i] = (uint16_t)ks;
+            H->rowbase[i] = rb;
+            ks += k;
+            rb += k * (L.ksumtot - ks);
+        }
+        H->ksum[nl] = (uint16_t)ks;
+    }
+    wave_lds_sync();
+
+    const float *xyz = r.xyz;
+    const uint8_t *tm = r.typemask;
+    uint32_t self_base = 0, pair_base = 0;
+    for (int i = 0; i < nl; ++i) {
+        const int si = WL.start[i], ni = WL.end[i] - si, ki = WL.k[i];
+        Pos ctr_i;
+        float size_i;
+        cluster_center_size(xyz, C, si, si + ni, cc, ctr_i, size_i);
+
+        // ---- self table S[i][a] (match_utils.py:77-122): items (a, u < v)
+        for (int e0 = 0; e0 < ki; e0 += kTabEntryChunk) {
+            const int ecur = min(kTabEntryChunk, ki - e0);
+            if (ni > 1) {
+                const int per = ni * ni; // walk all (u, v), keep u < v
+                const int total = ecur * per;
+                for (int t = s; t < total; t += GPW) {
+                    const int e = t / per, rr = t - e * per;
+                    const int u = rr / ni, v = rr - u * ni;
+                    if (u >= v) continue;
+                    const uint64_t nodes_a = cnodes[WL.candlist[i][e0 + e]];
+                    const uint64_t A = nodes_a & tnodes[tm[si + u]], B = nodes_a & tnodes[tm[si + v]];
+                    if (!A || !B) continue;
+                    const Pos pu = load_pos(xyz, C, si + u, cc), pv = load_pos(xyz, C, si + v, cc);
+                    const float d = norm3(pu.x - pv.x, pu.y - pv.y, pu.z - pv.z);
+                    float acc = 0.f;
+                    int np = 0;
+                    node_pair(tab, Nm, A, B, d, acc, np);
+                    atomicAdd(&acc_score[e * G + c], acc / (float)(__popcll(A) * __popcll(B)));
+                }
+            }
+            wave_lds_sync();
+            for (int e = s; e < ecur; e += GPW) {
+                St[(size_t)(self_base + e0 + e) * G + c] = acc_score[e * G + c];
+                acc_score[e * G + c] = 0.f;
+            }
+            wave_lds_sync();
+        }
+        self_base += ki;
+
+        for (int j = i + 1; j < nl; ++j) {
+            const int sj = WL.start[j], nj = WL.end[j] - sj, kj = WL.k[j];
+            Pos ctr_j;
+            float size_j;
+            cluster_center_size(xyz, C, sj, sj + nj, cc, ctr_j, size_j);
+            const float ldist = norm3(ctr_i.x - ctr_j.x, ctr_i.y - ctr_j.y, ctr_i.z - ctr_j.z); // graph_match.py:240
+            const float lsize = size_i + size_j;                                                 // :241
+            const int E = ki * kj, per = ni * nj;
+            for (int e0 = 0; e0 < E; e0 += kTabEntryChunk) {
+                const int ecur = min(kTabEntryChunk, E - e0);
+                const int total = ecur * per;
+                for (int t = s; t < total; t += GPW) {
+                    const int e = t / per, rr = t - e * per;
+                    const int u = rr / nj, v = rr - u * nj;
+                    const int ea = (e0 + e) / kj, eb = (e0 + e) - ea * kj;
+                    const int a = WL.candlist[i][ea], b = WL.candlist[j][eb];
+                    // cluster-distance prefilter (graph_match.py:263-268), per entry, any conformer
+                    const float2 mp = M.cpair[a * M.K + b];
+                    const bool near = lane_live && !((fabsf(ldist - mp.x) - lsize) > mp.y);
+                    if (!(__ballot(near) & slot_mask)) continue;
+                    const uint64_t A = cnodes[a] & tnodes[tm[si + u]], B = cnodes[b] & tnodes[tm[sj + v]];
+                    if (!A || !B) continue;
+                    const Pos pu = load_pos(xyz, C, si + u, cc), pv = load_pos(xyz, C, sj + v, cc);
+                    const float d = norm3(pu.x - pv.x, pu.y - pv.y, pu.z - pv.z);
+                    float acc = 0.f;
+                    int np = 0;
+                    node_pair(tab, Nm, A, B, d, acc, np);
+                    const int mn = __popcll(A) * __popcll(B);
+                    atomicAdd(&acc_score[e * G + c], acc / (float)mn);
+                    if (2 * np < mn) atomicAdd(&acc_fail[e * G + c], 1u); // num_pass < num_match * 0.5 (match_utils.py:61)
+                }
+                wave_lds_sync();
+                // finish the entries of this chunk: slots take entries, lane c its conformer
+                for (int e1 = 0; e1 < ecur; e1 += GPW) {
+                    const int e = e1 + s;
+                    const bool on = e < ecur;
+                    float value = -1.f;
+                    bool valid = false;
+                    if (on) {
+                        const int ea = (e0 + e) / kj, eb = (e0 + e) - ea * kj;
+                        const int a = WL.candlist[i][ea], b = WL.candlist[j][eb];
+                        const float2 mp = M.cpair[a * M.K + b];
+                        const bool near = lane_live && !((fabsf(ldist - mp.x) - lsize) > mp.y);
+                        const bool near_any = (__ballot(near) & slot_mask) != 0;
+                        int L1 = 0, L2 = 0; // ligand nodes with a compatible model node (graph_match.py:164-171)
+                        for (int u = 0; u < ni; ++u) L1 += (cnodes[a] & tnodes[tm[si + u]]) ? 1 : 0;
+                        for (int v = 0; v < nj; ++v) L2 += (cnodes[b] & tnodes[tm[sj + v]]) ? 1 : 0;
+                        const float score = acc_score[e * G + c];
+                        const int fails = (int)acc_fail[e * G + c];
+                        acc_score[e * G + c] = 0.f;
+                        acc_fail[e * G + c] = 0u;
+                        if (near_any) {
+                            valid = lane_live && (2 * fails <= L1 * L2) && (score > 0.f); // match_utils.py:71-74, tree.py:81
+                            value = (2 * fails <= L1 * L2) ? score : -1.f;
+                        }
+                    }
+                    const unsigned long long vbal = __ballot(valid);
+                    if (on) {
+                        const uint32_t idx = pair_base + (uint32_t)(e0 + e);
+                        Pt[(size_t)idx * G + c] = value;
+                        Vt[idx] = (vmask_t<G>)((G == 64) ? vbal : ((vbal >> (s * G)) & ((1ull << G) - 1ull)));
+                    }
+                }
+                wave_lds_sync();
+            }
+            pair_base += (uint32_t)E;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------ tree_kernel
 // Iterative form of ClusterMatchTree.dfs_run (tree.py:55-104). A frame f describes the tree node at
 // level f - 1 (frame 0 = root): `todo` = existing candidate children of level f not yet explored,
@@ -389,6 +606,7 @@ struct TreeParams {
     int depth_cap;
     int K;               // model clusters (bound on candidates per level)
     uint32_t tabcap;     // LDS bytes reserved for one ligand's validity-mask table (0 = read it from the arena)
+    uint32_t share_levels; // in-wave sharing hands over only subtrees with at least this many levels below their root
     uint32_t min_levels; // in export mode only subtrees with at least this many levels below their root are queued
     uint32_t flags;      // debug: 1 = no in-wave sharing, 2 = no global donation
     uint32_t budget;     // wave iterations after which a job donates its open subtrees to the queue
@@ -422,14 +640,6 @@ template <int G>
 __host__ __device__ inline uint32_t tree_wave_bytes(int depth, int K, uint32_t tabcap) {
     return (uint32_t)round16(tabcap) + kTreeSharedHdr + tree_local_stack_entries<G>() * task_bytes<G>() +
            (64 / G) * tree_group_bytes<G>(depth, K);
-}
-
-// Cross-lane hand-off through LDS inside one wavefront: DS operations of a wave execute in order, but
-// accesses made through generic pointers are FLAT instructions, which travel another path and may pass
-// (or be passed by) DS operations. Drain both counters before another lane's data is consumed.
-__device__ inline void wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 }
 
 // Pair-table index of (matched ancestor q, candidate 0 of level f): + b gives candidate b.
@@ -484,7 +694,7 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
     const int lane = threadIdx.x & 63;
     const int g = lane / G, c = lane % G;
     const int D = p.depth_cap, K = p.K;
-    const uint32_t budget = p.budget, qcap = p.qcap, flags = p.flags, min_levels = p.min_levels;
+    const uint32_t budget = p.budget, qcap = p.qcap, flags = p.flags, min_levels = p.min_levels, share_levels = p.share_levels;
     const unsigned long long max_iters = p.max_iters;
     uint32_t *const qtail = p.qtail;
     uint8_t *const queue = p.queue;
@@ -669,7 +879,8 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
                         if (Fs.w < 4 || ((Fs.z & F_EXPANDED) && todo[sfr] == 0)) ++sfr;
                         else break;
                     }
-                    can = sfr <= f && sfr < nl && donatable(sfr);
+                    // children too close to the leaves are cheaper to walk than to hand over
+                    can = sfr <= f && sfr < nl && nl - (sfr + 1) >= (int)share_levels && donatable(sfr);
                 }
                 const unsigned long long don_bal = __ballot(can && c == 0);
                 const int rank = __popcll(don_bal & below);
