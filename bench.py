@@ -193,6 +193,17 @@ def main():
         dominant = max(per_chunk, key=per_chunk.get)
         dom_ms = per_chunk[dominant]
         achieved = (alg_bytes_per_ligand * ligands_per_launch) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        # HBM traffic of the dominant kernel per launch, from the committed PMC passes (FETCH_SIZE / WRITE_SIZE,
+        # collected separately with rocprofv3 --pmc and corrected as MI355X_MICROARCH.md prescribes)
+        traffic = None
+        try:
+            pmc = json.loads((REPO / "profiles" / "r1_hbm_traffic.json").read_text())
+            key = {"tables_kernel": "pmx::tables_kernel_v2<8>", "tree_kernel<G,false>": "pmx::tree_kernel<8, false>",
+                   "tree_kernel<G,true>": "pmx::tree_kernel<8, true>"}[dominant.split(" ")[0]]
+            if args.conformers == 8:
+                traffic = pmc["kernels"][key]["hbm_bytes_per_ligand"] * ligands_per_launch
+        except Exception:
+            traffic = None
         out = {
             "metric": "ligand-conformers scored/sec (1 pocket)",
             "value": value,
@@ -220,7 +231,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_note": "HBM bytes per launch from profiles/r1_hbm_traffic.json (separate rocprofv3 --pmc passes); null if unavailable",
                 "algorithmic_bytes_per_ligand": alg_bytes_per_ligand,
                 "ligands_per_launch": ligands_per_launch,
                 "kernel_ms_per_launch": {"sizes+scan": ms_sizes / max(launches, 1), **per_chunk},
