@@ -1,0 +1,94 @@
+"""`python -m pharmaconet_amd.screening` - drop-in for the reference's `screening.py`.
+
+Same flags (`screening.py:9-43`): `-p/--pharmacophore_model`, `-d/--library_dir`, `-o/--out`, `--cpus`, and the seven
+type weights. `--library_dir` may be a directory of `.sdf` / `.mol2` files (perceived and packed on `--cpus` host
+processes; needs OpenBabel like the reference) or a packed library file (`.pmxlib`, see
+`pharmaconet_amd.library`) with an optional `<library>.names` text file giving one path per ligand.
+Output: `path,score` CSV, best first, ties in library order (`screening.py:70-75`). Scoring runs on the GPU.
+"""
+
+from __future__ import annotations
+
+import argparse
+import multiprocessing
+from pathlib import Path
+
+import numpy as np
+
+from .library import PackedLibrary
+from .pharmacophore_model import PharmacophoreModel
+
+
+class Screening_ArgParser(argparse.ArgumentParser):
+    def __init__(self):
+        super().__init__("scoring")
+        self.formatter_class = argparse.ArgumentDefaultsHelpFormatter
+        cfg = self.add_argument_group("config")
+        cfg.add_argument("-p", "--pharmacophore_model", type=str, required=True, help="path of pharmacophore model (.pm | .json)")
+        cfg.add_argument("-d", "--library_dir", type=str, required=True, help="molecular library directory, or a packed .pmxlib file")
+        cfg.add_argument("-o", "--out", type=str, required=True, help="result file path")
+        cfg.add_argument("--cpus", type=int, default=1, help="host processes for reading / packing molecule files")
+        par = self.add_argument_group("parameter")
+        par.add_argument("--hydrophobic", type=float, default=1.0, help="weight for hydrophobic carbon")
+        par.add_argument("--aromatic", type=float, default=4.0, help="weight for aromatic ring")
+        par.add_argument("--hba", type=float, default=4.0, help="weight for hbond acceptor")
+        par.add_argument("--hbd", type=float, default=4.0, help="weight for hbond donor")
+        par.add_argument("--halogen", type=float, default=4.0, help="weight for halogen atom")
+        par.add_argument("--anion", type=float, default=8.0, help="weight for anion")
+        par.add_argument("--cation", type=float, default=8.0, help="weight for cation")
+
+
+def _pack_file(path: str) -> bytes:
+    from .library import pack_ligand
+    from .ligand import Ligand
+
+    return pack_ligand(Ligand.load_from_file(path).features)
+
+
+def load_library(library: Path, cpus: int) -> tuple[list[str], PackedLibrary]:
+    if library.is_file():
+        lib = PackedLibrary.load(library)
+        names_file = Path(str(library) + ".names")
+        if names_file.exists():
+            names = names_file.read_text().splitlines()
+            if len(names) != len(lib):
+                raise ValueError(f"{names_file}: {len(names)} names for {len(lib)} ligands")
+        else:
+            names = [f"{library}#{i}" for i in range(len(lib))]
+        return names, lib
+    file_list = list(library.rglob("*.sdf")) + list(library.rglob("*.mol2"))  # screening.py:63-64
+    print(f"find {len(file_list)} molecules")
+    with multiprocessing.Pool(cpus) as pool:
+        records = pool.map(_pack_file, [str(f) for f in file_list])
+    return [str(f) for f in file_list], PackedLibrary.from_records(records)
+
+
+def write_csv(out: Path, names: list[str], scores: np.ndarray) -> None:
+    """`result.sort(key=score, reverse=True)` (stable) then `path,score` lines (screening.py:70-75).
+    Scores print with Python's float repr of the float32 value the GPU returned."""
+    order = np.lexsort((np.arange(len(scores)), -scores.astype(np.float64)))
+    with open(out, "w") as w:
+        w.write("path,score\n")
+        for i in order:
+            w.write(f"{names[i]},{float(scores[i])}\n")
+
+
+def main(argv=None) -> None:
+    args = Screening_ArgParser().parse_args(argv)
+    model = PharmacophoreModel.load(args.pharmacophore_model)
+    weight = dict(
+        Cation=args.cation,
+        Anion=args.anion,
+        Aromatic=args.aromatic,
+        HBond_donor=args.hbd,
+        HBond_acceptor=args.hba,
+        Halogen=args.halogen,
+        Hydrophobic=args.hydrophobic,
+    )
+    names, lib = load_library(Path(args.library_dir), args.cpus)
+    result = model.screen(lib, weights=weight)
+    write_csv(Path(args.out), names, result.scores.cpu().numpy())
+
+
+if __name__ == "__main__":
+    main()

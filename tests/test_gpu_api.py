@@ -137,3 +137,28 @@ def test_order_and_partition_invariance_large():
     recs = [dat[off[i] : off[i + 1]].tobytes() for i in range(n)]
     rev = model.screen(PackedLibrary.from_records(recs[::-1])).scores
     assert torch.equal(rev.flip(0), full[:n])
+
+
+def test_screening_cli_writes_the_reference_csv(tmp_path):
+    """`python -m pharmaconet_amd.screening` (screening.py:50-75): CSV sorted like the reference would."""
+    from conftest import GOLDEN
+    from pharmaconet_amd.screening import main
+
+    model, lib, weights, d = load_golden("set_6oim_c8_weights")
+    libfile = tmp_path / "lib.pmxlib"
+    lib.save(libfile)
+    (tmp_path / "lib.pmxlib.names").write_text("\n".join(f"mol_{i}.sdf" for i in range(len(lib))))
+    out = tmp_path / "out.csv"
+    main(["-p", str(GOLDEN / "model_6oim_like.pm"), "-d", str(libfile), "-o", str(out), "--hbd", "5", "--hba", "5", "--aromatic", "8"])
+    lines = out.read_text().splitlines()
+    assert lines[0] == "path,score" and len(lines) == len(lib) + 1
+    names = [ln.split(",")[0] for ln in lines[1:]]
+    scores = np.array([float(ln.split(",")[1]) for ln in lines[1:]])
+    assert np.all(np.diff(scores) <= 0)
+    ref = d["score"]
+    want = sorted(range(len(ref)), key=lambda i: ref[i], reverse=True)
+    # same ranking as the reference wherever reference scores differ by more than the float32 resolution
+    got_idx = [int(n.split("_")[1].split(".")[0]) for n in names]
+    for pos, (g, w) in enumerate(zip(got_idx, want)):
+        assert g == w or abs(ref[g] - ref[w]) <= 2e-6 * abs(ref[w]), pos
+    assert rel_err(scores, ref[got_idx]).max() < 2e-6 + 6e-8
