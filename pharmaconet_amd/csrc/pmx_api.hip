@@ -425,7 +425,7 @@ static int score_chunks(const pmx_model *model, const pmx_library *lib, const We
             tp.flags = (uint32_t)env_long("PMX_TREE_FLAGS", 0);
             tp.nsteps = reinterpret_cast<unsigned long long *>(ws.meta + 6);
             tp.dbg = ws.meta + 32;
-            tp.max_iters = (unsigned long long)std::max<long>(1, env_long("PMX_MAXITERS", 1L << 40));
+            tp.max_iters = (unsigned long long)std::max<long>(1, env_long("PMX_MAXITERS", 1L << 31));
             TRACE("tree kernel: grid=%u lds=%zu tabcap=%u depth=%d waves/cu=%d", n, lds, tabcap, depth, waves_per_cu);
             tree_kernel<G, false><<<dim3(n), dim3(64), lds, stream>>>(tp);
             HIPCHECK(hipGetLastError());

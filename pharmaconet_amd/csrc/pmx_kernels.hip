@@ -354,7 +354,7 @@ static_assert(sizeof(WaveLevels) % 16 == 0, "WaveLevels alignment");
 
 template <int G>
 __host__ __device__ constexpr uint32_t tables_v2_wave_bytes() {
-    return sizeof(WaveLevels) + kTabEntryChunk * G * 8;
+    return sizeof(WaveLevels) + kTabEntryChunk * G * 8 + kTabEntryChunk; // levels, accumulators, near-entry list
 }
 
 template <int G>
@@ -370,6 +370,7 @@ __global__ __launch_bounds__(256) void tables_kernel_v2(DevModel M, DevLibrary l
     WaveLevels &WL = *reinterpret_cast<WaveLevels *>(wave_base);
     float *acc_score = reinterpret_cast<float *>(wave_base + sizeof(WaveLevels)); // [kTabEntryChunk][G]
     unsigned *acc_fail = reinterpret_cast<unsigned *>(acc_score + kTabEntryChunk * G);
+    uint8_t *near_list = reinterpret_cast<uint8_t *>(acc_fail + kTabEntryChunk * G); // [kTabEntryChunk]
 
     for (int i = threadIdx.x; i < Nm * Nm; i += blockDim.x) {
         float4 e = M.edge[i];
@@ -447,10 +448,11 @@ __global__ __launch_bounds__(256) void tables_kernel_v2(DevModel M, DevLibrary l
             const int ecur = min(kTabEntryChunk, ki - e0);
             if (ni > 1) {
                 const int per = ni * ni; // walk all (u, v), keep u < v
+                const float inv_per = 1.0f / (float)per, inv_ni = 1.0f / (float)ni;
                 const int total = ecur * per;
                 for (int t = s; t < total; t += GPW) {
-                    const int e = t / per, rr = t - e * per;
-                    const int u = rr / ni, v = rr - u * ni;
+                    const int e = (int)(((float)t + 0.5f) * inv_per), rr = t - e * per;
+                    const int u = (int)(((float)rr + 0.5f) * inv_ni), v = rr - u * ni;
                     if (u >= v) continue;
                     const uint64_t nodes_a = cnodes[WL.candlist[i][e0 + e]];
                     const uint64_t A = nodes_a & tnodes[tm[si + u]], B = nodes_a & tnodes[tm[si + v]];
@@ -480,18 +482,38 @@ __global__ __launch_bounds__(256) void tables_kernel_v2(DevModel M, DevLibrary l
             const float ldist = norm3(ctr_i.x - ctr_j.x, ctr_i.y - ctr_j.y, ctr_i.z - ctr_j.z); // graph_match.py:240
             const float lsize = size_i + size_j;                                                 // :241
             const int E = ki * kj, per = ni * nj;
+            const float inv_per = 1.0f / (float)per, inv_nj = 1.0f / (float)nj, inv_kj = 1.0f / (float)kj;
             for (int e0 = 0; e0 < E; e0 += kTabEntryChunk) {
                 const int ecur = min(kTabEntryChunk, E - e0);
-                const int total = ecur * per;
+                // cluster-distance prefilter (graph_match.py:263-268) once per entry: keep the entries for which
+                // some conformer passes, as a compact list, so that items are only made for those
+                int n_near = 0;
+                for (int e1 = 0; e1 < ecur; e1 += GPW) {
+                    const int e = e1 + s;
+                    bool near = false;
+                    if (e < ecur) {
+                        const int ea = (int)(((float)(e0 + e) + 0.5f) * inv_kj), eb = (e0 + e) - ea * kj;
+                        const float2 mp = M.cpair[WL.candlist[i][ea] * M.K + WL.candlist[j][eb]];
+                        near = lane_live && !((fabsf(ldist - mp.x) - lsize) > mp.y);
+                    }
+                    const unsigned long long bal = __ballot(near);
+                    // one bit per slot: does any conformer of that slot's entry pass
+                    for (int q = 0; q < GPW; ++q) {
+                        const unsigned long long m = (G == 64) ? bal : ((bal >> (q * G)) & ((1ull << G) - 1ull));
+                        if (m && e1 + q < ecur) {
+                            near_list[n_near] = (uint8_t)(e1 + q);
+                            ++n_near;
+                        }
+                    }
+                }
+                wave_lds_sync();
+                const int total = n_near * per;
                 for (int t = s; t < total; t += GPW) {
-                    const int e = t / per, rr = t - e * per;
-                    const int u = rr / nj, v = rr - u * nj;
-                    const int ea = (e0 + e) / kj, eb = (e0 + e) - ea * kj;
+                    const int en = (int)(((float)t + 0.5f) * inv_per), rr = t - en * per;
+                    const int u = (int)(((float)rr + 0.5f) * inv_nj), v = rr - u * nj;
+                    const int e = near_list[en];
+                    const int ea = (int)(((float)(e0 + e) + 0.5f) * inv_kj), eb = (e0 + e) - ea * kj;
                     const int a = WL.candlist[i][ea], b = WL.candlist[j][eb];
-                    // cluster-distance prefilter (graph_match.py:263-268), per entry, any conformer
-                    const float2 mp = M.cpair[a * M.K + b];
-                    const bool near = lane_live && !((fabsf(ldist - mp.x) - lsize) > mp.y);
-                    if (!(__ballot(near) & slot_mask)) continue;
                     const uint64_t A = cnodes[a] & tnodes[tm[si + u]], B = cnodes[b] & tnodes[tm[sj + v]];
                     if (!A || !B) continue;
                     const Pos pu = load_pos(xyz, C, si + u, cc), pv = load_pos(xyz, C, sj + v, cc);
@@ -511,7 +533,7 @@ __global__ __launch_bounds__(256) void tables_kernel_v2(DevModel M, DevLibrary l
                     float value = -1.f;
                     bool valid = false;
                     if (on) {
-                        const int ea = (e0 + e) / kj, eb = (e0 + e) - ea * kj;
+                        const int ea = (int)(((float)(e0 + e) + 0.5f) * inv_kj), eb = (e0 + e) - ea * kj;
                         const int a = WL.candlist[i][ea], b = WL.candlist[j][eb];
                         const float2 mp = M.cpair[a * M.K + b];
                         const bool near = lane_live && !((fabsf(ldist - mp.x) - lsize) > mp.y);

@@ -53,3 +53,45 @@ def test_matches_oracle_on_fresh_ligands(name, oracle):
     assert np.all(got[zero] == 0.0)
     err = rel_err(got[~zero], ref[~zero])
     assert err.max() < RTOL + 6e-8, f"max rel err {err.max():.3e}"
+
+
+@pytest.mark.parametrize("num_conf", [2, 3, 12, 20, 33])
+def test_other_conformer_counts_match_oracle(num_conf, oracle):
+    """Conformer-group widths 2, 4, 16, 32, 64 (the fixtures cover 1, 8 and 64 lanes per ligand)."""
+    from pharmaconet_amd.constants import TYPE_ID, weights_vector
+    from pharmaconet_amd.synthetic import synthetic_library
+
+    model, _, _, _ = load_golden("set_6oim_c8")
+    st = model.__getstate__()
+    centers = np.array([n["center"] for n in st["nodes"]], dtype=np.float64)
+    types = np.array([TYPE_ID[n["type"]] for n in st["nodes"]])
+    lib = synthetic_library(120, num_conformers=num_conf, model_nodes=(centers, types), active_fraction=0.3, seed=4242 + num_conf)
+    ref = oracle.oracle_score(model.flat, lib, weights_vector(None), num_threads=8)
+    got, status = gpu_scores(model, lib, None)
+    assert np.all(status == 0)
+    zero = ref == 0
+    assert np.all(got[zero] == 0.0)
+    assert rel_err(got[~zero], ref[~zero]).max() < RTOL + 6e-8
+
+
+def test_mixed_conformer_counts_in_one_library(oracle):
+    """Ligands of one library may have different conformer counts (one SDF record per conformer, ligand.py:63-84)."""
+    from pharmaconet_amd import PackedLibrary
+    from pharmaconet_amd.constants import TYPE_ID, weights_vector
+    from pharmaconet_amd.synthetic import synthetic_library
+
+    model, _, _, _ = load_golden("set_c21_c8")
+    st = model.__getstate__()
+    centers = np.array([n["center"] for n in st["nodes"]], dtype=np.float64)
+    types = np.array([TYPE_ID[n["type"]] for n in st["nodes"]])
+    recs = []
+    for nc in (1, 5, 8, 3, 7):
+        part = synthetic_library(30, num_conformers=nc, model_nodes=(centers, types), active_fraction=0.5, seed=99 + nc)
+        recs += [part.record(i) for i in range(len(part))]
+    lib = PackedLibrary.from_records(recs)
+    ref = oracle.oracle_score(model.flat, lib, weights_vector(None), num_threads=8)
+    got, status = gpu_scores(model, lib, None)
+    assert np.all(status == 0)
+    zero = ref == 0
+    assert np.all(got[zero] == 0.0)
+    assert rel_err(got[~zero], ref[~zero]).max() < RTOL + 6e-8
