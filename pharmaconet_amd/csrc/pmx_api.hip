@@ -418,8 +418,9 @@ static int score_chunks(const pmx_model *model, const pmx_library *lib, const We
             tp.depth_cap = depth;
             tp.K = Kc;
             tp.tabcap = tabcap;
-            tp.budget = (uint32_t)std::max<long>(64, env_long("PMX_BUDGET", 2048));
+            tp.budget = (uint32_t)std::max<long>(64, env_long("PMX_BUDGET", 1024));
             tp.scores = scores;
+            tp.step_cap = (uint32_t)std::max<long>(1, env_long("PMX_STEP_CAP", 1 << 20));
             tp.share_levels = (uint32_t)std::max<long>(0, env_long("PMX_SHARE_LEVELS", 1));
             tp.min_levels = (uint32_t)std::max<long>(0, env_long("PMX_MIN_LEVELS", 4));
             tp.flags = (uint32_t)env_long("PMX_TREE_FLAGS", 0);

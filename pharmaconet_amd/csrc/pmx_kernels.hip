@@ -628,6 +628,7 @@ struct TreeParams {
     int depth_cap;
     int K;               // model clusters (bound on candidates per level)
     uint32_t tabcap;     // LDS bytes reserved for one ligand's validity-mask table (0 = read it from the arena)
+    uint32_t step_cap;   // children / returns handled by one walker step at most
     uint32_t share_levels; // in-wave sharing hands over only subtrees with at least this many levels below their root
     uint32_t min_levels; // in export mode only subtrees with at least this many levels below their root are queued
     uint32_t flags;      // debug: 1 = no in-wave sharing, 2 = no global donation
@@ -717,6 +718,7 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
     const int g = lane / G, c = lane % G;
     const int D = p.depth_cap, K = p.K;
     const uint32_t budget = p.budget, qcap = p.qcap, flags = p.flags, min_levels = p.min_levels, share_levels = p.share_levels;
+    const uint32_t step_cap = p.step_cap;
     const unsigned long long max_iters = p.max_iters;
     uint32_t *const qtail = p.qtail;
     uint8_t *const queue = p.queue;
@@ -992,7 +994,7 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
             if (f < nl && !(frm[f].z & F_EXPANDED)) {
                 expand(f); // first step of a root (whole tree or adopted subtree)
             } else {
-                for (;;) {
+                for (uint32_t inner = 0; inner < step_cap; ++inner) { // optional bound on the work of one step (PMX_STEP_CAP)
                     PMX_GUARD(13);
                     uchar4 F = frm[f];
                     const int nm = F.w;
