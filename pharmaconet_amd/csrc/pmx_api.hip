@@ -252,7 +252,7 @@ static uint32_t chunk_size() {
     static uint32_t v = [] {
         const char *s = std::getenv("PMX_CHUNK");
         long x = s ? std::atol(s) : 0;
-        return (uint32_t)(x > 0 ? std::min<long>(x, 1 << 22) : 131072);
+        return (uint32_t)(x > 0 ? std::min<long>(x, 1 << 22) : 262144);
     }();
     return v;
 }

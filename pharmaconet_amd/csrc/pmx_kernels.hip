@@ -655,7 +655,7 @@ constexpr uint32_t kTreeSharedHdr = 32 + 48 + 80; // k[32], ksum[24], rowbase[20
 
 template <int G>
 __host__ __device__ constexpr uint32_t tree_local_stack_entries() {
-    return 2 * (64 / G);
+    return 64 / G; // one entry per conformer group
 }
 
 // LDS bytes of one wave of tree_kernel.
