@@ -1,18 +1,23 @@
 // pmx_kernels.hip - the screening hot path on gfx950 (CDNA4, wave64).
 //
-// Execution model. A ligand is owned by a *conformer group*: G = 2^ceil(log2(max conformers)) adjacent
-// lanes of a wavefront, lane c of the group holding conformer c. A wave64 therefore carries 64 / G
-// ligands (8 at the 8-conformer shape of BASELINE.json, 1 at 64 conformers). Everything that is the
-// same for all conformers of a ligand (tree control, candidate sets, table indices) is computed
-// redundantly by the group's lanes, so control flow is uniform inside a group and diverges only
-// between groups. Conformers are coupled exactly where the reference couples them (the joint
-// `any conformer valid` and `num_matches + max_num_matches < 5` tests of tree.py:83-84,98).
+// Execution model. A ligand's conformers live in a *conformer group*: G = 2^ceil(log2(max conformers))
+// adjacent lanes of a wavefront, lane c of the group holding conformer c (8 lanes at the 8-conformer
+// shape of BASELINE.json, 64 at 64 conformers). Everything that is the same for all conformers of a
+// ligand (tree control, candidate sets, table indices) is computed redundantly by the group's lanes,
+// so control flow is uniform inside a group and diverges only between groups. Conformers are coupled
+// exactly where the reference couples them (the joint `any conformer valid` and
+// `num_matches + max_num_matches < 5` tests of tree.py:83-84,98), through __ballot.
 //
-// Three kernels per chunk of ligands:
-//   sizes_kernel   one thread per ligand: candidate sets -> number of tree levels, table size
-//   tables_kernel  conformer groups: the self / pair score tables of match_utils.py -> scratch arena
-//   tree_kernel    conformer groups, persistent with dynamic ligand fetch: the DFS of tree.py over
-//                  those tables, per-conformer maximum over leaves, mean -> score
+// Kernels per chunk of ligands (one HIP stream, kernel -> kernel ordering only):
+//   clear_kernel       zeroes the chunk's counters and accumulators
+//   sizes_kernel       one thread per ligand: candidate sets -> number of tree levels, table size
+//   scan_kernel        table sizes -> offsets in the scratch arena
+//   tables_kernel_v2   one wavefront per ligand: the self / pair score tables of match_utils.py
+//                      (tables_kernel, one group per ligand, is the earlier form kept for comparison)
+//   tree_kernel<G,0>   one wavefront (= block) per ligand: the DFS of tree.py over those tables, shared
+//                      by the wave's 64 / G groups; per-conformer maximum over leaves, mean -> score
+//   tree_kernel<G,1>   the same walker on subtrees queued by over-budget trees, in rounds
+//   finalize_kernel    scores of ligands whose tree was split
 //
 // Floating point: -ffp-contract=off (see build flags). Distances and the 2-sigma test reproduce the
 // reference's float32 results bit for bit; Gaussian sums agree to float32 rounding.
@@ -619,7 +624,7 @@ struct TreeParams {
     uint64_t first;      // library index of the chunk's first ligand
     uint32_t count;      // jobs: ligands (TASKS = false) or tasks [task_lo, task_lo + count)
     uint32_t task_lo;
-    uint32_t *counter;   // dynamic fetch counter
+    uint32_t *counter;   // (unused by the block-per-job launch; kept for diagnostics)
     uint32_t *qtail;     // task queue tail; qtail[1] = overflow flag
     uint8_t *queue;
     uint32_t qcap;
