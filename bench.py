@@ -48,8 +48,10 @@ def build_library(model, n_ligands, n_conf, base_count, rank, device):
     types = np.array([TYPE_ID[n["type"]] for n in st["nodes"]])
     t0 = time.time()
     base_count = min(base_count, n_ligands)
+    # Every rank's shard holds the same topologies (ligand index = copy * topologies + topology, shards are
+    # contiguous ranges of copies) with its own perturbation stream, so the ranks' work is statistically equal.
     base = synthetic_library(
-        base_count, first=rank * base_count, num_conformers=n_conf, model_nodes=(centers, types),
+        base_count, first=0, num_conformers=n_conf, model_nodes=(centers, types),
         active_fraction=0.1, seed=BASE_SEED, max_nodes=32, conformer_noise=0.0,
     )
     replicas = (n_ligands + base_count - 1) // base_count
@@ -114,13 +116,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         log(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # PMX_BENCH_DEVICE / PMX_BENCH_BACKEND exist to rehearse the multi-rank path on a 1-GPU box (all ranks on one
+    # device, gloo); the driver's runs use one GPU per rank and RCCL ("nccl").
+    dev_index = int(os.environ.get("PMX_BENCH_DEVICE", local_rank))
+    backend = os.environ.get("PMX_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     import __graft_entry__ as entry
 
@@ -138,7 +147,10 @@ def main():
     def step():
         res = engine.screen(model, lib, topk=args.topk, index_base=index_base)
         if world > 1:
-            top = allgather_topk(res.topk_scores, res.topk_indices, args.topk)
+            if backend == "nccl":
+                top = allgather_topk(res.topk_scores, res.topk_indices, args.topk)
+            else:
+                top = allgather_topk(res.topk_scores.cpu(), res.topk_indices.cpu(), args.topk)
         else:
             top = merge_topk(res.topk_scores.cpu().numpy(), res.topk_indices.cpu().numpy(), args.topk)
         return res, top
@@ -174,7 +186,7 @@ def main():
     elapsed = time.perf_counter() - t0
     engine.set_profiling(False)
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
