@@ -397,7 +397,7 @@ static int score_chunks(const pmx_model *model, const pmx_library *lib, const We
             uint32_t tabcap = (uint32_t)std::max<long>(0, env_long("PMX_TABCAP", 0));
             tabcap = (uint32_t)round16(tabcap);
             while (tabcap > 0 && tree_wave_bytes<G>(depth, Kc, tabcap) > 64 * 1024 - 512) tabcap -= std::min<uint32_t>(tabcap, 1024);
-            const size_t lds = tree_wave_bytes<G>(depth, Kc, tabcap);
+            const size_t lds = tree_wave_bytes<G>(depth, Kc, tabcap) + (size_t)std::max<long>(0, env_long("PMX_LDS_PAD", 0));
             if (lds > kLdsPerCu) return fail(PMX_ERR_INVALID, "tree state of %zu bytes does not fit LDS", lds);
             int waves_per_cu = (int)std::min<size_t>(16, kLdsPerCu / (lds + 256));
             waves_per_cu = std::max(1, waves_per_cu);

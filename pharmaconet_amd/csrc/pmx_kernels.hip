@@ -647,13 +647,12 @@ struct TreeParams {
 // LDS bytes of one conformer group's tree state for stacks that hold `depth` levels of a model with K clusters.
 template <int G>
 __host__ __device__ inline uint32_t tree_group_bytes(int depth, int K) {
-    const uint32_t tot_bytes = (uint32_t)(depth + 1) * G * 8;                                      // float64 totals [depth + 1][G]
     const uint32_t todo_bytes = (uint32_t)(depth + 1) * 8;                                         // unexplored existing candidates per frame
     const uint32_t cm_bytes = (uint32_t)round16((uint64_t)(depth + 1) * K * sizeof(vmask_t<G>));  // conformer masks of a frame's candidates
     const uint32_t msk_bytes = (uint32_t)round16((uint64_t)(depth + 1) * sizeof(vmask_t<G>));     // conformer masks by match count
     const uint32_t frm_bytes = (uint32_t)round16((uint64_t)(depth + 1) * 4);                      // frames {-, mx, flags, nm}
     const uint32_t mat_bytes = (uint32_t)round16((uint64_t)depth * 8);                            // matched ancestors
-    return tot_bytes + todo_bytes + cm_bytes + msk_bytes + frm_bytes + mat_bytes;
+    return todo_bytes + cm_bytes + msk_bytes + frm_bytes + mat_bytes;
 }
 
 constexpr uint32_t kTreeSharedHdr = 32 + 48 + 80; // k[32], ksum[24], rowbase[20] of the job's ligand
@@ -735,18 +734,19 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
     uint16_t *hksum = reinterpret_cast<uint16_t *>(shared + 32);        // [24]
     uint32_t *hrow = reinterpret_cast<uint32_t *>(shared + 32 + 48);    // [20]
     unsigned char *lstk = shared + kTreeSharedHdr;                      // local task stack
-    const uint32_t tot_bytes = (uint32_t)(D + 1) * G * 8;
     const uint32_t todo_bytes = (uint32_t)(D + 1) * 8;
     const uint32_t cm_bytes = (uint32_t)round16((uint64_t)(D + 1) * K * sizeof(vm_t));
     const uint32_t msk_bytes = (uint32_t)round16((uint64_t)(D + 1) * sizeof(vm_t));
     const uint32_t frm_bytes = (uint32_t)round16((uint64_t)(D + 1) * 4);
     unsigned char *base = lstk + LCAP * task_bytes<G>() + (size_t)g * tree_group_bytes<G>(D, K);
-    double *tot = reinterpret_cast<double *>(base);                                 // [D + 1][G]
-    uint64_t *todo = reinterpret_cast<uint64_t *>(base + tot_bytes);                // [D + 1]
-    vm_t *cm = reinterpret_cast<vm_t *>(base + tot_bytes + todo_bytes);             // [D + 1][K]
-    vm_t *msk = reinterpret_cast<vm_t *>(base + tot_bytes + todo_bytes + cm_bytes); // [D + 1]
-    uchar4 *frm = reinterpret_cast<uchar4 *>(base + tot_bytes + todo_bytes + cm_bytes + msk_bytes); // [D + 1] {-, mx, flags, nm}
-    int2 *mat = reinterpret_cast<int2 *>(base + tot_bytes + todo_bytes + cm_bytes + msk_bytes + frm_bytes); // [D] {R, k_j | a_j << 8 | j << 16}
+    // float64 totals by match count live in the wave's private (scratch) memory, not in LDS: they are read
+    // and written next to global table loads anyway, and LDS per wave decides how many waves a CU holds
+    double tot[PMX_MAX_LEVELS + 1];
+    uint64_t *todo = reinterpret_cast<uint64_t *>(base);                // [D + 1]
+    vm_t *cm = reinterpret_cast<vm_t *>(base + todo_bytes);             // [D + 1][K]
+    vm_t *msk = reinterpret_cast<vm_t *>(base + todo_bytes + cm_bytes); // [D + 1]
+    uchar4 *frm = reinterpret_cast<uchar4 *>(base + todo_bytes + cm_bytes + msk_bytes); // [D + 1] {-, mx, flags, nm}
+    int2 *mat = reinterpret_cast<int2 *>(base + todo_bytes + cm_bytes + msk_bytes + frm_bytes); // [D] {R, k_j | a_j << 8 | j << 16}
 
     uint32_t guard = 0;
     // ---- the job's tables
@@ -798,7 +798,7 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
             const int kj = hk[j];
             mat[q] = make_int2((int)hrow[j] - kj * (int)hksum[j + 1], kj | (a << 8) | (j << 16));
         }
-        tot[nm0 * G + c] = reinterpret_cast<const double *>(th + 1)[c];
+        tot[nm0] = reinterpret_cast<const double *>(th + 1)[c];
         msk[nm0] = (vm_t)th->mask;
         frm[f] = make_uchar4(0, 0, F_MATCHED, (unsigned char)nm0);
         busy = true;
@@ -818,7 +818,7 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
         }
         th->path[2 * nmr] = (uint8_t)fr;
         th->path[2 * nmr + 1] = (uint8_t)b;
-        reinterpret_cast<double *>(th + 1)[c] = tot[nmr * G + c] + (double)St[(size_t)(ksr + b) * G + c] + pair;
+        reinterpret_cast<double *>(th + 1)[c] = tot[nmr] + (double)St[(size_t)(ksr + b) * G + c] + pair;
     };
     // a frame may give children away once it has >= 4 matches (their subtrees hold >= 5, see above)
     auto donatable = [&](int fr) -> bool {
@@ -870,7 +870,7 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
             C = parse_record(p.lib.data + p.lib.offsets[p.first + li]).C;
             f0 = f = 0; // root frame
             sfr = 0;
-            tot[c] = 0.0;
+            tot[0] = 0.0;
             msk[0] = (vm_t)((C >= 64) ? ~0ull : ((1ull << C) - 1ull));
             frm[0] = make_uchar4(0, 0, 0, 0);
             busy = true;
@@ -1005,7 +1005,7 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
                     const int nm = F.w;
                     const bool matched = F.z & F_MATCHED;
                     if (f == nl) { // a subtree root that is itself a leaf (tree.py:103-104)
-                        const double t = tot[nm * G + c];
+                        const double t = tot[nm];
                         if (((msk[nm] >> c) & 1) && t > best) best = t;
                         --f;
                         if (f < f0) break;
@@ -1035,14 +1035,14 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
                         }
                         const vm_t m = cm[f * K + b];
                         // parent + self + accumulated pair (tree.py:38-41)
-                        const double t = tot[nm * G + c] + (double)St[(size_t)(ksf + b) * G + c] + pair_sum<G>(Pt, mat, nm, ksf, kf, b, c);
+                        const double t = tot[nm] + (double)St[(size_t)(ksf + b) * G + c] + pair_sum<G>(Pt, mat, nm, ksf, kf, b, c);
                         if (f + 1 == nl) { // the child is a leaf: per-conformer maximum (graph_match.py:105-108), returns 1
                             if (((m >> c) & 1) && t > best) best = t;
                             F.y = F.y > 1 ? F.y : 1;
                             frm[f] = F;
                             continue;
                         }
-                        tot[(nm + 1) * G + c] = t;
+                        tot[nm + 1] = t;
                         msk[nm + 1] = m;
                         // entry(this match, level f', b') = rowbase[f] + k_f * (ksum[f'] - ksum[f + 1]) + b * k_f' + b'
                         mat[nm] = make_int2((int)hrow[f] - kf * (int)hksum[f + 1], kf | (b << 8) | (f << 16));
@@ -1056,7 +1056,7 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
                         F.z |= F_SKIP;
                         frm[f] = F;
                         if (f + 1 == nl) { // a skip leaf carries this node's totals (tree.py:42-43) and returns 0
-                            const double t = tot[nm * G + c];
+                            const double t = tot[nm];
                             if (((msk[nm] >> c) & 1) && t > best) best = t;
                             continue;
                         }
@@ -1109,7 +1109,7 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
 // block to whichever CU frees a slot, which is the dynamic load balancing a work counter would give,
 // and the kernel stays a straight line of wave-uniform branches around the walker.
 template <int G, bool TASKS>
-__global__ __launch_bounds__(64) void tree_kernel(const TreeParams p) {
+__global__ __launch_bounds__(64, 6) void tree_kernel(const TreeParams p) { // 6 waves per SIMD: <= 80 VGPRs, measured best
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const uint32_t nx = blockIdx.x;
