@@ -365,7 +365,7 @@ static int score_chunks(const pmx_model *model, const pmx_library *lib, const We
             const size_t model_lds = (size_t)Nm * Nm * sizeof(float4) + 64 * 8 + 128 * 8;
             int v2_waves = 0; // waves (= ligands) per block that fit the 160 KB of LDS next to the model tables
             if (model_lds + tables_v2_wave_bytes<G>() + 1024 <= kLdsPerCu)
-                v2_waves = (int)std::min<size_t>(tab_waves, (kLdsPerCu - 1024 - model_lds) / tables_v2_wave_bytes<G>());
+                v2_waves = (int)std::min<size_t>(8, (kLdsPerCu - 1024 - model_lds) / tables_v2_wave_bytes<G>()); // <= 8 ligands share one staged model
             if (force_v1 || v2_waves < 1) {
                 const uint32_t groups_per_block = tab_waves * GPW;
                 tables_kernel<G><<<dim3((n + groups_per_block - 1) / groups_per_block), dim3(64 * tab_waves), tab_lds, stream>>>(

@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256) void tables_kernel(DevModel M, DevLibrary lib,
 // add the item's likelihood and fail flag into per-entry LDS accumulators (ds_add). Consecutive items
 // share (a, b) and so have the same number of model node pairs: the slots of a wave stay balanced, and
 // all lanes walk the same ligand, so there is no divergence between ligands.
-constexpr int kTabEntryChunk = 64; // entries accumulated in LDS at a time
+constexpr int kTabEntryChunk = 32; // entries accumulated in LDS at a time
 
 struct WaveLevels { // per wave, in LDS
     uint64_t cand[PMX_MAX_LEVELS];
@@ -363,7 +363,7 @@ __host__ __device__ constexpr uint32_t tables_v2_wave_bytes() {
 }
 
 template <int G>
-__global__ __launch_bounds__(256) void tables_kernel_v2(DevModel M, DevLibrary lib, Weights W, uint64_t first, uint32_t count,
+__global__ __launch_bounds__(512) void tables_kernel_v2(DevModel M, DevLibrary lib, Weights W, uint64_t first, uint32_t count,
                                                         const int32_t *status, const uint64_t *taboff, uint8_t *arena) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int GPW = 64 / G; // slots per wave
