@@ -394,10 +394,7 @@ static int score_chunks(const pmx_model *model, const pmx_library *lib, const We
         {
             const int depth = std::max<int>(1, (int)max_levels);
             const int Kc = std::max(1, model->dm.K);
-            uint32_t tabcap = (uint32_t)std::max<long>(0, env_long("PMX_TABCAP", 0));
-            tabcap = (uint32_t)round16(tabcap);
-            while (tabcap > 0 && tree_wave_bytes<G>(depth, Kc, tabcap) > 64 * 1024 - 512) tabcap -= std::min<uint32_t>(tabcap, 1024);
-            const size_t lds = tree_wave_bytes<G>(depth, Kc, tabcap) + (size_t)std::max<long>(0, env_long("PMX_LDS_PAD", 0));
+            const size_t lds = tree_wave_bytes<G>(depth, Kc) + (size_t)std::max<long>(0, env_long("PMX_LDS_PAD", 0));
             if (lds > kLdsPerCu) return fail(PMX_ERR_INVALID, "tree state of %zu bytes does not fit LDS", lds);
             int waves_per_cu = (int)std::min<size_t>(16, kLdsPerCu / (lds + 256));
             waves_per_cu = std::max(1, waves_per_cu);
@@ -417,7 +414,6 @@ static int score_chunks(const pmx_model *model, const pmx_library *lib, const We
             tp.deferred = ws.deferred;
             tp.depth_cap = depth;
             tp.K = Kc;
-            tp.tabcap = tabcap;
             tp.budget = (uint32_t)std::max<long>(64, env_long("PMX_BUDGET", 1024));
             tp.scores = scores;
             tp.step_cap = (uint32_t)std::max<long>(1, env_long("PMX_STEP_CAP", 1 << 20));
@@ -427,7 +423,7 @@ static int score_chunks(const pmx_model *model, const pmx_library *lib, const We
             tp.nsteps = reinterpret_cast<unsigned long long *>(ws.meta + 6);
             tp.dbg = ws.meta + 32;
             tp.max_iters = (unsigned long long)std::max<long>(1, env_long("PMX_MAXITERS", 1L << 31));
-            TRACE("tree kernel: grid=%u lds=%zu tabcap=%u depth=%d waves/cu=%d", n, lds, tabcap, depth, waves_per_cu);
+            TRACE("tree kernel: grid=%u lds=%zu depth=%d waves/cu=%d", n, lds, depth, waves_per_cu);
             tree_kernel<G, false><<<dim3(n), dim3(64), lds, stream>>>(tp);
             HIPCHECK(hipGetLastError());
             TRACE("tree kernel launched");
@@ -465,6 +461,16 @@ static int score_chunks(const pmx_model *model, const pmx_library *lib, const We
                     g_stats.max_iters_ligand = std::max<uint64_t>(g_stats.max_iters_ligand, ns);
                     std::memcpy(&ns, ws.meta_host + 12, 8);
                     g_stats.max_iters_task = std::max<uint64_t>(g_stats.max_iters_task, ns);
+#ifdef PMX_PROF
+                    {
+                        fprintf(stderr, "PMXPROF");
+                        for (int i = 0; i < 32; ++i) {
+                            std::memcpy(&ns, ws.meta_host + 128 + 2 * i, 8);
+                            fprintf(stderr, " %llu", ns);
+                        }
+                        fprintf(stderr, "\n");
+                    }
+#endif
                     break;
                 }
                 tp.count = hi - lo;

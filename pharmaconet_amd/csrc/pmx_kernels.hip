@@ -363,7 +363,7 @@ __host__ __device__ constexpr uint32_t tables_v2_wave_bytes() {
 }
 
 template <int G>
-__global__ __launch_bounds__(512) void tables_kernel_v2(DevModel M, DevLibrary lib, Weights W, uint64_t first, uint32_t count,
+__global__ __launch_bounds__(512, 6) void tables_kernel_v2(DevModel M, DevLibrary lib, Weights W, uint64_t first, uint32_t count,
                                                         const int32_t *status, const uint64_t *taboff, uint8_t *arena) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int GPW = 64 / G; // slots per wave
@@ -632,7 +632,6 @@ struct TreeParams {
     uint8_t *deferred;           // [chunk] ligand was split: score comes from bestbuf
     int depth_cap;
     int K;               // model clusters (bound on candidates per level)
-    uint32_t tabcap;     // LDS bytes reserved for one ligand's validity-mask table (0 = read it from the arena)
     uint32_t step_cap;   // children / returns handled by one walker step at most
     uint32_t share_levels; // in-wave sharing hands over only subtrees with at least this many levels below their root
     uint32_t min_levels; // in export mode only subtrees with at least this many levels below their root are queued
@@ -647,12 +646,13 @@ struct TreeParams {
 // LDS bytes of one conformer group's tree state for stacks that hold `depth` levels of a model with K clusters.
 template <int G>
 __host__ __device__ inline uint32_t tree_group_bytes(int depth, int K) {
-    const uint32_t todo_bytes = (uint32_t)(depth + 1) * 8;                                         // unexplored existing candidates per frame
+    const uint32_t todo_bytes = (uint32_t)round16((uint64_t)(depth + 1) * 8);                      // unexplored existing candidates per frame
     const uint32_t cm_bytes = (uint32_t)round16((uint64_t)(depth + 1) * K * sizeof(vmask_t<G>));  // conformer masks of a frame's candidates
     const uint32_t msk_bytes = (uint32_t)round16((uint64_t)(depth + 1) * sizeof(vmask_t<G>));     // conformer masks by match count
     const uint32_t frm_bytes = (uint32_t)round16((uint64_t)(depth + 1) * 4);                      // frames {-, mx, flags, nm}
     const uint32_t mat_bytes = (uint32_t)round16((uint64_t)depth * 8);                            // matched ancestors
-    return todo_bytes + cm_bytes + msk_bytes + frm_bytes + mat_bytes;
+    const uint32_t eb_bytes = (uint32_t)round16((uint64_t)depth * 4);                             // their pair-table rows for the current frame
+    return todo_bytes + cm_bytes + msk_bytes + frm_bytes + mat_bytes + eb_bytes;
 }
 
 constexpr uint32_t kTreeSharedHdr = 32 + 48 + 80; // k[32], ksum[24], rowbase[20] of the job's ligand
@@ -664,14 +664,46 @@ __host__ __device__ constexpr uint32_t tree_local_stack_entries() {
 
 // LDS bytes of one wave of tree_kernel.
 template <int G>
-__host__ __device__ inline uint32_t tree_wave_bytes(int depth, int K, uint32_t tabcap) {
-    return (uint32_t)round16(tabcap) + kTreeSharedHdr + tree_local_stack_entries<G>() * task_bytes<G>() +
+__host__ __device__ inline uint32_t tree_wave_bytes(int depth, int K) {
+    return kTreeSharedHdr + tree_local_stack_entries<G>() * task_bytes<G>() +
            (64 / G) * tree_group_bytes<G>(depth, K);
 }
 
 // Pair-table index of (matched ancestor q, candidate 0 of level f): + b gives candidate b.
 __device__ inline int entry_base(const int2 mq, int ksf, int kf) {
     return mq.x + (mq.y & 255) * ksf + ((mq.y >> 8) & 255) * kf;
+}
+
+// log2 of the bytes of one pair entry in the P table (G floats)
+template <int G>
+__host__ __device__ constexpr int p_entry_shift() {
+    return G == 1 ? 2 : G == 2 ? 3 : G == 4 ? 4 : G == 8 ? 5 : G == 16 ? 6 : G == 32 ? 7 : 8;
+}
+
+// The same sum with the ancestors' entry bases of the current frame taken from the group's LDS cache
+// (eb[q] = entry_base(mat[q], ksf, kf)): one shift-add per term, 32-bit offsets from the wave-uniform
+// table base. bc = (b << p_entry_shift) + 4 * c.
+template <int G>
+__device__ inline double pair_sum_eb(const unsigned char *Pt, const int *eb, int nm, uint32_t bc) {
+    constexpr int SH = p_entry_shift<G>();
+    double pair = 0.0;
+    int q = 0;
+    for (; q + 8 <= nm; q += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float *>(Pt + (((uint32_t)eb[q + u] << SH) + bc));
+#pragma unroll
+        for (int u = 0; u < 8; ++u) pair += (double)v[u];
+    }
+    for (; q + 4 <= nm; q += 4) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float *>(Pt + (((uint32_t)eb[q + u] << SH) + bc));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) pair += (double)v[u];
+    }
+    for (; q < nm; ++q) pair += (double)*reinterpret_cast<const float *>(Pt + (((uint32_t)eb[q] << SH) + bc));
+    return pair;
 }
 
 // sum_q P[entry(q, f, b)][c] in ancestor order (tree.py:78-82), loads issued four at a time
@@ -698,8 +730,9 @@ __device__ inline double pair_sum(const float *Pt, const int2 *mat, int nm, int 
 }
 
 // Walks one job (a whole ligand tree, or a subtree task) with all conformer groups of the wave.
-// INLDS: the tables were staged at smem[0 .. tabcap); otherwise they are read from the arena.
-template <int G, bool TASKS, bool INLDS>
+// The job's tables are read from the arena (L2); staging them in LDS was measured and costs more in
+// occupancy than it saves in latency.
+template <int G, bool TASKS>
 #ifdef PMX_GUARDS
 #define PMX_GUARD(code)                                                         \
     do {                                                                        \
@@ -729,12 +762,12 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
     const unsigned long long below = (g == 0) ? 0ull : ((1ull << (g * G)) - 1ull); // lanes of lower groups
 
     // ---- LDS carve
-    unsigned char *shared = smem + round16(p.tabcap);
+    unsigned char *shared = smem;
     uint8_t *hk = shared;                                               // k[32]
     uint16_t *hksum = reinterpret_cast<uint16_t *>(shared + 32);        // [24]
     uint32_t *hrow = reinterpret_cast<uint32_t *>(shared + 32 + 48);    // [20]
     unsigned char *lstk = shared + kTreeSharedHdr;                      // local task stack
-    const uint32_t todo_bytes = (uint32_t)(D + 1) * 8;
+    const uint32_t todo_bytes = (uint32_t)round16((uint64_t)(D + 1) * 8);
     const uint32_t cm_bytes = (uint32_t)round16((uint64_t)(D + 1) * K * sizeof(vm_t));
     const uint32_t msk_bytes = (uint32_t)round16((uint64_t)(D + 1) * sizeof(vm_t));
     const uint32_t frm_bytes = (uint32_t)round16((uint64_t)(D + 1) * 4);
@@ -747,30 +780,36 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
     vm_t *msk = reinterpret_cast<vm_t *>(base + todo_bytes + cm_bytes); // [D + 1]
     uchar4 *frm = reinterpret_cast<uchar4 *>(base + todo_bytes + cm_bytes + msk_bytes); // [D + 1] {-, mx, flags, nm}
     int2 *mat = reinterpret_cast<int2 *>(base + todo_bytes + cm_bytes + msk_bytes + frm_bytes); // [D] {R, k_j | a_j << 8 | j << 16}
+    // [D] entry_base(mat[q], level ebf) of the matched ancestors for the frame the group is working in
+    int *eb = reinterpret_cast<int *>(__builtin_assume_aligned(
+        base + todo_bytes + cm_bytes + msk_bytes + frm_bytes + (uint32_t)round16((uint64_t)D * 8), 16));
+    int ebf = -1;
 
     uint32_t guard = 0;
+#ifdef PMX_PROF // build with PMX_CXXFLAGS=-DPMX_PROF: where a wave's time goes (s_memtime) and what it does
+    unsigned long long pc_share = 0, pc_expand = 0, pc_adv = 0, pc_all = 0, pt0 = 0, pt1 = 0;
+    unsigned pn_leaf = 0, pn_exp = 0, pn_desc = 0, pn_pl = 0, pn_vl = 0, pn_fill = 0, pn_ret = 0, pn_skip = 0, pn_exported = 0;
+#define PROF(x) x
+#else
+#define PROF(x)
+#endif
     // ---- the job's tables
     const TabHeader *H = reinterpret_cast<const TabHeader *>(blk);
-    const int nl = (int)H->nl;
-    const uint32_t T = H->T, ksumtot = H->ksumtot;
+    const int nl = __builtin_amdgcn_readfirstlane((int)H->nl);
+    const uint32_t T = (uint32_t)__builtin_amdgcn_readfirstlane((int)H->T);
+    const uint32_t ksumtot = (uint32_t)__builtin_amdgcn_readfirstlane((int)H->ksumtot);
     const uint32_t v_bytes = (uint32_t)round16(uint64_t(T) * sizeof(vm_t));
     const uint32_t s_bytes = (uint32_t)round16(uint64_t(ksumtot) * G * 4);
     const uint32_t p_bytes = (uint32_t)round16(uint64_t(T) * G * 4);
     const unsigned char *tab = blk + sizeof(TabHeader);
     (void)p_bytes;
-    const vm_t *Vt = reinterpret_cast<const vm_t *>(tab);
-    if (INLDS) { // the validity masks (1 byte per pair entry at G <= 8) are small and read by every expansion
-        const uint32_t n16 = v_bytes / 16;
-        const uint4 *src = reinterpret_cast<const uint4 *>(tab);
-        uint4 *dst = reinterpret_cast<uint4 *>(smem);
-        for (uint32_t i = lane; i < n16; i += 64) {
-            PMX_GUARD(1);
-            dst[i] = src[i];
-        }
-        Vt = reinterpret_cast<const vm_t *>(smem);
-    }
     const float *St = reinterpret_cast<const float *>(tab + v_bytes);
     const float *Pt = reinterpret_cast<const float *>(tab + v_bytes + s_bytes);
+    const unsigned char *Pb = reinterpret_cast<const unsigned char *>(Pt); // wave-uniform: one job per wave
+    const unsigned char *Vb = tab; // validity masks
+    const unsigned char *Sb = reinterpret_cast<const unsigned char *>(St);
+    constexpr int PSH = p_entry_shift<G>();
+    constexpr int VSH = sizeof(vm_t) == 1 ? 0 : sizeof(vm_t) == 2 ? 1 : sizeof(vm_t) == 4 ? 2 : 3;
     for (int i = lane; i <= nl; i += 64) {
         PMX_GUARD(2);
         hksum[i] = H->ksum[i];
@@ -801,6 +840,7 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
         tot[nm0] = reinterpret_cast<const double *>(th + 1)[c];
         msk[nm0] = (vm_t)th->mask;
         frm[f] = make_uchar4(0, 0, F_MATCHED, (unsigned char)nm0);
+        ebf = -1;
         busy = true;
     };
     // describe candidate b of frame fr (conformer mask m) as a task record
@@ -828,39 +868,81 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
 
     // Enter frame fr: evaluate every candidate of level fr against the matched ancestors (tree.py:78-84);
     // lane c takes candidates c, c + G, ...; mask(b) = mask(parent) & AND_q V[entry(q, fr, b)].
+    // pair-table rows of the matched ancestors against level fr, one ancestor per lane of the group
+    auto fill_eb = [&](int fr, int nmr) {
+        const int kr = hk[fr], ksr = hksum[fr];
+        for (int q = c; q < nmr; q += G) eb[q] = entry_base(mat[q], ksr, kr);
+        ebf = fr;
+        wave_lds_sync();
+    };
     auto expand = [&](int fr) {
+        PROF(const unsigned long long e0 = __builtin_amdgcn_s_memtime());
         uchar4 Fr = frm[fr];
         const int nmr = Fr.w;
-        const int kr = hk[fr], ksr = hksum[fr];
+        const int kr = hk[fr];
+        PROF(++pn_exp; pn_vl += (unsigned)(nmr * ((kr + G - 1) / G)));
         uint64_t E = 0;
         const vm_t pm = msk[nmr];
+        fill_eb(fr, nmr);
         for (int b0 = 0; b0 < kr; b0 += G) {
             const int b = b0 + c;
             const bool on = b < kr;
             const int bb = on ? b : 0;
             vm_t m = on ? pm : (vm_t)0;
+            const uint32_t bv = (uint32_t)bb << VSH;
+            auto vld = [&](int q) -> vm_t { return *reinterpret_cast<const vm_t *>(Vb + (((uint32_t)eb[q] << VSH) + bv)); };
             int q = 0;
             for (; q + 8 <= nmr; q += 8) {
                 vm_t v[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = Vt[entry_base(mat[q + u], ksr, kr) + bb];
+                for (int u = 0; u < 8; ++u) v[u] = vld(q + u);
 #pragma unroll
                 for (int u = 0; u < 8; ++u) m &= v[u];
             }
             for (; q + 4 <= nmr; q += 4) {
-                const vm_t v0 = Vt[entry_base(mat[q], ksr, kr) + bb], v1 = Vt[entry_base(mat[q + 1], ksr, kr) + bb];
-                const vm_t v2 = Vt[entry_base(mat[q + 2], ksr, kr) + bb], v3 = Vt[entry_base(mat[q + 3], ksr, kr) + bb];
+                const vm_t v0 = vld(q), v1 = vld(q + 1), v2 = vld(q + 2), v3 = vld(q + 3);
                 m &= (vm_t)(v0 & v1 & v2 & v3);
             }
-            for (; q < nmr; ++q) m &= Vt[entry_base(mat[q], ksr, kr) + bb];
+            for (; q < nmr; ++q) m &= vld(q);
             if (on) cm[fr * K + b] = m;
             const unsigned long long bal = __ballot(on && m != 0);
             E |= ((G == 64) ? bal : ((bal >> (g * G)) & ((1ull << G) - 1ull))) << b0;
         }
         wave_lds_sync();
-        todo[fr] = E;
-        Fr.z |= F_EXPANDED | (E ? F_ANY : 0);
-        frm[fr] = Fr;
+        if (fr + 1 == nl) {
+            // The children are leaves: finish the whole frame here. Each existing candidate feeds the
+            // per-conformer maximum (graph_match.py:105-108) and returns 1; the skip leaf (tree.py:98-101,
+            // :42-43) carries this node's totals and returns 0; then return to the parent (tree.py:102).
+            const double tp = tot[nmr];
+            const int ksr = hksum[fr];
+            uint64_t left = E;
+            while (left) {
+                const int b = __ffsll((unsigned long long)left) - 1;
+                left &= left - 1;
+                const uint32_t bc = ((uint32_t)b << PSH) + 4u * (uint32_t)c;
+                const float self = *reinterpret_cast<const float *>(Sb + (((uint32_t)ksr << PSH) + bc));
+                const double t = tp + (double)self + pair_sum_eb<G>(Pb, eb, nmr, bc);
+                if (((cm[fr * K + b] >> c) & 1) && t > best) best = t;
+                PROF(++pn_leaf; pn_pl += (unsigned)nmr);
+            }
+            const int mx = E ? 1 : 0;
+            if (!E || nmr + mx < 5) {
+                if (((pm >> c) & 1) && tp > best) best = tp;
+            }
+            const unsigned char ret = (unsigned char)(mx + ((Fr.z & F_MATCHED) ? 1 : 0));
+            f = fr - 1;
+            if (f >= f0) {
+                uchar4 Pf = frm[f];
+                Pf.y = Pf.y > ret ? Pf.y : ret;
+                frm[f] = Pf;
+            }
+            PROF(++pn_ret);
+        } else {
+            todo[fr] = E;
+            Fr.z |= F_EXPANDED | (E ? F_ANY : 0);
+            frm[fr] = Fr;
+        }
+        PROF(pc_expand += __builtin_amdgcn_s_memtime() - e0);
     };
 
     if (g == 0) {
@@ -880,6 +962,7 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
 
     for (;;) {
         PMX_GUARD(12);
+        PROF(pt0 = __builtin_amdgcn_s_memtime());
         const unsigned long long busy_bal = __ballot(busy && c == 0);
         sp = __builtin_amdgcn_readfirstlane(sp);
         if (!busy_bal && sp == 0) break;
@@ -992,13 +1075,14 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
             if (!__builtin_amdgcn_readfirstlane((int)qtail[1])) sp = 0;
         }
 
+        PROF(pt1 = __builtin_amdgcn_s_memtime(); pc_share += pt1 - pt0);
         // ---- one DFS step per busy group: advance to (and through) the next frame expansion.
         // Leaf children are consumed inside their parent's step; a step ends when a new frame has been
         // entered and its candidates evaluated, or when the group's subtree is finished.
         if (busy) {
-            if (f < nl && !(frm[f].z & F_EXPANDED)) {
-                expand(f); // first step of a root (whole tree or adopted subtree)
-            } else {
+            // a step ends in one frame expansion; all groups of the wave do theirs together, below
+            bool need_exp = f < nl && !(frm[f].z & F_EXPANDED); // first step of a root (whole tree or adopted subtree)
+            if (!need_exp) {
                 for (uint32_t inner = 0; inner < step_cap; ++inner) { // optional bound on the work of one step (PMX_STEP_CAP)
                     PMX_GUARD(13);
                     uchar4 F = frm[f];
@@ -1029,19 +1113,21 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
                                 F.y = F.y > 1 ? F.y : 1; // the child given away returns at least 1
                                 frm[f] = F;
                                 exported = true;
+                                PROF(++pn_exported);
                                 continue;
                             }
                             if (c == 0) qtail[1] = 1; // queue full: walk it here
                         }
                         const vm_t m = cm[f * K + b];
                         // parent + self + accumulated pair (tree.py:38-41)
-                        const double t = tot[nm] + (double)St[(size_t)(ksf + b) * G + c] + pair_sum<G>(Pt, mat, nm, ksf, kf, b, c);
-                        if (f + 1 == nl) { // the child is a leaf: per-conformer maximum (graph_match.py:105-108), returns 1
-                            if (((m >> c) & 1) && t > best) best = t;
-                            F.y = F.y > 1 ? F.y : 1;
-                            frm[f] = F;
-                            continue;
+                        if (ebf != f) {
+                            fill_eb(f, nm); // back from a deeper frame
+                            PROF(++pn_fill);
                         }
+                        PROF(pn_pl += (unsigned)nm);
+                        const uint32_t bc = ((uint32_t)b << PSH) + 4u * (uint32_t)c;
+                        const float self = *reinterpret_cast<const float *>(Sb + (((uint32_t)ksf << PSH) + bc));
+                        const double t = tot[nm] + (double)self + pair_sum_eb<G>(Pb, eb, nm, bc);
                         tot[nm + 1] = t;
                         msk[nm + 1] = m;
                         // entry(this match, level f', b') = rowbase[f] + k_f * (ksum[f'] - ksum[f + 1]) + b * k_f' + b'
@@ -1049,25 +1135,23 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
                         ++f;
                         frm[f] = make_uchar4(0, 0, F_MATCHED, (unsigned char)(nm + 1));
                         if (f < sfr) sfr = f;
-                        expand(f);
+                        PROF(++pn_desc);
+                        need_exp = true;
                         break;
                     }
                     if (!(F.z & F_SKIP) && (!(F.z & F_ANY) || (nm + F.y) < 5)) { // skip child (tree.py:98-101)
                         F.z |= F_SKIP;
                         frm[f] = F;
-                        if (f + 1 == nl) { // a skip leaf carries this node's totals (tree.py:42-43) and returns 0
-                            const double t = tot[nm];
-                            if (((msk[nm] >> c) & 1) && t > best) best = t;
-                            continue;
-                        }
                         ++f;
                         frm[f] = make_uchar4(0, 0, 0, (unsigned char)nm);
                         if (f < sfr) sfr = f;
-                        expand(f);
+                        PROF(++pn_skip);
+                        need_exp = true;
                         break;
                     }
                     // all children done: return max_num_matches + matched (tree.py:102)
                     const unsigned char ret = (unsigned char)(F.y + (matched ? 1 : 0));
+                    PROF(++pn_ret);
                     --f;
                     if (f < f0) break;
                     uchar4 Pf = frm[f];
@@ -1075,9 +1159,27 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
                     frm[f] = Pf;
                 }
             }
+            if (need_exp) expand(f);
             if (f < f0) busy = false;
         }
+        PROF(const unsigned long long pt2 = __builtin_amdgcn_s_memtime(); pc_adv += pt2 - pt1; pc_all += pt2 - pt0);
     }
+#ifdef PMX_PROF
+    {
+        unsigned long long *pr = reinterpret_cast<unsigned long long *>(p.dbg + 96) + (TASKS ? 16 : 0);
+        if (lane == 0) {
+            atomicAdd(pr + 0, pc_all); atomicAdd(pr + 1, pc_share); atomicAdd(pr + 2, pc_expand); atomicAdd(pr + 3, pc_adv);
+            atomicAdd(pr + 4, total_iters);
+        }
+        if (c == 0) {
+            atomicAdd(pr + 5, (unsigned long long)pn_leaf); atomicAdd(pr + 6, (unsigned long long)pn_exp);
+            atomicAdd(pr + 7, (unsigned long long)pn_desc); atomicAdd(pr + 8, (unsigned long long)pn_pl);
+            atomicAdd(pr + 9, (unsigned long long)pn_vl); atomicAdd(pr + 10, (unsigned long long)pn_fill);
+            atomicAdd(pr + 11, (unsigned long long)pn_ret); atomicAdd(pr + 12, (unsigned long long)pn_skip);
+            atomicAdd(pr + 13, (unsigned long long)pn_exported);
+        }
+    }
+#endif
 
     // ---- combine the groups' per-conformer maxima; lanes of group 0 end up with the wave's maxima
 #pragma unroll
@@ -1104,6 +1206,7 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
 }
 
 #undef PMX_GUARD
+#undef PROF
 
 // One block (= one wavefront) per job, no persistent fetch loop: the hardware dispatcher hands the next
 // block to whichever CU frees a slot, which is the dynamic load balancing a work counter would give,
@@ -1132,10 +1235,8 @@ __global__ __launch_bounds__(64, 6) void tree_kernel(const TreeParams p) { // 6 
         if (lane == 0) p.scores[li] = __builtin_nanf("");
     } else if (bytes == 0) { // no ligand cluster has a candidate (graph_match.py:95-99)
         if (!TASKS && lane == 0) p.scores[li] = 0.f;
-    } else if ((uint32_t)round16((uint64_t)__builtin_amdgcn_readfirstlane(reinterpret_cast<const TabHeader *>(blk)->T) * sizeof(vmask_t<G>)) <= p.tabcap) {
-        run_job<G, TASKS, true>(p, smem, li, task, blk);
     } else {
-        run_job<G, TASKS, false>(p, smem, li, task, blk);
+        run_job<G, TASKS>(p, smem, li, task, blk);
     }
 }
 
