@@ -375,6 +375,7 @@ static int score_chunks(const pmx_model *model, const pmx_library *lib, const We
                 tables_kernel_v2<G><<<dim3((n + v2_waves - 1) / v2_waves), dim3(64 * v2_waves), lds2, stream>>>(
                     model->dm, lib->dl, W, lig0, n, status, ws.taboff, ws.arena);
             }
+            bounds_kernel<G><<<dim3((n + 3) / 4), dim3(256), 0, stream>>>(n, status, ws.taboff, ws.arena);
             HIPCHECK(hipGetLastError());
             if (trace_on()) {
                 TRACE("tables kernel launched (%u bytes of tables)", (unsigned)table_total);

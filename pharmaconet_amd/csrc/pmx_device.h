@@ -38,6 +38,8 @@ struct Weights {
 //   V : vmask_t [T]           conformer-validity mask of each pair entry (bit c <=> P[.][c] > 0, tree.py:81)
 //   S : float   [ksumtot][G]  self table  (match_utils.py:77-122)
 //   P : float   [T][G]        pair table  (match_utils.py:9-74), -1 where invalid
+//   R : double  [nl + 1][G]   R[f][c] = upper bound on what levels f.. can still add to conformer c's total
+//                             (bounds_kernel; lets the walker drop subtrees that cannot raise the maximum)
 // Pair entry (i, a, j, b), i < j: rowbase[i] + k[i] * (ksum[j] - ksum[i + 1]) + a * k[j] + b.
 struct TabHeader {
     uint32_t nl;      // number of tree levels (ligand clusters kept, <= 20)
@@ -57,9 +59,9 @@ using vmask_t = std::conditional_t<(G <= 8), uint8_t,
 __host__ __device__ inline uint64_t round16(uint64_t x) { return (x + 15) & ~uint64_t(15); }
 
 template <int G>
-__host__ __device__ inline uint64_t table_bytes(uint32_t T, uint32_t ksumtot) {
+__host__ __device__ inline uint64_t table_bytes(uint32_t T, uint32_t ksumtot, uint32_t nl) {
     return sizeof(TabHeader) + round16(uint64_t(T) * sizeof(vmask_t<G>)) + round16(uint64_t(ksumtot) * G * 4) +
-           round16(uint64_t(T) * G * 4);
+           round16(uint64_t(T) * G * 4) + uint64_t(nl + 1) * G * 8;
 }
 
 // A ligand record of the packed library (pharmaconet_amd/library.py).

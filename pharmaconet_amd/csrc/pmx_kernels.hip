@@ -62,7 +62,7 @@ __device__ inline Levels scan_levels(const Record &r, const uint64_t *tclus, F &
 template <int G>
 __device__ inline uint32_t table_units(const Levels &L) {
     if (L.nl == 0) return 0;
-    return (uint32_t)(table_bytes<G>(L.T, L.ksumtot) / 16);
+    return (uint32_t)(round16(table_bytes<G>(L.T, L.ksumtot, (uint32_t)L.nl)) / 16);
 }
 
 // ----------------------------------------------------------------------------------- sizes_kernel
@@ -569,6 +569,66 @@ __global__ __launch_bounds__(512, 6) void tables_kernel_v2(DevModel M, DevLibrar
     }
 }
 
+// ---------------------------------------------------------------------------------- bounds_kernel
+// Upper bounds for the tree search. The reported score only needs the per-conformer MAXIMUM over leaves
+// (graph_match.py:103-109), so a subtree whose best possible leaf cannot exceed the maximum found so far
+// may be dropped without changing the result, provided the walker's return-value bookkeeping does not
+// need it - which holds for subtrees rooted at nodes with >= 5 matches (see tree_kernel).
+// A leaf total is sum of S over the matched (level, candidate) picks + sum of P over pairs of picks.
+// For conformer c, level l can add at most
+//   U[l][c] = max(0, max_b ( S[l][b][c] + sum_{j < l} max(0, max_a P[(j, a), (l, b)][c]) ))
+// whatever is picked on the other levels, so R[f][c] = sum_{l >= f} U[l][c] bounds everything levels
+// f.. add to a node's total. One wavefront per ligand: lane c of group g takes candidates b = g, g + 64/G, ...
+template <int G>
+__global__ __launch_bounds__(256) void bounds_kernel(uint32_t count, const int32_t *status, const uint64_t *taboff, uint8_t *arena) {
+    constexpr int GPW = 64 / G;
+    const int lane = threadIdx.x & 63;
+    const int g = lane / G, c = lane % G;
+    const uint32_t li = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    if (li >= count) return;
+    if (status[li] != PMX_LIGAND_OK) return;
+    const uint64_t o0 = taboff[li], o1 = taboff[li + 1];
+    if (o1 == o0) return;
+    uint8_t *blk = arena + o0;
+    const TabHeader *H = reinterpret_cast<const TabHeader *>(blk);
+    const int nl = (int)H->nl;
+    const uint32_t T = H->T, ksumtot = H->ksumtot;
+    const uint32_t v_bytes = (uint32_t)round16(uint64_t(T) * sizeof(vmask_t<G>));
+    const uint32_t s_bytes = (uint32_t)round16(uint64_t(ksumtot) * G * 4);
+    const uint32_t p_bytes = (uint32_t)round16(uint64_t(T) * G * 4);
+    const unsigned char *tab = blk + sizeof(TabHeader);
+    const float *St = reinterpret_cast<const float *>(tab + v_bytes);
+    const float *Pt = reinterpret_cast<const float *>(tab + v_bytes + s_bytes);
+    double *Rt = reinterpret_cast<double *>(blk + sizeof(TabHeader) + v_bytes + s_bytes + p_bytes);
+    double suffix = 0.0;
+    if (g == 0) Rt[(size_t)nl * G + c] = 0.0;
+    for (int l = nl - 1; l >= 0; --l) {
+        const int kl = H->k[l], ksl = H->ksum[l];
+        double u = 0.0;
+        for (int b = g; b < kl; b += GPW) {
+            double v = (double)St[(size_t)(ksl + b) * G + c];
+            for (int j = 0; j < l; ++j) {
+                const int kj = H->k[j];
+                const uint32_t e0 = H->rowbase[j] + (uint32_t)kj * (uint32_t)(ksl - (int)H->ksum[j + 1]) + (uint32_t)b;
+                float m = 0.f;
+                for (int a = 0; a < kj; ++a) {
+                    const float pv = Pt[(size_t)(e0 + (uint32_t)a * (uint32_t)kl) * G + c];
+                    m = pv > m ? pv : m;
+                }
+                v += (double)m;
+            }
+            u = v > u ? v : u;
+        }
+#pragma unroll
+        for (int d = G; d < 64; d <<= 1) {
+            const double o = __shfl_xor(u, d);
+            u = o > u ? o : u;
+        }
+        suffix += u;
+        if (g == 0) Rt[(size_t)l * G + c] = suffix;
+    }
+}
+
 // ------------------------------------------------------------------------------------ tree_kernel
 // Iterative form of ClusterMatchTree.dfs_run (tree.py:55-104). A frame f describes the tree node at
 // level f - 1 (frame 0 = root): `todo` = existing candidate children of level f not yet explored,
@@ -788,7 +848,7 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
     uint32_t guard = 0;
 #ifdef PMX_PROF // build with PMX_CXXFLAGS=-DPMX_PROF: where a wave's time goes (s_memtime) and what it does
     unsigned long long pc_share = 0, pc_expand = 0, pc_adv = 0, pc_all = 0, pt0 = 0, pt1 = 0;
-    unsigned pn_leaf = 0, pn_exp = 0, pn_desc = 0, pn_pl = 0, pn_vl = 0, pn_fill = 0, pn_ret = 0, pn_skip = 0, pn_exported = 0;
+    unsigned pn_leaf = 0, pn_exp = 0, pn_desc = 0, pn_pl = 0, pn_vl = 0, pn_fill = 0, pn_ret = 0, pn_skip = 0, pn_exported = 0, pn_pruned = 0;
 #define PROF(x) x
 #else
 #define PROF(x)
@@ -802,12 +862,14 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
     const uint32_t s_bytes = (uint32_t)round16(uint64_t(ksumtot) * G * 4);
     const uint32_t p_bytes = (uint32_t)round16(uint64_t(T) * G * 4);
     const unsigned char *tab = blk + sizeof(TabHeader);
-    (void)p_bytes;
     const float *St = reinterpret_cast<const float *>(tab + v_bytes);
     const float *Pt = reinterpret_cast<const float *>(tab + v_bytes + s_bytes);
     const unsigned char *Pb = reinterpret_cast<const unsigned char *>(Pt); // wave-uniform: one job per wave
     const unsigned char *Vb = tab; // validity masks
     const unsigned char *Sb = reinterpret_cast<const unsigned char *>(St);
+    const unsigned char *Rb = tab + v_bytes + s_bytes + p_bytes; // R[f][c]: what levels f.. can still add (bounds_kernel)
+    constexpr int RSH = p_entry_shift<G>() + 1;                  // log2 bytes of one row of R (G doubles)
+    constexpr double kBoundSlack = 1.0 + 1e-9; // covers the float64 rounding of the sums the bound is compared with
     constexpr int PSH = p_entry_shift<G>();
     constexpr int VSH = sizeof(vm_t) == 1 ? 0 : sizeof(vm_t) == 2 ? 1 : sizeof(vm_t) == 4 ? 2 : 3;
     for (int i = lane; i <= nl; i += 64) {
@@ -826,6 +888,7 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
     uint32_t iters = 0;
     unsigned long long nsteps = 0, total_iters = 0;
     double best = 0.0; // graph_match.py:104
+    if (TASKS) best = __longlong_as_double((long long)p.bestbuf[(size_t)li * G + c]); // maxima of the ligand's finished walkers
 
     // start a walker on the subtree described by a task record (global queue or local stack)
     auto adopt = [&](const TaskHeader *th) {
@@ -844,9 +907,7 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
         busy = true;
     };
     // describe candidate b of frame fr (conformer mask m) as a task record
-    auto describe = [&](TaskHeader *th, int fr, int nmr, int b, vm_t m) {
-        const int kr = hk[fr], ksr = hksum[fr];
-        const double pair = pair_sum<G>(Pt, mat, nmr, ksr, kr, b, c);
+    auto describe = [&](TaskHeader *th, int fr, int nmr, int b, vm_t m, double t) {
         th->lig = li;
         th->f0 = (uint8_t)(fr + 1);
         th->nm = (uint8_t)(nmr + 1);
@@ -858,7 +919,18 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
         }
         th->path[2 * nmr] = (uint8_t)fr;
         th->path[2 * nmr + 1] = (uint8_t)b;
-        reinterpret_cast<double *>(th + 1)[c] = tot[nmr] + (double)St[(size_t)(ksr + b) * G + c] + pair;
+        reinterpret_cast<double *>(th + 1)[c] = t;
+    };
+    // total of candidate b of frame fr: parent + self + accumulated pair (tree.py:38-41); any frame, slow path
+    auto child_total = [&](int fr, int nmr, int b) -> double {
+        const int kr = hk[fr], ksr = hksum[fr];
+        return tot[nmr] + (double)St[(size_t)(ksr + b) * G + c] + pair_sum<G>(Pt, mat, nmr, ksr, kr, b, c);
+    };
+    // can the subtree below a child (frame fr + 1, conformer mask m, total t) still raise a conformer's maximum?
+    auto may_improve = [&](int fr, vm_t m, double t) -> bool {
+        const double r = *reinterpret_cast<const double *>(Rb + (((uint32_t)(fr + 1) << RSH) + 8u * (uint32_t)c));
+        const unsigned long long bal = __ballot(((m >> c) & 1) && (t + r) * kBoundSlack > best);
+        return ((G == 64) ? bal : ((bal >> (g * G)) & ((1ull << G) - 1ull))) != 0;
     };
     // a frame may give children away once it has >= 4 matches (their subtrees hold >= 5, see above)
     auto donatable = [&](int fr) -> bool {
@@ -1003,7 +1075,8 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
                     const uint64_t left = todo[sfr];
                     const int b = __ffsll((unsigned long long)left) - 1;
                     todo[sfr] = left & (left - 1);
-                    describe(reinterpret_cast<TaskHeader *>(lstk + (size_t)(sp + rank) * task_bytes<G>()), sfr, Fr.w, b, cm[sfr * K + b]);
+                    describe(reinterpret_cast<TaskHeader *>(lstk + (size_t)(sp + rank) * task_bytes<G>()), sfr, Fr.w, b, cm[sfr * K + b],
+                             child_total(sfr, Fr.w, b));
                     Fr.y = Fr.y > 1 ? Fr.y : 1; // the child given away returns at least 1
                     frm[sfr] = Fr;
                 }
@@ -1011,6 +1084,12 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
                 wave_lds_sync();
             }
             if (sp > 0) {
+                // the groups walk parts of one tree: pool the maxima found so far (tightens the bound test)
+#pragma unroll
+                for (int d = G; d < 64; d <<= 1) {
+                    const double o = __shfl_xor(best, d);
+                    best = o > best ? o : best;
+                }
                 const unsigned long long idle_bal = __ballot(!busy && c == 0);
                 const int rank = __popcll(idle_bal & below);
                 const int npop = min(sp, n_idle);
@@ -1040,7 +1119,8 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
                             break;
                         }
                         const int b = __ffsll((unsigned long long)left) - 1;
-                        describe(reinterpret_cast<TaskHeader *>(queue + (size_t)slot * task_bytes<G>()), fr, Fr.w, b, cm[fr * K + b]);
+                        describe(reinterpret_cast<TaskHeader *>(queue + (size_t)slot * task_bytes<G>()), fr, Fr.w, b, cm[fr * K + b],
+                                 child_total(fr, Fr.w, b));
                         left &= left - 1;
                         gave = true;
                         Fr.y = Fr.y > 1 ? Fr.y : 1;
@@ -1104,30 +1184,38 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
                         const int kf = hk[f], ksf = hksum[f];
                         const int b = __ffsll((unsigned long long)left) - 1;
                         todo[f] = left & (left - 1);
-                        if (export_mode && nm >= 4 && nl - (f + 1) >= (int)min_levels) {
-                            uint32_t slot = 0;
-                            if (c == 0) slot = atomicAdd(qtail, 1u);
-                            slot = __shfl(slot, g * G);
-                            if (slot < qcap) {
-                                describe(reinterpret_cast<TaskHeader *>(queue + (size_t)slot * task_bytes<G>()), f, nm, b, cm[f * K + b]);
-                                F.y = F.y > 1 ? F.y : 1; // the child given away returns at least 1
-                                frm[f] = F;
-                                exported = true;
-                                PROF(++pn_exported);
-                                continue;
-                            }
-                            if (c == 0) qtail[1] = 1; // queue full: walk it here
-                        }
                         const vm_t m = cm[f * K + b];
-                        // parent + self + accumulated pair (tree.py:38-41)
                         if (ebf != f) {
                             fill_eb(f, nm); // back from a deeper frame
                             PROF(++pn_fill);
                         }
                         PROF(pn_pl += (unsigned)nm);
+                        // parent + self + accumulated pair (tree.py:38-41)
                         const uint32_t bc = ((uint32_t)b << PSH) + 4u * (uint32_t)c;
                         const float self = *reinterpret_cast<const float *>(Sb + (((uint32_t)ksf << PSH) + bc));
                         const double t = tot[nm] + (double)self + pair_sum_eb<G>(Pb, eb, nm, bc);
+                        if (nm >= 4) { // the child holds >= 5 matches: its subtree is a pure enumeration of leaves
+                            if (!may_improve(f, m, t)) { // no leaf below can exceed the maxima found so far
+                                F.y = F.y > 1 ? F.y : 1; // the dropped child returns at least 1
+                                frm[f] = F;
+                                PROF(++pn_pruned);
+                                continue;
+                            }
+                            if (export_mode && nl - (f + 1) >= (int)min_levels) {
+                                uint32_t slot = 0;
+                                if (c == 0) slot = atomicAdd(qtail, 1u);
+                                slot = __shfl(slot, g * G);
+                                if (slot < qcap) {
+                                    describe(reinterpret_cast<TaskHeader *>(queue + (size_t)slot * task_bytes<G>()), f, nm, b, m, t);
+                                    F.y = F.y > 1 ? F.y : 1; // the child given away returns at least 1
+                                    frm[f] = F;
+                                    exported = true;
+                                    PROF(++pn_exported);
+                                    continue;
+                                }
+                                if (c == 0) qtail[1] = 1; // queue full: walk it here
+                            }
+                        }
                         tot[nm + 1] = t;
                         msk[nm + 1] = m;
                         // entry(this match, level f', b') = rowbase[f] + k_f * (ksum[f'] - ksum[f + 1]) + b * k_f' + b'
@@ -1176,7 +1264,7 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
             atomicAdd(pr + 7, (unsigned long long)pn_desc); atomicAdd(pr + 8, (unsigned long long)pn_pl);
             atomicAdd(pr + 9, (unsigned long long)pn_vl); atomicAdd(pr + 10, (unsigned long long)pn_fill);
             atomicAdd(pr + 11, (unsigned long long)pn_ret); atomicAdd(pr + 12, (unsigned long long)pn_skip);
-            atomicAdd(pr + 13, (unsigned long long)pn_exported);
+            atomicAdd(pr + 13, (unsigned long long)pn_exported); atomicAdd(pr + 14, (unsigned long long)pn_pruned);
         }
     }
 #endif
