@@ -229,8 +229,10 @@ extern "C" int pmx_library_destroy(pmx_library *lib) {
 }
 
 // ---------------------------------------------------------------------------------- workspace
-struct Workspace {
-    uint32_t chunk_cap = 0;
+// Chunks are software-pipelined over two buffer slots: while the tree kernels of chunk k run on the caller's
+// stream, the table kernels of chunk k + 1 run on an internal side stream. The two phases bind differently
+// (tables: VALU / LDS; tree search: memory latency), so their wavefronts share the CUs well.
+struct Slot {
     uint32_t *units = nullptr;
     int32_t *status = nullptr;
     uint64_t *taboff = nullptr;
@@ -238,12 +240,25 @@ struct Workspace {
     size_t arena_cap = 0;
     uint32_t *meta = nullptr;      // device: [0] max levels, [1] fetch counter, [2..3] table bytes (u64), [4] task queue tail, [5] queue overflow
     uint32_t *meta_host = nullptr; // pinned mirror
-    uint8_t *queue = nullptr;      // task queue of the tree kernels
-    size_t queue_bytes = 0;
     unsigned long long *bestbuf = nullptr; // [chunk_cap][64] per-conformer maxima of split ligands
     uint8_t *deferred = nullptr;           // [chunk_cap]
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // profiling: sizes | tables | tree start | tier 1 | tasks
+    hipEvent_t tables_done = nullptr; // side stream: tables + bounds of the chunk in this slot are written
+    hipEvent_t walk_done = nullptr;   // caller's stream: the tree kernels no longer need this slot
+    // per-chunk values carried from the table phase to the tree phase
+    uint32_t n = 0, max_levels = 0;
+    uint64_t lig0 = 0, table_total = 0;
+    bool walked = false;
+};
+
+struct Workspace {
+    uint32_t chunk_cap = 0;
+    Slot slot[2];
+    uint8_t *queue = nullptr; // task queue of the tree kernels (one chunk walks at a time)
+    size_t queue_bytes = 0;
     int num_cu = 0;
-    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipStream_t side = nullptr;
+    hipEvent_t entry = nullptr;
 };
 static std::map<int, Workspace> g_ws;
 static std::mutex g_mu;
@@ -267,25 +282,33 @@ static int ensure_workspace(int device, Workspace **out) {
     Workspace &w = g_ws[device];
     const uint32_t cap = chunk_size();
     if (w.chunk_cap < cap) {
-        if (w.units) (void)hipFree(w.units);
-        if (w.status) (void)hipFree(w.status);
-        if (w.taboff) (void)hipFree(w.taboff);
-        HIPCHECK(hipMalloc((void **)&w.units, (size_t)cap * 4));
-        HIPCHECK(hipMalloc((void **)&w.status, (size_t)cap * 4));
-        HIPCHECK(hipMalloc((void **)&w.taboff, ((size_t)cap + 1) * 8));
-        if (w.bestbuf) (void)hipFree(w.bestbuf);
-        if (w.deferred) (void)hipFree(w.deferred);
-        HIPCHECK(hipMalloc((void **)&w.bestbuf, (size_t)cap * 64 * 8));
-        HIPCHECK(hipMalloc((void **)&w.deferred, (size_t)cap));
+        for (Slot &sl : w.slot) {
+            if (sl.units) (void)hipFree(sl.units);
+            if (sl.status) (void)hipFree(sl.status);
+            if (sl.taboff) (void)hipFree(sl.taboff);
+            if (sl.bestbuf) (void)hipFree(sl.bestbuf);
+            if (sl.deferred) (void)hipFree(sl.deferred);
+            HIPCHECK(hipMalloc((void **)&sl.units, (size_t)cap * 4));
+            HIPCHECK(hipMalloc((void **)&sl.status, (size_t)cap * 4));
+            HIPCHECK(hipMalloc((void **)&sl.taboff, ((size_t)cap + 1) * 8));
+            HIPCHECK(hipMalloc((void **)&sl.bestbuf, (size_t)cap * 64 * 8));
+            HIPCHECK(hipMalloc((void **)&sl.deferred, (size_t)cap));
+        }
         w.chunk_cap = cap;
     }
-    if (!w.meta) {
-        HIPCHECK(hipMalloc((void **)&w.meta, 1024));
-        HIPCHECK(hipHostMalloc((void **)&w.meta_host, 1024));
+    if (!w.side) {
         hipDeviceProp_t prop;
         HIPCHECK(hipGetDeviceProperties(&prop, device));
         w.num_cu = prop.multiProcessorCount;
-        for (auto &ev : w.ev) HIPCHECK(hipEventCreate(&ev));
+        HIPCHECK(hipStreamCreateWithFlags(&w.side, hipStreamNonBlocking));
+        HIPCHECK(hipEventCreateWithFlags(&w.entry, hipEventDisableTiming));
+        for (Slot &sl : w.slot) {
+            HIPCHECK(hipMalloc((void **)&sl.meta, 1024));
+            HIPCHECK(hipHostMalloc((void **)&sl.meta_host, 1024));
+            for (auto &ev : sl.ev) HIPCHECK(hipEventCreate(&ev));
+            HIPCHECK(hipEventCreateWithFlags(&sl.tables_done, hipEventDisableTiming));
+            HIPCHECK(hipEventCreateWithFlags(&sl.walk_done, hipEventDisableTiming));
+        }
     }
     if (!w.queue) {
         w.queue_bytes = (size_t)std::max<long>(16, env_long("PMX_TASKQ_MB", 4096)) << 20;
@@ -311,15 +334,190 @@ static bool trace_on() {
         }                                 \
     } while (0)
 
+// Table phase of one chunk on stream `q`: sizes -> scan -> (one small device-to-host read) -> pair-score
+// tables -> search bounds.
 template <int G>
-static int score_chunks(const pmx_model *model, const pmx_library *lib, const Weights &W, uint64_t first, uint64_t count,
-                        float *scores_dev, int32_t *status_dev, hipStream_t stream, Workspace &ws) {
+static int table_phase(const pmx_model *model, const pmx_library *lib, const Weights &W, uint64_t lig0, uint32_t n,
+                       int32_t *status, Slot &sl, hipStream_t q) {
     constexpr int GPW = 64 / G;
-    const uint32_t cap = ws.chunk_cap;
-    static bool attr_set = false;
     const int Nm = model->dm.Nm;
     const int tab_waves = 4;
     const size_t tab_lds = (size_t)Nm * Nm * sizeof(float4) + 64 * 8 + 128 * 8 + (size_t)tab_waves * GPW * sizeof(GroupLevels);
+    if (sl.walked) HIPCHECK(hipStreamWaitEvent(q, sl.walk_done, 0)); // the slot's previous chunk has been walked
+    sl.n = n;
+    sl.lig0 = lig0;
+    {
+        const uint64_t words = std::max<uint64_t>((uint64_t)n * G, 256);
+        clear_kernel<<<dim3((unsigned)((words + 255) / 256)), dim3(256), 0, q>>>(sl.meta, 256, sl.bestbuf, (uint64_t)n * G, sl.deferred, n);
+    }
+    if (g_profiling) HIPCHECK(hipEventRecord(sl.ev[0], q));
+    sizes_kernel<G><<<dim3((n + 255) / 256), dim3(256), 0, q>>>(lib->dl, model->dm.tclus, lig0, n, sl.units, status, sl.meta);
+    scan_kernel<<<dim3(1), dim3(1024), 0, q>>>(sl.units, n, sl.taboff, reinterpret_cast<uint64_t *>(sl.meta + 2));
+    HIPCHECK(hipGetLastError());
+    TRACE("chunk at %llu: sizes+scan launched, n=%u", (unsigned long long)lig0, n);
+    HIPCHECK(hipMemcpyAsync(sl.meta_host, sl.meta, 1024, hipMemcpyDeviceToHost, q));
+    HIPCHECK(hipStreamSynchronize(q));
+    sl.max_levels = sl.meta_host[0];
+    std::memcpy(&sl.table_total, sl.meta_host + 2, 8);
+    TRACE("max_levels=%u table bytes=%llu", sl.max_levels, (unsigned long long)sl.table_total);
+    if (sl.table_total > sl.arena_cap) {
+        if (sl.arena) (void)hipFree(sl.arena);
+        sl.arena = nullptr;
+        sl.arena_cap = 0;
+        const size_t want = (size_t)(sl.table_total + sl.table_total / 4 + (1u << 20));
+        HIPCHECK(hipMalloc((void **)&sl.arena, want));
+        sl.arena_cap = want;
+    }
+    if (g_profiling) HIPCHECK(hipEventRecord(sl.ev[1], q));
+    if (sl.table_total > 0) {
+        static const bool force_v1 = std::getenv("PMX_TABLES_V1") != nullptr;
+        const size_t model_lds = (size_t)Nm * Nm * sizeof(float4) + 64 * 8 + 128 * 8;
+        int v2_waves = 0; // waves (= ligands) per block that fit the 160 KB of LDS next to the model tables
+        if (model_lds + tables_v2_wave_bytes<G>() + 1024 <= kLdsPerCu)
+            v2_waves = (int)std::min<size_t>(8, (kLdsPerCu - 1024 - model_lds) / tables_v2_wave_bytes<G>()); // <= 8 ligands share one staged model
+        if (force_v1 || v2_waves < 1) {
+            const uint32_t groups_per_block = tab_waves * GPW;
+            tables_kernel<G><<<dim3((n + groups_per_block - 1) / groups_per_block), dim3(64 * tab_waves), tab_lds, q>>>(
+                model->dm, lib->dl, W, lig0, n, status, sl.taboff, sl.arena);
+        } else {
+            const size_t lds2 = model_lds + (size_t)v2_waves * tables_v2_wave_bytes<G>();
+            tables_kernel_v2<G><<<dim3((n + v2_waves - 1) / v2_waves), dim3(64 * v2_waves), lds2, q>>>(
+                model->dm, lib->dl, W, lig0, n, status, sl.taboff, sl.arena);
+        }
+        bounds_kernel<G><<<dim3((n + 3) / 4), dim3(256), 0, q>>>(n, status, sl.taboff, sl.arena);
+        HIPCHECK(hipGetLastError());
+    }
+    if (g_profiling) HIPCHECK(hipEventRecord(sl.ev[2], q));
+    HIPCHECK(hipEventRecord(sl.tables_done, q));
+    return PMX_OK;
+}
+
+// Tree phase of the chunk in `sl` on the caller's stream: one wavefront per ligand, then rounds over the task
+// queue (one small device-to-host read per round), then the scores of split ligands.
+template <int G>
+static int tree_phase(const pmx_model *model, const pmx_library *lib, int32_t *status, float *scores, Slot &sl, Workspace &ws,
+                      hipStream_t stream) {
+    const uint32_t n = sl.n;
+    const uint64_t lig0 = sl.lig0;
+    HIPCHECK(hipStreamWaitEvent(stream, sl.tables_done, 0));
+    if (g_profiling) HIPCHECK(hipEventRecord(sl.ev[3], stream));
+    const int depth = std::max<int>(1, (int)sl.max_levels);
+    const int Kc = std::max(1, model->dm.K);
+    const size_t lds = tree_wave_bytes<G>(depth, Kc) + (size_t)std::max<long>(0, env_long("PMX_LDS_PAD", 0));
+    if (lds > kLdsPerCu) return fail(PMX_ERR_INVALID, "tree state of %zu bytes does not fit LDS", lds);
+    TreeParams tp;
+    tp.arena = sl.arena;
+    tp.taboff = sl.taboff;
+    tp.status = status;
+    tp.lib = lib->dl;
+    tp.first = lig0;
+    tp.count = n;
+    tp.task_lo = 0;
+    tp.counter = sl.meta + 1;
+    tp.qtail = sl.meta + 4;
+    tp.queue = ws.queue;
+    tp.qcap = (uint32_t)std::min<size_t>(ws.queue_bytes / task_bytes<G>(), 0x7fffffffu);
+    tp.bestbuf = sl.bestbuf;
+    tp.deferred = sl.deferred;
+    tp.depth_cap = depth;
+    tp.K = Kc;
+    tp.budget = (uint32_t)std::max<long>(64, env_long("PMX_BUDGET", 1024));
+    tp.scores = scores;
+    tp.step_cap = (uint32_t)std::max<long>(1, env_long("PMX_STEP_CAP", 1 << 20));
+    tp.share_levels = (uint32_t)std::max<long>(0, env_long("PMX_SHARE_LEVELS", 1));
+    tp.min_levels = (uint32_t)std::max<long>(0, env_long("PMX_MIN_LEVELS", 4));
+    tp.flags = (uint32_t)env_long("PMX_TREE_FLAGS", 0);
+    tp.nsteps = reinterpret_cast<unsigned long long *>(sl.meta + 6);
+    tp.dbg = sl.meta + 32;
+    tp.max_iters = (unsigned long long)std::max<long>(1, env_long("PMX_MAXITERS", 1L << 31));
+    TRACE("tree kernel: grid=%u lds=%zu depth=%d", n, lds, depth);
+    tree_kernel<G, false><<<dim3(n), dim3(64), lds, stream>>>(tp);
+    HIPCHECK(hipGetLastError());
+    if (g_profiling) HIPCHECK(hipEventRecord(sl.ev[4], stream));
+    // rounds over the task queue: walkers that ran over budget appended subtrees
+    uint32_t lo = 0;
+    for (;;) {
+        HIPCHECK(hipMemcpyAsync(sl.meta_host, sl.meta, 1024, hipMemcpyDeviceToHost, stream));
+        HIPCHECK(hipStreamSynchronize(stream));
+        const uint32_t *mh = sl.meta_host;
+        if (lo == 0 && g_stats.n_rounds == 0) {
+            unsigned long long ns1;
+            std::memcpy(&ns1, mh + 6, 8);
+            g_stats.n_steps_first += ns1;
+        }
+        const uint32_t hi = std::min<uint32_t>(mh[4], tp.qcap);
+        TRACE("round: lo=%u hi=%u", lo, hi);
+        if (mh[5]) g_stats.queue_overflow = 1;
+        if (mh[32] == 2) return fail(PMX_ERR_INVALID, "tree kernel watchdog fired at location %u", mh[35]);
+        if (mh[32]) {
+            char buf[400];
+            int o = snprintf(buf, sizeof(buf), "tree walk hit the iteration cap (nl=%u busy=%u):", mh[33], mh[34]);
+            for (int gq = 0; gq < 8 && o < 380; ++gq) {
+                const uint32_t *d = mh + 32 + 16 + gq * 8;
+                o += snprintf(buf + o, sizeof(buf) - o, " [g%d li=%u busy=%u f=%d f0=%d sp=%d sfr=%d frm=%08x todo=%x]", gq, d[0], d[1], (int)d[2], (int)d[3], (int)d[4], (int)d[5], d[6], d[7]);
+            }
+            return fail(PMX_ERR_INVALID, "%s", buf);
+        }
+        if (hi <= lo) {
+            unsigned long long ns;
+            std::memcpy(&ns, mh + 6, 8);
+            g_stats.n_steps += ns;
+            std::memcpy(&ns, mh + 8, 8);
+            g_stats.n_iters += ns;
+            std::memcpy(&ns, mh + 10, 8);
+            g_stats.max_iters_ligand = std::max<uint64_t>(g_stats.max_iters_ligand, ns);
+            std::memcpy(&ns, mh + 12, 8);
+            g_stats.max_iters_task = std::max<uint64_t>(g_stats.max_iters_task, ns);
+#ifdef PMX_PROF
+            {
+                fprintf(stderr, "PMXPROF");
+                for (int i = 0; i < 32; ++i) {
+                    std::memcpy(&ns, mh + 128 + 2 * i, 8);
+                    fprintf(stderr, " %llu", ns);
+                }
+                fprintf(stderr, "\n");
+            }
+#endif
+            break;
+        }
+        tp.count = hi - lo;
+        tp.task_lo = lo;
+        tree_kernel<G, true><<<dim3(tp.count), dim3(64), lds, stream>>>(tp);
+        HIPCHECK(hipGetLastError());
+        g_stats.n_tasks += tp.count;
+        g_stats.n_rounds += 1;
+        lo = hi;
+    }
+    if (lo > 0) {
+        finalize_kernel<G><<<dim3((n + 255) / 256), dim3(256), 0, stream>>>(lib->dl, lig0, n, sl.deferred, sl.bestbuf, scores);
+        HIPCHECK(hipGetLastError());
+    }
+    HIPCHECK(hipEventRecord(sl.walk_done, stream));
+    sl.walked = true;
+    if (g_profiling) {
+        HIPCHECK(hipEventRecord(sl.ev[5], stream));
+        HIPCHECK(hipEventSynchronize(sl.ev[5]));
+        float a = 0, b = 0, c = 0, d = 0;
+        HIPCHECK(hipEventElapsedTime(&a, sl.ev[0], sl.ev[1]));
+        HIPCHECK(hipEventElapsedTime(&b, sl.ev[1], sl.ev[2]));
+        HIPCHECK(hipEventElapsedTime(&c, sl.ev[3], sl.ev[4]));
+        HIPCHECK(hipEventElapsedTime(&d, sl.ev[4], sl.ev[5]));
+        g_stats.ms_sizes += a;
+        g_stats.ms_tables += b;
+        g_stats.ms_tree += c;
+        g_stats.ms_tasks += d;
+        g_stats.ms_total += a + b + c + d;
+    }
+    g_stats.table_bytes += sl.table_total;
+    g_stats.n_chunks += 1;
+    return PMX_OK;
+}
+
+template <int G>
+static int score_chunks(const pmx_model *model, const pmx_library *lib, const Weights &W, uint64_t first, uint64_t count,
+                        float *scores_dev, int32_t *status_dev, hipStream_t stream, Workspace &ws) {
+    const uint32_t cap = ws.chunk_cap;
+    static bool attr_set = false;
     if (!attr_set) {
         HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&tables_kernel<G>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));
@@ -331,180 +529,27 @@ static int score_chunks(const pmx_model *model, const pmx_library *lib, const We
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));
         attr_set = true;
     }
-    for (uint64_t done = 0; done < count; done += cap) {
-        const uint32_t n = (uint32_t)std::min<uint64_t>(cap, count - done);
-        const uint64_t lig0 = first + done;
-        int32_t *status = status_dev ? status_dev + done : ws.status;
-        float *scores = scores_dev + done;
-        {
-            const uint64_t words = std::max<uint64_t>((uint64_t)n * G, 256);
-            clear_kernel<<<dim3((unsigned)((words + 255) / 256)), dim3(256), 0, stream>>>(ws.meta, 256, ws.bestbuf, (uint64_t)n * G, ws.deferred, n);
-        }
-        if (g_profiling) HIPCHECK(hipEventRecord(ws.ev[0], stream));
-        sizes_kernel<G><<<dim3((n + 255) / 256), dim3(256), 0, stream>>>(lib->dl, model->dm.tclus, lig0, n, ws.units, status, ws.meta);
-        scan_kernel<<<dim3(1), dim3(1024), 0, stream>>>(ws.units, n, ws.taboff, reinterpret_cast<uint64_t *>(ws.meta + 2));
-        HIPCHECK(hipGetLastError());
-        TRACE("chunk %llu: sizes+scan launched, n=%u", (unsigned long long)done, n);
-        HIPCHECK(hipMemcpyAsync(ws.meta_host, ws.meta, 1024, hipMemcpyDeviceToHost, stream));
-        HIPCHECK(hipStreamSynchronize(stream));
-        const uint32_t max_levels = ws.meta_host[0];
-        TRACE("max_levels=%u", max_levels);
-        uint64_t table_total;
-        std::memcpy(&table_total, ws.meta_host + 2, 8);
-        if (table_total > ws.arena_cap) {
-            if (ws.arena) (void)hipFree(ws.arena);
-            ws.arena = nullptr;
-            ws.arena_cap = 0;
-            const size_t want = (size_t)(table_total + table_total / 4 + (1u << 20));
-            HIPCHECK(hipMalloc((void **)&ws.arena, want));
-            ws.arena_cap = want;
-        }
-        if (g_profiling) HIPCHECK(hipEventRecord(ws.ev[1], stream));
-        if (table_total > 0) {
-            static const bool force_v1 = std::getenv("PMX_TABLES_V1") != nullptr;
-            const size_t model_lds = (size_t)Nm * Nm * sizeof(float4) + 64 * 8 + 128 * 8;
-            int v2_waves = 0; // waves (= ligands) per block that fit the 160 KB of LDS next to the model tables
-            if (model_lds + tables_v2_wave_bytes<G>() + 1024 <= kLdsPerCu)
-                v2_waves = (int)std::min<size_t>(8, (kLdsPerCu - 1024 - model_lds) / tables_v2_wave_bytes<G>()); // <= 8 ligands share one staged model
-            if (force_v1 || v2_waves < 1) {
-                const uint32_t groups_per_block = tab_waves * GPW;
-                tables_kernel<G><<<dim3((n + groups_per_block - 1) / groups_per_block), dim3(64 * tab_waves), tab_lds, stream>>>(
-                    model->dm, lib->dl, W, lig0, n, status, ws.taboff, ws.arena);
-            } else {
-                const size_t lds2 = model_lds + (size_t)v2_waves * tables_v2_wave_bytes<G>();
-                tables_kernel_v2<G><<<dim3((n + v2_waves - 1) / v2_waves), dim3(64 * v2_waves), lds2, stream>>>(
-                    model->dm, lib->dl, W, lig0, n, status, ws.taboff, ws.arena);
-            }
-            bounds_kernel<G><<<dim3((n + 3) / 4), dim3(256), 0, stream>>>(n, status, ws.taboff, ws.arena);
-            HIPCHECK(hipGetLastError());
-            if (trace_on()) {
-                TRACE("tables kernel launched (%u bytes of tables)", (unsigned)table_total);
-                HIPCHECK(hipStreamSynchronize(stream));
-                TRACE("tables kernel done");
-                std::vector<uint64_t> offs(std::min<uint32_t>(n, 8) + 1);
-                HIPCHECK(hipMemcpy(offs.data(), ws.taboff, offs.size() * 8, hipMemcpyDeviceToHost));
-                for (size_t q = 0; q + 1 < offs.size(); ++q) {
-                    uint32_t hdr[4] = {0, 0, 0, 0};
-                    if (offs[q + 1] > offs[q]) HIPCHECK(hipMemcpy(hdr, ws.arena + offs[q], 16, hipMemcpyDeviceToHost));
-                    TRACE("  ligand %zu: taboff=%llu bytes=%llu header nl=%u T=%u ksumtot=%u", q, (unsigned long long)offs[q],
-                          (unsigned long long)(offs[q + 1] - offs[q]), hdr[0], hdr[1], hdr[2]);
-                }
-            }
-        }
-        if (g_profiling) HIPCHECK(hipEventRecord(ws.ev[2], stream));
-        {
-            const int depth = std::max<int>(1, (int)max_levels);
-            const int Kc = std::max(1, model->dm.K);
-            const size_t lds = tree_wave_bytes<G>(depth, Kc) + (size_t)std::max<long>(0, env_long("PMX_LDS_PAD", 0));
-            if (lds > kLdsPerCu) return fail(PMX_ERR_INVALID, "tree state of %zu bytes does not fit LDS", lds);
-            int waves_per_cu = (int)std::min<size_t>(16, kLdsPerCu / (lds + 256));
-            waves_per_cu = std::max(1, waves_per_cu);
-            TreeParams tp;
-            tp.arena = ws.arena;
-            tp.taboff = ws.taboff;
-            tp.status = status;
-            tp.lib = lib->dl;
-            tp.first = lig0;
-            tp.count = n;
-            tp.task_lo = 0;
-            tp.counter = ws.meta + 1;
-            tp.qtail = ws.meta + 4;
-            tp.queue = ws.queue;
-            tp.qcap = (uint32_t)std::min<size_t>(ws.queue_bytes / task_bytes<G>(), 0x7fffffffu);
-            tp.bestbuf = ws.bestbuf;
-            tp.deferred = ws.deferred;
-            tp.depth_cap = depth;
-            tp.K = Kc;
-            tp.budget = (uint32_t)std::max<long>(64, env_long("PMX_BUDGET", 1024));
-            tp.scores = scores;
-            tp.step_cap = (uint32_t)std::max<long>(1, env_long("PMX_STEP_CAP", 1 << 20));
-            tp.share_levels = (uint32_t)std::max<long>(0, env_long("PMX_SHARE_LEVELS", 1));
-            tp.min_levels = (uint32_t)std::max<long>(0, env_long("PMX_MIN_LEVELS", 4));
-            tp.flags = (uint32_t)env_long("PMX_TREE_FLAGS", 0);
-            tp.nsteps = reinterpret_cast<unsigned long long *>(ws.meta + 6);
-            tp.dbg = ws.meta + 32;
-            tp.max_iters = (unsigned long long)std::max<long>(1, env_long("PMX_MAXITERS", 1L << 31));
-            TRACE("tree kernel: grid=%u lds=%zu depth=%d waves/cu=%d", n, lds, depth, waves_per_cu);
-            tree_kernel<G, false><<<dim3(n), dim3(64), lds, stream>>>(tp);
-            HIPCHECK(hipGetLastError());
-            TRACE("tree kernel launched");
-            if (g_profiling) HIPCHECK(hipEventRecord(ws.ev[3], stream));
-            // rounds over the task queue: walkers that ran over budget appended subtrees
-            uint32_t lo = 0;
-            for (;;) {
-                HIPCHECK(hipMemcpyAsync(ws.meta_host, ws.meta, 1024, hipMemcpyDeviceToHost, stream));
-                HIPCHECK(hipStreamSynchronize(stream));
-                if (lo == 0 && g_stats.n_rounds == 0) {
-                    unsigned long long ns1;
-                    std::memcpy(&ns1, ws.meta_host + 6, 8);
-                    g_stats.n_steps_first += ns1;
-                }
-                const uint32_t hi = std::min<uint32_t>(ws.meta_host[4], tp.qcap);
-                TRACE("round: lo=%u hi=%u", lo, hi);
-                if (ws.meta_host[5]) g_stats.queue_overflow = 1;
-                if (ws.meta_host[32] == 2) return fail(PMX_ERR_INVALID, "tree kernel watchdog fired at location %u", ws.meta_host[35]);
-                if (ws.meta_host[32]) {
-                    char buf[400];
-                    int o = snprintf(buf, sizeof(buf), "tree walk hit the iteration cap (nl=%u busy=%u):", ws.meta_host[33], ws.meta_host[34]);
-                    for (int gq = 0; gq < 8 && o < 380; ++gq) {
-                        const uint32_t *d = ws.meta_host + 32 + 16 + gq * 8;
-                        o += snprintf(buf + o, sizeof(buf) - o, " [g%d li=%u busy=%u f=%d f0=%d sp=%d sfr=%d frm=%08x todo=%x]", gq, d[0], d[1], (int)d[2], (int)d[3], (int)d[4], (int)d[5], d[6], d[7]);
-                    }
-                    return fail(PMX_ERR_INVALID, "%s", buf);
-                }
-                if (hi <= lo) {
-                    unsigned long long ns;
-                    std::memcpy(&ns, ws.meta_host + 6, 8);
-                    g_stats.n_steps += ns;
-                    std::memcpy(&ns, ws.meta_host + 8, 8);
-                    g_stats.n_iters += ns;
-                    std::memcpy(&ns, ws.meta_host + 10, 8);
-                    g_stats.max_iters_ligand = std::max<uint64_t>(g_stats.max_iters_ligand, ns);
-                    std::memcpy(&ns, ws.meta_host + 12, 8);
-                    g_stats.max_iters_task = std::max<uint64_t>(g_stats.max_iters_task, ns);
-#ifdef PMX_PROF
-                    {
-                        fprintf(stderr, "PMXPROF");
-                        for (int i = 0; i < 32; ++i) {
-                            std::memcpy(&ns, ws.meta_host + 128 + 2 * i, 8);
-                            fprintf(stderr, " %llu", ns);
-                        }
-                        fprintf(stderr, "\n");
-                    }
-#endif
-                    break;
-                }
-                tp.count = hi - lo;
-                tp.task_lo = lo;
-                tree_kernel<G, true><<<dim3(tp.count), dim3(64), lds, stream>>>(tp);
-                HIPCHECK(hipGetLastError());
-                g_stats.n_tasks += tp.count;
-                g_stats.n_rounds += 1;
-                lo = hi;
-            }
-            if (lo > 0) {
-                finalize_kernel<G><<<dim3((n + 255) / 256), dim3(256), 0, stream>>>(lib->dl, lig0, n, ws.deferred, ws.bestbuf, scores);
-                HIPCHECK(hipGetLastError());
-            }
-        }
-        if (g_profiling) {
-            HIPCHECK(hipEventRecord(ws.ev[4], stream));
-            HIPCHECK(hipEventSynchronize(ws.ev[4]));
-            float a = 0, b = 0, c = 0, d = 0;
-            HIPCHECK(hipEventElapsedTime(&a, ws.ev[0], ws.ev[1]));
-            HIPCHECK(hipEventElapsedTime(&b, ws.ev[1], ws.ev[2]));
-            HIPCHECK(hipEventElapsedTime(&c, ws.ev[2], ws.ev[3]));
-            HIPCHECK(hipEventElapsedTime(&d, ws.ev[3], ws.ev[4]));
-            g_stats.ms_sizes += a;
-            g_stats.ms_tables += b;
-            g_stats.ms_tree += c;
-            g_stats.ms_tasks += d;
-            g_stats.ms_total += a + b + c + d;
-        }
-        g_stats.table_bytes += table_total;
-        g_stats.n_chunks += 1;
+    // PMX_OVERLAP=0 runs both phases on the caller's stream (no concurrency between chunks)
+    static const bool overlap = env_long("PMX_OVERLAP", 1) != 0;
+    hipStream_t side = overlap ? ws.side : stream;
+    if (overlap) { // the side stream starts after whatever the caller queued before this call
+        HIPCHECK(hipEventRecord(ws.entry, stream));
+        HIPCHECK(hipStreamWaitEvent(side, ws.entry, 0));
     }
-    return PMX_OK;
+    const uint64_t n_chunks = (count + cap - 1) / cap;
+    auto chunk_n = [&](uint64_t k) { return (uint32_t)std::min<uint64_t>(cap, count - k * cap); };
+    auto chunk_status = [&](uint64_t k) { return status_dev ? status_dev + k * cap : ws.slot[k & 1].status; };
+    int rc = table_phase<G>(model, lib, W, first, chunk_n(0), chunk_status(0), ws.slot[0], side);
+    for (uint64_t k = 0; k < n_chunks && rc == PMX_OK; ++k) {
+        if (k + 1 < n_chunks)
+            rc = table_phase<G>(model, lib, W, first + (k + 1) * cap, chunk_n(k + 1), chunk_status(k + 1), ws.slot[(k + 1) & 1], side);
+        if (rc == PMX_OK) rc = tree_phase<G>(model, lib, chunk_status(k), scores_dev + k * cap, ws.slot[k & 1], ws, stream);
+    }
+    if (rc != PMX_OK) { // leave no work in flight that still references the slots
+        (void)hipStreamSynchronize(side);
+        (void)hipStreamSynchronize(stream);
+    }
+    return rc;
 }
 
 static int next_pow2(int x) {

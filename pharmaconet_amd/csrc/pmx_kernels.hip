@@ -193,7 +193,11 @@ __device__ inline void node_pair(const float4 *tab, int Nm, uint64_t A, uint64_t
                 if (y0 < nc) {
                     float4 e[4];
 #pragma unroll
+#ifdef PMX_EXP_UNIFORM_E
+                    for (int y = 0; y < 4; ++y) e[y] = tab[y0 + y];
+#else
                     for (int y = 0; y < 4; ++y) e[y] = row[col[y0 + y]];
+#endif
 #pragma unroll
                     for (int y = 0; y < 4; ++y) {
                         const bool on = y0 + y < nc;

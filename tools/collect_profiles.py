@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Turn the rocprofv3 outputs of one gpurun call into the tracked summaries under profiles/.
+
+  python tools/collect_profiles.py <bench.json> <kernel_stats.csv> <fetch_dir> <write_dir> <sq_dir> [ligands_in_pmc_run]
+
+The PMC passes are separate runs (`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, one SQ pass) of
+`bench.py --ligands 200000 --steps 1 --warmup 0`; FETCH_SIZE / WRITE_SIZE are KiB and the read side is
+doubled as MI355X_MICROARCH.md prescribes for gfx950.
+"""
+import collections
+import csv
+import json
+import shutil
+import sys
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parents[1]
+PROF = REPO / "profiles"
+
+
+def short(name):
+    return name.split("(")[0].replace("void ", "")
+
+
+def main():
+    bench, kstats, fetch_dir, write_dir, sq_dir = (Path(a) for a in sys.argv[1:6])
+    n_lig = int(sys.argv[6]) if len(sys.argv) > 6 else 200704
+    PROF.mkdir(exist_ok=True)
+    shutil.copy(bench, PROF / "r1_bench_1M.json")
+    # kernel stats: keep pmx kernels and the five largest others
+    rows = list(csv.reader(open(kstats)))
+    keep = [rows[0]] + [r for r in rows[1:] if "pmx::" in r[0] or "cub" in r[0].lower()]
+    csv.writer(open(PROF / "r1_kernel_stats.csv", "w", newline="")).writerows(keep)
+    res = {}
+    for d, ctr, out in ((fetch_dir, "FETCH_SIZE", "r1_pmc_fetch_size.csv"), (write_dir, "WRITE_SIZE", "r1_pmc_write_size.csv")):
+        f = next(d.glob("*counter_collection.csv"))
+        rows = list(csv.reader(open(f)))
+        ki = rows[0].index("Kernel_Name")
+        csv.writer(open(PROF / out, "w", newline="")).writerows([rows[0]] + [r for r in rows[1:] if "pmx::" in r[ki]])
+        tot, cnt = collections.defaultdict(float), collections.Counter()
+        for row in csv.DictReader(open(f)):
+            if "pmx::" in row["Kernel_Name"] and row["Counter_Name"] == ctr:
+                k = short(row["Kernel_Name"])
+                tot[k] += float(row["Counter_Value"])
+                cnt[k] += 1
+        res[ctr] = (tot, cnt)
+    out = {
+        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of bench.py --ligands 200000 --steps 1 --warmup 0",
+        "note": "FETCH_SIZE / WRITE_SIZE in KiB; hbm_bytes_per_ligand = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 / ligands, the read "
+                "side doubled per MI355X_MICROARCH.md (gfx950 reports half of wide coalesced reads; narrow accesses are "
+                "uncalibrated, so the read figure is an upper estimate). The counters see L2 <-> fabric traffic, i.e. they "
+                "include what the 256 MB Infinity Cache serves (the walkers' private totals).",
+        "ligands": n_lig,
+        "kernels": {},
+    }
+    for k, f in res["FETCH_SIZE"][0].items():
+        w = res["WRITE_SIZE"][0].get(k, 0.0)
+        if f + w < 1000:
+            continue
+        out["kernels"][k] = {
+            "fetch_kib_raw": f, "write_kib": w, "hbm_bytes_per_ligand": (2 * f + w) * 1024 / n_lig,
+            "launches": res["FETCH_SIZE"][1][k],
+        }
+    json.dump(out, open(PROF / "r1_hbm_traffic.json", "w"), indent=1)
+    sq = collections.defaultdict(lambda: collections.defaultdict(float))
+    for row in csv.DictReader(open(next(sq_dir.glob("*counter_collection.csv")))):
+        k = row["Kernel_Name"]
+        if "pmx::" in k and ("tree_kernel" in k or "tables_kernel" in k or "bounds_kernel" in k):
+            sq[short(k).replace("pmx::", "")][row["Counter_Name"]] += float(row["Counter_Value"])
+    json.dump({"source": "rocprofv3 --pmc SQ_* (one pass) of bench.py --ligands 200000 --steps 1 --warmup 0; SQ_WAVE_CYCLES, "
+                         "SQ_WAIT_* and SQ_ACTIVE_* count quad-cycles", "counters": sq},
+              open(PROF / "r1_pmc_sq_summary.json", "w"), indent=1)
+    for k, v in out["kernels"].items():
+        print(f"{k:40s} fetch {v['fetch_kib_raw'] / 1e6:8.3f} GiB  write {v['write_kib'] / 1e6:8.3f} GiB  {v['hbm_bytes_per_ligand']:10.0f} B/ligand")
+    for k, v in sq.items():
+        print(k, {c: round(x / 1e9, 2) for c, x in v.items()})
+
+
+if __name__ == "__main__":
+    main()
