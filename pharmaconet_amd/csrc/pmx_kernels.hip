@@ -696,7 +696,8 @@ struct TaskHeader { // 64 bytes, followed by double tot[G]
     uint32_t lig;   // ligand index inside the chunk
     uint8_t f0;     // frame of the subtree's root
     uint8_t nm;     // matches on the path, root included
-    uint8_t pad[2];
+    uint8_t jg;     // in-wave hand-over from a frame with < 4 matches: group and frame that need the root's
+    uint8_t jf;     // return value (tree.py:98); jg = 0xff otherwise
     uint64_t mask;  // conformer mask of the root
     uint8_t path[2 * PMX_MAX_LEVELS]; // (level, candidate) of every match on the path
     uint8_t pad2[8];
@@ -747,7 +748,7 @@ __host__ __device__ inline uint32_t tree_group_bytes(int depth, int K) {
     return todo_bytes + cm_bytes + msk_bytes + frm_bytes + mat_bytes + eb_bytes;
 }
 
-constexpr uint32_t kTreeSharedHdr = 32 + 48 + 80; // k[32], ksum[24], rowbase[20] of the job's ligand
+constexpr uint32_t kTreeSharedHdr = 32 + 48 + 80 + 256; // k[32], ksum[24], rowbase[20] of the job's ligand; one report word per group
 
 template <int G>
 __host__ __device__ constexpr uint32_t tree_local_stack_entries() {
@@ -858,6 +859,7 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
     uint8_t *hk = shared;                                               // k[32]
     uint16_t *hksum = reinterpret_cast<uint16_t *>(shared + 32);        // [24]
     uint32_t *hrow = reinterpret_cast<uint32_t *>(shared + 32 + 48);    // [20]
+    uint32_t *rep = reinterpret_cast<uint32_t *>(shared + 32 + 48 + 80); // [GPW] return values of handed-over subtrees
     unsigned char *lstk = shared + kTreeSharedHdr;                      // local task stack
     const uint32_t todo_bytes = (uint32_t)round16((uint64_t)(D + 1) * 8);
     const uint32_t cm_bytes = (uint32_t)round16((uint64_t)(D + 1) * K * sizeof(vm_t));
@@ -876,6 +878,7 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
     int *eb = reinterpret_cast<int *>(__builtin_assume_aligned(
         base + todo_bytes + cm_bytes + msk_bytes + frm_bytes + (uint32_t)round16((uint64_t)D * 8), 16));
     int ebf = -1;
+    int jg = -1, jf = 0, root_ret = 0; // who waits for this walker's root (see the joins below)
 
     uint32_t guard = 0;
 #ifdef PMX_PROF // build with PMX_CXXFLAGS=-DPMX_PROF: where a wave's time goes (s_memtime) and what it does
@@ -912,6 +915,7 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
             hrow[i] = H->rowbase[i];
         }
     }
+    if (lane < GPW) rep[lane] = 0;
     wave_lds_sync();
 
     // ---- walker state
@@ -936,11 +940,15 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
         msk[nm0] = (vm_t)th->mask;
         frm[f] = make_uchar4(0, 0, F_MATCHED, (unsigned char)nm0);
         ebf = -1;
+        jg = th->jg == 0xff ? -1 : (int)th->jg;
+        jf = th->jf;
         busy = true;
     };
     // describe candidate b of frame fr (conformer mask m) as a task record
-    auto describe = [&](TaskHeader *th, int fr, int nmr, int b, vm_t m, double t) {
+    auto describe = [&](TaskHeader *th, int fr, int nmr, int b, vm_t m, double t, bool joined) {
         th->lig = li;
+        th->jg = joined ? (uint8_t)g : (uint8_t)0xff;
+        th->jf = (uint8_t)fr;
         th->f0 = (uint8_t)(fr + 1);
         th->nm = (uint8_t)(nmr + 1);
         th->mask = (uint64_t)m;
@@ -1039,6 +1047,8 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
                 uchar4 Pf = frm[f];
                 Pf.y = Pf.y > ret ? Pf.y : ret;
                 frm[f] = Pf;
+            } else {
+                root_ret = ret;
             }
             PROF(++pn_ret);
         } else {
@@ -1088,15 +1098,14 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
             if (need > 0 && n_busy > 0) {
                 bool can = false;
                 if (busy) {
-                    // skip frames that can never give a child away (fewer than 4 matches, or exhausted)
+                    // skip frames that have no child left to give away
                     while (sfr <= f && sfr < nl) {
                         PMX_GUARD(5);
-                        const uchar4 Fs = frm[sfr];
-                        if (Fs.w < 4 || ((Fs.z & F_EXPANDED) && todo[sfr] == 0)) ++sfr;
+                        if ((frm[sfr].z & F_EXPANDED) && todo[sfr] == 0) ++sfr;
                         else break;
                     }
                     // children too close to the leaves are cheaper to walk than to hand over
-                    can = sfr <= f && sfr < nl && nl - (sfr + 1) >= (int)share_levels && donatable(sfr);
+                    can = sfr <= f && sfr < nl && nl - (sfr + 1) >= (int)share_levels && (frm[sfr].z & F_EXPANDED) && todo[sfr] != 0;
                 }
                 const unsigned long long don_bal = __ballot(can && c == 0);
                 const int rank = __popcll(don_bal & below);
@@ -1107,9 +1116,14 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
                     const uint64_t left = todo[sfr];
                     const int b = __ffsll((unsigned long long)left) - 1;
                     todo[sfr] = left & (left - 1);
+                    // With >= 4 matches here the child's return value is settled (at least 1, see above). Below that
+                    // the skip rule (tree.py:98) needs the real value: the frame counts the children it has out
+                    // (.x) and waits for their reports before it decides.
+                    const bool joined = Fr.w < 4;
                     describe(reinterpret_cast<TaskHeader *>(lstk + (size_t)(sp + rank) * task_bytes<G>()), sfr, Fr.w, b, cm[sfr * K + b],
-                             child_total(sfr, Fr.w, b));
-                    Fr.y = Fr.y > 1 ? Fr.y : 1; // the child given away returns at least 1
+                             child_total(sfr, Fr.w, b), joined);
+                    if (joined) Fr.x = (unsigned char)(Fr.x + 1);
+                    else Fr.y = Fr.y > 1 ? Fr.y : 1;
                     frm[sfr] = Fr;
                 }
                 sp = __builtin_amdgcn_readfirstlane(sp + take);
@@ -1152,7 +1166,7 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
                         }
                         const int b = __ffsll((unsigned long long)left) - 1;
                         describe(reinterpret_cast<TaskHeader *>(queue + (size_t)slot * task_bytes<G>()), fr, Fr.w, b, cm[fr * K + b],
-                                 child_total(fr, Fr.w, b));
+                                 child_total(fr, Fr.w, b), false);
                         left &= left - 1;
                         gave = true;
                         Fr.y = Fr.y > 1 ? Fr.y : 1;
@@ -1191,6 +1205,7 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
         // ---- one DFS step per busy group: advance to (and through) the next frame expansion.
         // Leaf children are consumed inside their parent's step; a step ends when a new frame has been
         // entered and its candidates evaluated, or when the group's subtree is finished.
+        const bool was_busy = busy;
         if (busy) {
             // a step ends in one frame expansion; all groups of the wave do theirs together, below
             bool need_exp = f < nl && !(frm[f].z & F_EXPANDED); // first step of a root (whole tree or adopted subtree)
@@ -1203,10 +1218,13 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
                     if (f == nl) { // a subtree root that is itself a leaf (tree.py:103-104)
                         const double t = tot[nm];
                         if (((msk[nm] >> c) & 1) && t > best) best = t;
-                        --f;
-                        if (f < f0) break;
-                        uchar4 Pf = frm[f];
                         const unsigned char ret = matched ? 1 : 0;
+                        --f;
+                        if (f < f0) {
+                            root_ret = ret;
+                            break;
+                        }
+                        uchar4 Pf = frm[f];
                         Pf.y = Pf.y > ret ? Pf.y : ret;
                         frm[f] = Pf;
                         continue;
@@ -1238,7 +1256,7 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
                                 if (c == 0) slot = atomicAdd(qtail, 1u);
                                 slot = __shfl(slot, g * G);
                                 if (slot < qcap) {
-                                    describe(reinterpret_cast<TaskHeader *>(queue + (size_t)slot * task_bytes<G>()), f, nm, b, m, t);
+                                    describe(reinterpret_cast<TaskHeader *>(queue + (size_t)slot * task_bytes<G>()), f, nm, b, m, t, false);
                                     F.y = F.y > 1 ? F.y : 1; // the child given away returns at least 1
                                     frm[f] = F;
                                     exported = true;
@@ -1259,6 +1277,7 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
                         need_exp = true;
                         break;
                     }
+                    if (F.x) break; // children walked by other groups have not reported yet: wait for their return values
                     if (!(F.z & F_SKIP) && (!(F.z & F_ANY) || (nm + F.y) < 5)) { // skip child (tree.py:98-101)
                         F.z |= F_SKIP;
                         frm[f] = F;
@@ -1273,7 +1292,10 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
                     const unsigned char ret = (unsigned char)(F.y + (matched ? 1 : 0));
                     PROF(++pn_ret);
                     --f;
-                    if (f < f0) break;
+                    if (f < f0) {
+                        root_ret = ret;
+                        break;
+                    }
                     uchar4 Pf = frm[f];
                     Pf.y = Pf.y > ret ? Pf.y : ret;
                     frm[f] = Pf;
@@ -1281,6 +1303,32 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
             }
             if (need_exp) expand(f);
             if (f < f0) busy = false;
+        }
+        // ---- joins: a walker whose root was handed over by a frame with < 4 matches reports the root's return
+        // value; the frame's group takes it into max_num_matches (tree.py:96-97) and stops waiting for it
+        if (GPW > 1) {
+            const bool post = was_busy && !busy && jg >= 0;
+            if (__ballot(post)) {
+                if (post && c == 0) rep[g] = 0x80000000u | (uint32_t)jg | ((uint32_t)jf << 8) | ((uint32_t)root_ret << 16);
+                wave_lds_sync();
+                for (int m = 0; m < GPW; ++m) {
+                    const uint32_t r = rep[m];
+                    if ((r >> 31) && (int)(r & 255u) == g) {
+                        const int fr = (int)((r >> 8) & 255u);
+                        const unsigned char ret = (unsigned char)((r >> 16) & 255u);
+                        uchar4 Fr = frm[fr];
+                        Fr.x = (unsigned char)(Fr.x - 1);
+                        Fr.y = Fr.y > ret ? Fr.y : ret;
+                        frm[fr] = Fr;
+                    }
+                }
+                wave_lds_sync();
+                if (post) {
+                    if (c == 0) rep[g] = 0;
+                    jg = -1;
+                }
+                wave_lds_sync();
+            }
         }
         PROF(const unsigned long long pt2 = __builtin_amdgcn_s_memtime(); pc_adv += pt2 - pt1; pc_all += pt2 - pt0);
     }
