@@ -183,13 +183,15 @@ class PharmacophoreModel:
         self._engine_handle = None
 
     @classmethod
-    def create(cls, *args, **kwargs):
-        """Density maps -> model graph (`pharmacophore_model.py:108-149`) is the modeling pipeline's
-        job and stays with the reference (`modeling.py`); this package consumes its `.pm` / `.json`."""
-        raise NotImplementedError(
-            "PharmacophoreModel.create() belongs to the modeling pipeline; build the model with the "
-            "reference's modeling.py and load the resulting .pm / .json here"
-        )
+    def create(cls, pdbblock, center, hotspot_infos, resolution: float = 0.5, size: int = 64):
+        """Hotspot density maps -> model (`pharmacophore_model.py:108-149`): same arguments as the reference;
+        `hotspot_infos` = [{nci_type, hotspot_position, hotspot_score, point_map}]. The graph build of
+        `utils/density_map.py` is restated in `pharmaconet_amd.model_builder` (host side, once per pocket)."""
+        from .model_builder import build_model_state
+
+        model = cls()
+        model.__setstate__(build_model_state(pdbblock, center, hotspot_infos, resolution, size))
+        return model
 
     # ------------------------------------------------------------ accessors
     @property
