@@ -1380,7 +1380,10 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
 // block to whichever CU frees a slot, which is the dynamic load balancing a work counter would give,
 // and the kernel stays a straight line of wave-uniform branches around the walker.
 template <int G, bool TASKS>
-__global__ __launch_bounds__(64, 6) void tree_kernel(const TreeParams p) { // 6 waves per SIMD: <= 80 VGPRs, measured best
+#ifndef PMX_TREE_WAVES
+#define PMX_TREE_WAVES 6 // waves per SIMD the register budget is set for: 6 -> <= 80 VGPRs, measured best (5 and 8 are slower)
+#endif
+__global__ __launch_bounds__(64, PMX_TREE_WAVES) void tree_kernel(const TreeParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const uint32_t nx = blockIdx.x;
