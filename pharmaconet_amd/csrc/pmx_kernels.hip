@@ -167,16 +167,17 @@ __device__ inline void cluster_center_size(const float *xyz, int C, int start, i
 
 // One (ligand node, ligand node) term of match_utils.py:26-69: the sum over compatible model node
 // pairs (m in A, n in B) of w_m w_n / std * exp(-z^2 / 2), and the count of pairs within 2 sigma.
-// The columns of B are decoded once (eight at a time) and reused for every row of A, so the inner loop is
-// batches of four independent LDS reads + the arithmetic; the Gaussian is one v_exp_f32 (results below 2^-126
+// The columns of B are decoded once (twelve at a time) and reused for every row of A, so the inner loop is
+// batches of three independent LDS reads + the arithmetic; the Gaussian is one v_exp_f32 (results below 2^-126
 // flush to zero, far under float32 resolution of the sums). Order: m ascending, n ascending, as the
-// reference (clusters of more than 8 compatible nodes are summed in column blocks of 8).
+// reference (clusters of more than 12 compatible nodes are summed in column blocks of 12).
 __device__ inline void node_pair(const float4 *tab, int Nm, uint64_t A, uint64_t B, float d, float &acc, int &npass) {
+    constexpr int W = 3, NCOL = 12; // batch width and columns decoded per pass: cluster sizes of 3, 6, 9 nodes waste nothing
     while (B) {
-        int col[8];
+        int col[NCOL];
         int nc = 0;
 #pragma unroll
-        for (int y = 0; y < 8; ++y) {
+        for (int y = 0; y < NCOL; ++y) {
             col[y] = 0;
             if (B) {
                 col[y] = __ffsll((unsigned long long)B) - 1;
@@ -184,22 +185,18 @@ __device__ inline void node_pair(const float4 *tab, int Nm, uint64_t A, uint64_t
                 nc = y + 1;
             }
         }
-        // weights of the absent columns are zero: fma(0, x, acc) leaves acc unchanged, so the four reads of a
-        // batch can be issued together and nothing branches per term
+        // weights of the absent columns are zero: fma(0, x, acc) leaves acc unchanged, so the reads of a batch
+        // can be issued together and nothing branches per term
         for (uint64_t am = A; am; am &= am - 1) {
             const float4 *row = tab + (__ffsll((unsigned long long)am) - 1) * Nm;
 #pragma unroll
-            for (int y0 = 0; y0 < 8; y0 += 4) {
+            for (int y0 = 0; y0 < NCOL; y0 += W) {
                 if (y0 < nc) {
-                    float4 e[4];
+                    float4 e[W];
 #pragma unroll
-#ifdef PMX_EXP_UNIFORM_E
-                    for (int y = 0; y < 4; ++y) e[y] = tab[y0 + y];
-#else
-                    for (int y = 0; y < 4; ++y) e[y] = row[col[y0 + y]];
-#endif
+                    for (int y = 0; y < W; ++y) e[y] = row[col[y0 + y]];
 #pragma unroll
-                    for (int y = 0; y < 4; ++y) {
+                    for (int y = 0; y < W; ++y) {
                         const bool on = y0 + y < nc;
                         const float t = fabsf(d - e[y].x);
                         const float q = t * e[y].y;
