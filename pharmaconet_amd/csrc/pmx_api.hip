@@ -82,7 +82,8 @@ extern "C" int pmx_model_create(const pmx_model_desc *d, int device, pmx_model *
     const size_t off_tnodes = off_cnodes + 64 * 8;
     const size_t off_tclus = off_tnodes + 128 * 8;
     const size_t off_cpair = off_tclus + 128 * 8;
-    const size_t total = off_cpair + round16(n_pair * sizeof(float2)) + 16;
+    const size_t off_clist = off_cpair + round16(n_pair * sizeof(float2));
+    const size_t total = off_clist + (size_t)std::max(K, 1) * 128 * 16 + 16;
     std::vector<unsigned char> host(total, 0);
     float4 *edge = reinterpret_cast<float4 *>(host.data() + off_edge);
     uint8_t *ntype = host.data() + off_type;
@@ -113,6 +114,20 @@ extern "C" int pmx_model_create(const pmx_model_desc *d, int device, pmx_model *
         tclus[mask] = clus;
     }
     for (int a = 0; a < K; ++a)
+        for (int mask = 0; mask < 128; ++mask) {
+            unsigned char *e = host.data() + off_clist + ((size_t)a * 128 + mask) * 16;
+            const uint64_t nodes = cnodes[a] & tnodes[mask];
+            const int cnt = __builtin_popcountll(nodes);
+            if (cnt > 12) {
+                e[0] = 0xff;
+                continue;
+            }
+            e[0] = (unsigned char)cnt;
+            int q = 1;
+            for (int m = 0; m < Nm; ++m)
+                if (nodes >> m & 1) e[q++] = (unsigned char)m;
+        }
+    for (int a = 0; a < K; ++a)
         for (int b = 0; b < K; ++b) {
             const double *ca = d->cluster_center + 3 * a, *cb = d->cluster_center + 3 * b;
             const double dist = std::sqrt((ca[0] - cb[0]) * (ca[0] - cb[0]) + (ca[1] - cb[1]) * (ca[1] - cb[1]) +
@@ -139,6 +154,7 @@ extern "C" int pmx_model_create(const pmx_model_desc *d, int device, pmx_model *
     m->dm.tnodes = reinterpret_cast<const uint64_t *>(b8 + off_tnodes);
     m->dm.tclus = reinterpret_cast<const uint64_t *>(b8 + off_tclus);
     m->dm.cpair = reinterpret_cast<const float2 *>(b8 + off_cpair);
+    m->dm.clist = reinterpret_cast<const uint4 *>(b8 + off_clist);
     *out = m;
     return PMX_OK;
 }

@@ -22,6 +22,9 @@ struct DevModel {
     const uint64_t *tnodes;   // [128]  ligand node type mask -> model nodes of any of those types
     const uint64_t *tclus;    // [128]  ligand cluster type mask -> model clusters sharing a type (graph_match.py:130-134)
     const float2 *cpair;      // [K * K] {float32(|center_a - center_b|), float32(size_a + size_b)}  (graph_match.py:263-265)
+    // [K * 128] nodes of cluster a compatible with ligand type mask t, as a list: byte 0 = count (0xff: more than
+    // 12, use the masks), bytes 1..12 = node numbers ascending (the reference's order, graph_match.py:148-150)
+    const uint4 *clist;
 };
 
 struct DevLibrary {

@@ -209,6 +209,57 @@ __device__ inline void node_pair(const float4 *tab, int Nm, uint64_t A, uint64_t
     }
 }
 
+// The same term with the two node sets given as the model's precomputed lists (DevModel::clist: byte 0 = count,
+// bytes 1..12 = node numbers ascending): no mask walking. Only for sets of at most 12 nodes (count != 0xff).
+__device__ inline void node_pair_lists(const float4 *tab, int Nm, const uint4 la, const uint4 lb, float d, float &acc, int &npass) {
+    constexpr int W = 3, NCOL = 12;
+    const int na = (int)(la.x & 255u), nc = (int)(lb.x & 255u);
+    int col[NCOL];
+    col[0] = (lb.x >> 8) & 255u, col[1] = (lb.x >> 16) & 255u, col[2] = lb.x >> 24;
+    col[3] = lb.y & 255u, col[4] = (lb.y >> 8) & 255u, col[5] = (lb.y >> 16) & 255u, col[6] = lb.y >> 24;
+    col[7] = lb.z & 255u, col[8] = (lb.z >> 8) & 255u, col[9] = (lb.z >> 16) & 255u, col[10] = lb.z >> 24;
+    col[11] = lb.w & 255u;
+    // rows: a 96-bit shift register over bytes 1..12 of la
+    uint32_t s0 = (la.x >> 8) | (la.y << 24), s1 = (la.y >> 8) | (la.z << 24), s2 = (la.z >> 8) | (la.w << 24);
+    for (int r = 0; r < na; ++r) {
+        const float4 *row = tab + (int)(s0 & 255u) * Nm;
+        s0 = (s0 >> 8) | (s1 << 24);
+        s1 = (s1 >> 8) | (s2 << 24);
+        s2 >>= 8;
+#pragma unroll
+        for (int y0 = 0; y0 < NCOL; y0 += W) {
+            if (y0 < nc) {
+                float4 e[W];
+#pragma unroll
+                for (int y = 0; y < W; ++y) e[y] = row[col[y0 + y]];
+#pragma unroll
+                for (int y = 0; y < W; ++y) {
+                    const bool on = y0 + y < nc;
+                    const float t = fabsf(d - e[y].x);
+                    const float q = t * e[y].y;
+                    acc = __builtin_fmaf(on ? e[y].w : 0.f, __builtin_amdgcn_exp2f(-(q * q)), acc);
+                    npass += (on && t <= e[y].z) ? 1 : 0;
+                }
+            }
+        }
+    }
+}
+
+// One (ligand node, ligand node) term against model clusters a and b; returns |A| * |B| (0: nothing compatible).
+__device__ inline int cluster_node_pair(const DevModel &M, const float4 *tab, const uint64_t *cnodes, const uint64_t *tnodes, int a, int b,
+                                        unsigned tmu, unsigned tmv, float d, float &acc, int &npass) {
+    const uint4 la = M.clist[a * 128 + (int)tmu], lb = M.clist[b * 128 + (int)tmv];
+    const int na = (int)(la.x & 255u), nb = (int)(lb.x & 255u);
+    if (na == 0 || nb == 0) return 0;
+    if (na != 255 && nb != 255) {
+        node_pair_lists(tab, M.Nm, la, lb, d, acc, npass);
+        return na * nb;
+    }
+    const uint64_t A = cnodes[a] & tnodes[tmu], B = cnodes[b] & tnodes[tmv];
+    node_pair(tab, M.Nm, A, B, d, acc, npass);
+    return __popcll(A) * __popcll(B);
+}
+
 template <int G>
 __global__ __launch_bounds__(256) void tables_kernel(DevModel M, DevLibrary lib, Weights W, uint64_t first, uint32_t count,
                                                      const int32_t *status, const uint64_t *taboff, uint8_t *arena) {
@@ -488,15 +539,14 @@ __global__ __launch_bounds__(512, 6) void tables_kernel_v2(DevModel M, DevLibrar
                     const int e = (int)(((float)t + 0.5f) * inv_per), rr = t - e * per;
                     const int u = (int)(((float)rr + 0.5f) * inv_ni), v = rr - u * ni;
                     if (u >= v) continue;
-                    const uint64_t nodes_a = cnodes[WL.candlist[i][e0 + e]];
-                    const uint64_t A = nodes_a & tnodes[tm[si + u]], B = nodes_a & tnodes[tm[si + v]];
-                    if (!A || !B) continue;
+                    const int a = WL.candlist[i][e0 + e];
                     const Pos pu = load_pos(xyz, C, si + u, cc), pv = load_pos(xyz, C, si + v, cc);
                     const float d = norm3(pu.x - pv.x, pu.y - pv.y, pu.z - pv.z);
                     float acc = 0.f;
                     int np = 0;
-                    node_pair(tab, Nm, A, B, d, acc, np);
-                    atomicAdd(&acc_score[e * G + c], acc / (float)(__popcll(A) * __popcll(B)));
+                    const int mn = cluster_node_pair(M, tab, cnodes, tnodes, a, a, tm[si + u], tm[si + v], d, acc, np);
+                    if (!mn) continue;
+                    atomicAdd(&acc_score[e * G + c], acc / (float)mn);
                 }
             }
             wave_lds_sync();
@@ -548,14 +598,12 @@ __global__ __launch_bounds__(512, 6) void tables_kernel_v2(DevModel M, DevLibrar
                     const int e = near_list[en];
                     const int ea = (int)(((float)(e0 + e) + 0.5f) * inv_kj), eb = (e0 + e) - ea * kj;
                     const int a = WL.candlist[i][ea], b = WL.candlist[j][eb];
-                    const uint64_t A = cnodes[a] & tnodes[tm[si + u]], B = cnodes[b] & tnodes[tm[sj + v]];
-                    if (!A || !B) continue;
                     const Pos pu = load_pos(xyz, C, si + u, cc), pv = load_pos(xyz, C, sj + v, cc);
                     const float d = norm3(pu.x - pv.x, pu.y - pv.y, pu.z - pv.z);
                     float acc = 0.f;
                     int np = 0;
-                    node_pair(tab, Nm, A, B, d, acc, np);
-                    const int mn = __popcll(A) * __popcll(B);
+                    const int mn = cluster_node_pair(M, tab, cnodes, tnodes, a, b, tm[si + u], tm[sj + v], d, acc, np);
+                    if (!mn) continue;
                     atomicAdd(&acc_score[e * G + c], acc / (float)mn);
                     if (2 * np < mn) atomicAdd(&acc_fail[e * G + c], 1u); // num_pass < num_match * 0.5 (match_utils.py:61)
                 }
