@@ -971,6 +971,12 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
     double best = 0.0; // graph_match.py:104
     if (TASKS) best = __longlong_as_double((long long)p.bestbuf[(size_t)li * G + c]); // maxima of the ligand's finished walkers
 
+    // can the subtree below a child (frame fr + 1, conformer mask m, total t) still raise a conformer's maximum?
+    auto may_improve = [&](int fr, vm_t m, double t) -> bool {
+        const double r = *reinterpret_cast<const double *>(Rb + (((uint32_t)(fr + 1) << RSH) + 8u * (uint32_t)c));
+        const unsigned long long bal = __ballot(((m >> c) & 1) && (t + r) * kBoundSlack > best);
+        return ((G == 64) ? bal : ((bal >> (g * G)) & ((1ull << G) - 1ull))) != 0;
+    };
     // start a walker on the subtree described by a task record (global queue or local stack)
     auto adopt = [&](const TaskHeader *th) {
         const int nm0 = th->nm;
@@ -987,7 +993,9 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
         ebf = -1;
         jg = th->jg == 0xff ? -1 : (int)th->jg;
         jf = th->jf;
-        busy = true;
+        // a subtree with >= 5 matches at its root that can no longer raise any maximum (the maxima may have grown
+        // since it was handed over) is not walked at all
+        busy = nm0 < 5 || may_improve(f - 1, (vm_t)th->mask, tot[nm0]);
     };
     // describe candidate b of frame fr (conformer mask m) as a task record
     auto describe = [&](TaskHeader *th, int fr, int nmr, int b, vm_t m, double t, bool joined) {
@@ -1010,12 +1018,6 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
     auto child_total = [&](int fr, int nmr, int b) -> double {
         const int kr = hk[fr], ksr = hksum[fr];
         return tot[nmr] + (double)St[(size_t)(ksr + b) * G + c] + pair_sum<G>(Pt, mat, nmr, ksr, kr, b, c);
-    };
-    // can the subtree below a child (frame fr + 1, conformer mask m, total t) still raise a conformer's maximum?
-    auto may_improve = [&](int fr, vm_t m, double t) -> bool {
-        const double r = *reinterpret_cast<const double *>(Rb + (((uint32_t)(fr + 1) << RSH) + 8u * (uint32_t)c));
-        const unsigned long long bal = __ballot(((m >> c) & 1) && (t + r) * kBoundSlack > best);
-        return ((G == 64) ? bal : ((bal >> (g * G)) & ((1ull << G) - 1ull))) != 0;
     };
     // a frame may give children away once it has >= 4 matches (their subtrees hold >= 5, see above)
     auto donatable = [&](int fr) -> bool {
