@@ -279,13 +279,10 @@ struct Workspace {
 static std::map<int, Workspace> g_ws;
 static std::mutex g_mu;
 
-static uint32_t chunk_size() {
-    static uint32_t v = [] {
-        const char *s = std::getenv("PMX_CHUNK");
-        long x = s ? std::atol(s) : 0;
-        return (uint32_t)(x > 0 ? std::min<long>(x, 1 << 22) : 262144);
-    }();
-    return v;
+static uint32_t chunk_size() { // read per call: tests vary it to cut the library differently
+    const char *s = std::getenv("PMX_CHUNK");
+    const long x = s ? std::atol(s) : 0;
+    return (uint32_t)(x > 0 ? std::min<long>(x, 1 << 22) : 262144);
 }
 
 static long env_long(const char *name, long dflt) {
@@ -400,7 +397,8 @@ static int table_phase(const pmx_model *model, const pmx_library *lib, const Wei
             tables_kernel_v2<G><<<dim3((n + v2_waves - 1) / v2_waves), dim3(64 * v2_waves), lds2, q>>>(
                 model->dm, lib->dl, W, lig0, n, status, sl.taboff, sl.arena);
         }
-        bounds_kernel<G><<<dim3((n + 3) / 4), dim3(256), 0, q>>>(n, status, sl.taboff, sl.arena);
+        bounds_kernel<G><<<dim3((n + 3) / 4), dim3(256), 0, q>>>(n, status, sl.taboff, sl.arena,
+                                                                 (int)(env_long("PMX_TREE_FLAGS", 0) & 4));
         HIPCHECK(hipGetLastError());
     }
     if (g_profiling) HIPCHECK(hipEventRecord(sl.ev[2], q));
@@ -532,7 +530,7 @@ static int tree_phase(const pmx_model *model, const pmx_library *lib, int32_t *s
 template <int G>
 static int score_chunks(const pmx_model *model, const pmx_library *lib, const Weights &W, uint64_t first, uint64_t count,
                         float *scores_dev, int32_t *status_dev, hipStream_t stream, Workspace &ws) {
-    const uint32_t cap = ws.chunk_cap;
+    const uint32_t cap = std::min<uint32_t>(chunk_size(), ws.chunk_cap);
     static bool attr_set = false;
     if (!attr_set) {
         HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&tables_kernel<G>),
@@ -546,7 +544,7 @@ static int score_chunks(const pmx_model *model, const pmx_library *lib, const We
         attr_set = true;
     }
     // PMX_OVERLAP=0 runs both phases on the caller's stream (no concurrency between chunks)
-    static const bool overlap = env_long("PMX_OVERLAP", 1) != 0;
+    const bool overlap = env_long("PMX_OVERLAP", 1) != 0;
     hipStream_t side = overlap ? ws.side : stream;
     if (overlap) { // the side stream starts after whatever the caller queued before this call
         HIPCHECK(hipEventRecord(ws.entry, stream));

@@ -657,7 +657,8 @@ __global__ __launch_bounds__(512, 6) void tables_kernel_v2(DevModel M, DevLibrar
 // whatever is picked on the other levels, so R[f][c] = sum_{l >= f} U[l][c] bounds everything levels
 // f.. add to a node's total. One wavefront per ligand: lane c of group g takes candidates b = g, g + 64/G, ...
 template <int G>
-__global__ __launch_bounds__(256) void bounds_kernel(uint32_t count, const int32_t *status, const uint64_t *taboff, uint8_t *arena) {
+__global__ __launch_bounds__(256) void bounds_kernel(uint32_t count, const int32_t *status, const uint64_t *taboff, uint8_t *arena,
+                                                      int no_bounds /* debug: write +inf, so that nothing is ever dropped */) {
     constexpr int GPW = 64 / G;
     const int lane = threadIdx.x & 63;
     const int g = lane / G, c = lane % G;
@@ -678,6 +679,10 @@ __global__ __launch_bounds__(256) void bounds_kernel(uint32_t count, const int32
     const float *Pt = reinterpret_cast<const float *>(tab + v_bytes + s_bytes);
     double *Rt = reinterpret_cast<double *>(blk + sizeof(TabHeader) + v_bytes + s_bytes + p_bytes);
     double suffix = 0.0;
+    if (no_bounds) {
+        for (int l = g; l <= nl; l += GPW) Rt[(size_t)l * G + c] = __builtin_inf();
+        return;
+    }
     if (g == 0) Rt[(size_t)nl * G + c] = 0.0;
     for (int l = nl - 1; l >= 0; --l) {
         const int kl = H->k[l], ksl = H->ksum[l];
@@ -773,7 +778,7 @@ struct TreeParams {
     uint32_t step_cap;   // children / returns handled by one walker step at most
     uint32_t share_levels; // in-wave sharing hands over only subtrees with at least this many levels below their root
     uint32_t min_levels; // in export mode only subtrees with at least this many levels below their root are queued
-    uint32_t flags;      // debug: 1 = no in-wave sharing, 2 = no global donation
+    uint32_t flags;      // debug: 1 = no in-wave sharing, 2 = no global donation (4 = no bound test: see bounds_kernel)
     uint32_t budget;     // wave iterations after which a job donates its open subtrees to the queue
     unsigned long long *nsteps; // total DFS steps (diagnostics)
     uint32_t *dbg;       // [0] = error flag (iteration cap hit), then 8 words per group

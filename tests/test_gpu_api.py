@@ -182,3 +182,43 @@ def test_sharded_screen_merges_to_the_global_ranking():
     top_s, top_i = merge_topk(np.concatenate(parts_s), np.concatenate(parts_i), k)
     assert top_i.tolist() == full.topk_indices.cpu().numpy().tolist()
     np.testing.assert_array_equal(top_s, full.topk_scores.cpu().numpy())
+
+
+def test_scores_do_not_depend_on_how_the_work_is_cut(monkeypatch):
+    """The same bits whatever the launch structure: several chunks through the two-slot pipeline, phases
+    serialised, subtrees exported early, no in-wave sharing - and with the bound test of the tree search switched
+    off (every subtree walked, as the reference does): dropping subtrees never changes a score."""
+    import torch
+
+    from pharmaconet_amd import engine
+    from pharmaconet_amd.constants import TYPE_ID
+    from pharmaconet_amd.engine import DeviceLibrary
+    from pharmaconet_amd.synthetic import expand_library_on_device, synthetic_library
+
+    model, _, _, _ = load_golden("set_6oim_c8")
+    st = model.__getstate__()
+    centers = np.array([n["center"] for n in st["nodes"]])
+    types = np.array([TYPE_ID[n["type"]] for n in st["nodes"]])
+    base = synthetic_library(256, num_conformers=8, model_nodes=(centers, types), conformer_noise=0.0, seed=4242)
+    offsets, data = expand_library_on_device(base, 120, "cuda")  # 30,720 ligands
+    lib = DeviceLibrary.from_device_buffers(offsets, data)
+    want = model.screen(lib).scores
+    steps_default = engine.last_score_stats()["n_steps"]
+    assert torch.isfinite(want).all()
+    for env in (
+        {"PMX_CHUNK": "4001"},                      # 8 chunks, both buffer slots reused
+        {"PMX_CHUNK": "4001", "PMX_OVERLAP": "0"},  # the same on one stream
+        {"PMX_BUDGET": "64"},                       # trees are split across wavefronts much earlier
+        {"PMX_TREE_FLAGS": "1"},                    # no hand-over between the groups of a wave
+        {"PMX_TREE_FLAGS": "4"},                    # no bound test
+    ):
+        with monkeypatch.context() as mp:
+            for k, v in env.items():
+                mp.setenv(k, v)
+            got = model.screen(lib).scores
+            stats = engine.last_score_stats()
+        assert torch.equal(got, want), env
+        if env.get("PMX_CHUNK"):
+            assert stats["n_chunks"] == 8
+        if env.get("PMX_TREE_FLAGS") == "4":
+            assert stats["n_steps"] > 2 * steps_default  # the bound test is what keeps the trees small
