@@ -352,10 +352,7 @@ static bool trace_on() {
 template <int G>
 static int table_phase(const pmx_model *model, const pmx_library *lib, const Weights &W, uint64_t lig0, uint32_t n,
                        int32_t *status, Slot &sl, hipStream_t q) {
-    constexpr int GPW = 64 / G;
     const int Nm = model->dm.Nm;
-    const int tab_waves = 4;
-    const size_t tab_lds = (size_t)Nm * Nm * sizeof(float4) + 64 * 8 + 128 * 8 + (size_t)tab_waves * GPW * sizeof(GroupLevels);
     if (sl.walked) HIPCHECK(hipStreamWaitEvent(q, sl.walk_done, 0)); // the slot's previous chunk has been walked
     sl.n = n;
     sl.lig0 = lig0;
@@ -383,20 +380,13 @@ static int table_phase(const pmx_model *model, const pmx_library *lib, const Wei
     }
     if (g_profiling) HIPCHECK(hipEventRecord(sl.ev[1], q));
     if (sl.table_total > 0) {
-        static const bool force_v1 = std::getenv("PMX_TABLES_V1") != nullptr;
+        // <= 8 ligands (waves) per block share one staged model table; the 160 KB of LDS always hold at least one
         const size_t model_lds = (size_t)Nm * Nm * sizeof(float4) + 64 * 8 + 128 * 8;
-        int v2_waves = 0; // waves (= ligands) per block that fit the 160 KB of LDS next to the model tables
-        if (model_lds + tables_v2_wave_bytes<G>() + 1024 <= kLdsPerCu)
-            v2_waves = (int)std::min<size_t>(8, (kLdsPerCu - 1024 - model_lds) / tables_v2_wave_bytes<G>()); // <= 8 ligands share one staged model
-        if (force_v1 || v2_waves < 1) {
-            const uint32_t groups_per_block = tab_waves * GPW;
-            tables_kernel<G><<<dim3((n + groups_per_block - 1) / groups_per_block), dim3(64 * tab_waves), tab_lds, q>>>(
-                model->dm, lib->dl, W, lig0, n, status, sl.taboff, sl.arena);
-        } else {
-            const size_t lds2 = model_lds + (size_t)v2_waves * tables_v2_wave_bytes<G>();
-            tables_kernel_v2<G><<<dim3((n + v2_waves - 1) / v2_waves), dim3(64 * v2_waves), lds2, q>>>(
-                model->dm, lib->dl, W, lig0, n, status, sl.taboff, sl.arena);
-        }
+        if (model_lds + tables_v2_wave_bytes<G>() + 1024 > kLdsPerCu) return fail(PMX_ERR_INVALID, "model tables do not fit LDS");
+        const int v2_waves = (int)std::min<size_t>(8, (kLdsPerCu - 1024 - model_lds) / tables_v2_wave_bytes<G>());
+        const size_t lds2 = model_lds + (size_t)v2_waves * tables_v2_wave_bytes<G>();
+        tables_kernel_v2<G><<<dim3((n + v2_waves - 1) / v2_waves), dim3(64 * v2_waves), lds2, q>>>(
+            model->dm, lib->dl, W, lig0, n, status, sl.taboff, sl.arena);
         bounds_kernel<G><<<dim3((n + 3) / 4), dim3(256), 0, q>>>(n, status, sl.taboff, sl.arena,
                                                                  (int)(env_long("PMX_TREE_FLAGS", 0) & 4));
         HIPCHECK(hipGetLastError());
@@ -533,8 +523,6 @@ static int score_chunks(const pmx_model *model, const pmx_library *lib, const We
     const uint32_t cap = std::min<uint32_t>(chunk_size(), ws.chunk_cap);
     static bool attr_set = false;
     if (!attr_set) {
-        HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&tables_kernel<G>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));
         HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&tables_kernel_v2<G>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));
         HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&tree_kernel<G, false>),

@@ -13,7 +13,7 @@
 //   sizes_kernel       one thread per ligand: candidate sets -> number of tree levels, table size
 //   scan_kernel        table sizes -> offsets in the scratch arena
 //   tables_kernel_v2   one wavefront per ligand: the self / pair score tables of match_utils.py
-//                      (tables_kernel, one group per ligand, is the earlier form kept for comparison)
+//   bounds_kernel      per level, the most it can still add to a total (lets the tree search drop subtrees)
 //   tree_kernel<G,0>   one wavefront (= block) per ligand: the DFS of tree.py over those tables, shared
 //                      by the wave's 64 / G groups; per-conformer maximum over leaves, mean -> score
 //   tree_kernel<G,1>   the same walker on subtrees queued by over-budget trees, in rounds
@@ -118,15 +118,7 @@ __device__ inline void wave_lds_sync() {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 }
 
-// ---------------------------------------------------------------------------------- tables_kernel
-struct GroupLevels { // per conformer group, in LDS
-    uint64_t cand[PMX_MAX_LEVELS];
-    uint8_t start[PMX_MAX_LEVELS];
-    uint8_t end[PMX_MAX_LEVELS];
-    uint8_t k[PMX_MAX_LEVELS];
-    uint8_t pad[4];
-};
-static_assert(sizeof(GroupLevels) % 16 == 0, "GroupLevels alignment");
+// --------------------------------------------------------------------------- table kernels: helpers
 
 struct Pos {
     float x, y, z;
@@ -260,166 +252,8 @@ __device__ inline int cluster_node_pair(const DevModel &M, const float4 *tab, co
     return __popcll(A) * __popcll(B);
 }
 
-template <int G>
-__global__ __launch_bounds__(256) void tables_kernel(DevModel M, DevLibrary lib, Weights W, uint64_t first, uint32_t count,
-                                                     const int32_t *status, const uint64_t *taboff, uint8_t *arena) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int GPW = 64 / G; // groups per wave
-    const int Nm = M.Nm;
-    float4 *tab = reinterpret_cast<float4 *>(smem);
-    uint64_t *cnodes = reinterpret_cast<uint64_t *>(smem + (size_t)Nm * Nm * sizeof(float4));
-    uint64_t *tnodes = cnodes + 64;
-    GroupLevels *glev = reinterpret_cast<GroupLevels *>(tnodes + 128);
-
-    // stage the model: edge table with the call's weights folded in (weights / stds, match_utils.py:65)
-    for (int i = threadIdx.x; i < Nm * Nm; i += blockDim.x) {
-        float4 e = M.edge[i];
-        const float wm = W.w[M.node_type[i / Nm]], wn = W.w[M.node_type[i % Nm]];
-        e.w = (wm * wn) / e.w;
-        tab[i] = e;
-    }
-    for (int i = threadIdx.x; i < 64; i += blockDim.x) cnodes[i] = M.cnodes[i];
-    for (int i = threadIdx.x; i < 128; i += blockDim.x) tnodes[i] = M.tnodes[i];
-    __syncthreads();
-
-    const int lane = threadIdx.x & 63;
-    const int g = lane / G, c = lane % G;
-    const int gib = (threadIdx.x >> 6) * GPW + g;
-    const uint64_t gid = (uint64_t)blockIdx.x * (blockDim.x / 64) * GPW + gib;
-    if (gid >= count) return;
-    if (status[gid] != PMX_LIGAND_OK) return;
-    const uint64_t off = taboff[gid];
-    if (taboff[gid + 1] == off) return; // no levels: score 0 (graph_match.py:95-99)
-
-    const Record r = parse_record(lib.data + lib.offsets[first + gid]);
-    const int C = r.C;
-    const int cc = c < C ? c : C - 1; // idle lanes of the group shadow the last conformer
-    const bool lane_live = c < C;
-    GroupLevels &GL = glev[gib];
-    const Levels L = scan_levels(r, M.tclus, [&](int lev, int start, int end, uint64_t cand, uint32_t k) {
-        GL.cand[lev] = cand;
-        GL.start[lev] = (uint8_t)start;
-        GL.end[lev] = (uint8_t)end;
-        GL.k[lev] = (uint8_t)k;
-    });
-    const int nl = L.nl;
-
-    uint8_t *blk = arena + off;
-    TabHeader *H = reinterpret_cast<TabHeader *>(blk);
-    vmask_t<G> *Vt = reinterpret_cast<vmask_t<G> *>(blk + sizeof(TabHeader));
-    float *St = reinterpret_cast<float *>(blk + sizeof(TabHeader) + round16(uint64_t(L.T) * sizeof(vmask_t<G>)));
-    float *Pt = St + round16(uint64_t(L.ksumtot) * G * 4) / 4;
-
-    // header (every lane of the group writes the same bytes)
-    H->nl = (uint32_t)nl;
-    H->T = L.T;
-    H->ksumtot = L.ksumtot;
-    H->pad = 0;
-    {
-        uint32_t ks = 0, rb = 0;
-        for (int i = 0; i < nl; ++i) {
-            const uint32_t k = GL.k[i];
-            H->k[i] = (uint8_t)k;
-            H->ksum[i] = (uint16_t)ks;
-            H->rowbase[i] = rb;
-            ks += k;
-            rb += k * (L.ksumtot - ks); // k_i * sum_{j > i} k_j
-        }
-        H->ksum[nl] = (uint16_t)ks;
-    }
-
-    const float *xyz = r.xyz;
-    const uint8_t *tm = r.typemask;
-    uint32_t self_idx = 0, pair_idx = 0;
-    for (int i = 0; i < nl; ++i) {
-        const int si = GL.start[i], ei = GL.end[i];
-        const uint64_t candi = GL.cand[i];
-        Pos ctr_i;
-        float size_i;
-        cluster_center_size(xyz, C, si, ei, cc, ctr_i, size_i);
-
-        // self table S[i][a] (match_utils.py:77-122): node pairs u < v inside the cluster, no pass logic
-        for (uint64_t ca = candi; ca; ca &= ca - 1) {
-            const uint64_t nodes_a = cnodes[__ffsll((unsigned long long)ca) - 1];
-            float score = 0.f;
-            for (int u = si; u < ei; ++u) {
-                const uint64_t A = nodes_a & tnodes[tm[u]];
-                if (!A) continue;
-                const Pos pu = load_pos(xyz, C, u, cc);
-                for (int v = u + 1; v < ei; ++v) {
-                    const uint64_t B = nodes_a & tnodes[tm[v]];
-                    if (!B) continue;
-                    const Pos pv = load_pos(xyz, C, v, cc);
-                    const float d = norm3(pu.x - pv.x, pu.y - pv.y, pu.z - pv.z);
-                    float acc = 0.f;
-                    int np = 0;
-                    node_pair(tab, Nm, A, B, d, acc, np);
-                    score = score + acc / (float)(__popcll(A) * __popcll(B));
-                }
-            }
-            St[(size_t)self_idx * G + c] = score;
-            ++self_idx;
-        }
-
-        for (int j = i + 1; j < nl; ++j) {
-            const int sj = GL.start[j], ej = GL.end[j];
-            const uint64_t candj = GL.cand[j];
-            Pos ctr_j;
-            float size_j;
-            cluster_center_size(xyz, C, sj, ej, cc, ctr_j, size_j);
-            const float ldist = norm3(ctr_i.x - ctr_j.x, ctr_i.y - ctr_j.y, ctr_i.z - ctr_j.z); // graph_match.py:240
-            const float lsize = size_i + size_j;                                                 // :241
-            for (uint64_t ca = candi; ca; ca &= ca - 1) {
-                const int a = __ffsll((unsigned long long)ca) - 1;
-                const uint64_t nodes_a = cnodes[a];
-                for (uint64_t cb = candj; cb; cb &= cb - 1) {
-                    const int b = __ffsll((unsigned long long)cb) - 1;
-                    const uint64_t nodes_b = cnodes[b];
-                    // cluster-distance prefilter, graph_match.py:263-268: skip when no conformer can match
-                    const float2 mp = M.cpair[a * M.K + b];
-                    const bool near = lane_live && !((fabsf(ldist - mp.x) - lsize) > mp.y);
-                    const unsigned long long near_bal = __ballot(near);
-                    const unsigned long long grp = (G == 64) ? ~0ull : (((1ull << G) - 1ull) << (g * G));
-                    float value = -1.f;
-                    bool valid = false;
-                    if (near_bal & grp) {
-                        // match_utils.py:9-74
-                        float score = 0.f;
-                        int fails = 0, L1 = 0, L2 = 0;
-                        for (int v = sj; v < ej; ++v) L2 += (nodes_b & tnodes[tm[v]]) ? 1 : 0;
-                        for (int u = si; u < ei; ++u) {
-                            const uint64_t A = nodes_a & tnodes[tm[u]];
-                            if (!A) continue;
-                            ++L1;
-                            const Pos pu = load_pos(xyz, C, u, cc);
-                            for (int v = sj; v < ej; ++v) {
-                                const uint64_t B = nodes_b & tnodes[tm[v]];
-                                if (!B) continue;
-                                const Pos pv = load_pos(xyz, C, v, cc);
-                                const float d = norm3(pu.x - pv.x, pu.y - pv.y, pu.z - pv.z);
-                                float acc = 0.f;
-                                int np = 0;
-                                node_pair(tab, Nm, A, B, d, acc, np);
-                                const int mn = __popcll(A) * __popcll(B);
-                                score = score + acc / (float)mn;
-                                fails += (2 * np < mn) ? 1 : 0; // num_pass < num_match * 0.5   (:61)
-                            }
-                        }
-                        valid = lane_live && (2 * fails <= L1 * L2) && (score > 0.f); // :71-74, tree.py:81
-                        value = (2 * fails <= L1 * L2) ? score : -1.f;
-                    }
-                    const unsigned long long vbal = __ballot(valid);
-                    Pt[(size_t)pair_idx * G + c] = value;
-                    Vt[pair_idx] = (vmask_t<G>)((G == 64) ? vbal : ((vbal >> (g * G)) & ((1ull << G) - 1ull)));
-                    ++pair_idx;
-                }
-            }
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------- tables_kernel_v2
-// Same tables as tables_kernel, organised for lane utilisation: ONE wavefront per ligand. Within a pair of
+// The self / pair score tables of match_utils.py, organised for lane utilisation: ONE wavefront per ligand. Within a pair of
 // ligand clusters (i, j) the work is the flat list of items (entry (a, b), ligand node u, ligand node v);
 // the wave's 64 / G lane groups ("slots") take consecutive items, lane c of a slot its conformer c, and
 // add the item's likelihood and fail flag into per-entry LDS accumulators (ds_add). Consecutive items
