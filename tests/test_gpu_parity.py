@@ -125,3 +125,46 @@ def test_fp16_coordinate_sweep_stress_config():
     print(f"fp16 coordinates: median rel err {np.median(err):.2e}, max {err.max():.2e} over {nz.sum()} ligands")
     assert np.median(err) < 2e-3
     assert rel_err(full_scores[nz], d["score"][nz]).max() < RTOL + 6e-8
+
+
+def test_bench_size_library_properties_and_oracle_sample(oracle, monkeypatch):
+    """BASELINE.json configs[1] at full size (the library `bench.py` times: 1 003 520 ligands x 8 conformers):
+    scores are finite and non-negative, bit-identical when the pass is cut into 11 chunks instead of 4, their
+    checksum is reproducible, and a random sample of 3 000 ligands agrees with the CPU oracle."""
+    import os
+
+    import torch
+
+    from pharmaconet_amd import PackedLibrary
+    from pharmaconet_amd.constants import TYPE_ID, weights_vector
+    from pharmaconet_amd.engine import DeviceLibrary
+    from pharmaconet_amd.synthetic import BASE_SEED, expand_library_on_device, synthetic_library
+
+    model, _, _, _ = load_golden("set_6oim_c8")
+    st = model.__getstate__()
+    centers = np.array([n["center"] for n in st["nodes"]], dtype=np.float64)
+    types = np.array([TYPE_ID[n["type"]] for n in st["nodes"]])
+    base = synthetic_library(4096, first=0, num_conformers=8, model_nodes=(centers, types), active_fraction=0.1,
+                             seed=BASE_SEED, max_nodes=32, conformer_noise=0.0)
+    offsets, data = expand_library_on_device(base, 245, "cuda", seed=BASE_SEED)
+    lib = DeviceLibrary.from_device_buffers(offsets, data)
+    assert len(lib) == 1_003_520
+    full = model.screen(lib).scores
+    assert torch.isfinite(full).all() and (full >= 0).all()
+    checksum = full.double().sum().item()
+    with monkeypatch.context() as mp:
+        mp.setenv("PMX_CHUNK", "100000")
+        again = model.screen(lib).scores
+    assert torch.equal(again, full)
+    assert again.double().sum().item() == checksum
+    # oracle on a sample
+    rng = np.random.default_rng(99)
+    pick = np.sort(rng.choice(len(lib), size=3000, replace=False))
+    off = offsets.cpu().numpy()
+    dat = data.cpu().numpy()
+    sample = PackedLibrary.from_records([dat[off[i] : off[i + 1]].tobytes() for i in pick])
+    ref = oracle.oracle_score(model.flat, sample, weights_vector(None), num_threads=os.cpu_count() or 8)
+    got = full[torch.from_numpy(pick).cuda()].cpu().numpy()
+    zero = ref == 0
+    assert np.all(got[zero] == 0.0)
+    assert rel_err(got[~zero], ref[~zero]).max() < RTOL + 6e-8
