@@ -8,7 +8,8 @@
 // exactly where the reference couples them (the joint `any conformer valid` and
 // `num_matches + max_num_matches < 5` tests of tree.py:83-84,98), through __ballot.
 //
-// Kernels per chunk of ligands (one HIP stream, kernel -> kernel ordering only):
+// Kernels per chunk of ligands (table phase on a side stream, tree phase on the caller's stream, ordered by
+// events; see pmx_api.hip):
 //   clear_kernel       zeroes the chunk's counters and accumulators
 //   sizes_kernel       one thread per ligand: candidate sets -> number of tree levels, table size
 //   scan_kernel        table sizes -> offsets in the scratch arena
@@ -557,9 +558,9 @@ __global__ __launch_bounds__(256) void bounds_kernel(uint32_t count, const int32
 // and descending into an existing candidate adds
 //   total(b) = total(parent) + S[f][b] + sum_q P[entry(q, f, b)]       (tree.py:38-41)
 //
-// One wavefront per ligand. The ligand's tables (V, S, P; ~10 KB at BASELINE shapes) are staged in
-// LDS once, and the wave's 64 / G conformer groups walk different subtrees of the SAME tree, so a
-// step is a short chain of LDS reads instead of dependent HBM round trips.
+// One wavefront per ligand. The ligand's tables (V, S, P, R; ~11 KB at BASELINE shapes) stay in the arena and
+// are read through L2 with 32-bit offsets from a wave-uniform base; the wave's 64 / G conformer groups walk
+// different subtrees of the SAME tree, sharing its tables in cache.
 //
 // Work splitting. Trees are heavy-tailed (median ~1e3 nodes, tail > 1e7), and a tree walked by one
 // group is a serial chain. The only coupling between sibling subtrees is the skip rule
@@ -575,7 +576,12 @@ __global__ __launch_bounds__(256) void bounds_kernel(uint32_t count, const int32
 //   * across waves: a job that exceeds its iteration budget appends all its open children to a global
 //     task queue; tasks are run by the same kernel (TASKS = true) in rounds, splitting again when over
 //     budget; per-conformer maxima of split ligands are combined with atomicMax in `bestbuf`
-//     (non-negative doubles order as uint64).
+//     (non-negative doubles order as uint64);
+// and it may DROP a child whose subtree cannot raise any conformer's maximum (bound test against the
+// suffix bounds R of bounds_kernel): the maxima, hence the score, and by the argument above every skip
+// decision stay what they were. Frames with < 4 matches need their children's real return values; their
+// children are handed over inside the wave only, with a join (the frame counts the children it has out in
+// `.x` and waits for the walkers' reports, see `rep`).
 struct TaskHeader { // 64 bytes, followed by double tot[G]
     uint32_t lig;   // ligand index inside the chunk
     uint8_t f0;     // frame of the subtree's root
