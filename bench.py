@@ -31,6 +31,7 @@ REPO = Path(__file__).resolve().parent
 sys.path.insert(0, str(REPO))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s HBM3E spec
+VALU_LANE_OPS = 256 * 64 * 2.4e9  # plain (unpacked) VALU lane-operations per second
 
 
 def log(*a):
@@ -81,7 +82,7 @@ def cpu_baseline(model, offsets, data, n_conf, budget_s=15.0):
     w = weights_vector(None)
     probe = sample(min(2048, offsets.numel() - 1))
     t0 = time.perf_counter()
-    orc.oracle_score(model.flat, probe, w, num_threads=cores)
+    _, probe_stats = orc.oracle_score(model.flat, probe, w, num_threads=cores, with_stats=True)
     dt = time.perf_counter() - t0
     rate = len(probe) / max(dt, 1e-6)
     n = int(min(offsets.numel() - 1, max(len(probe), rate * budget_s)))
@@ -89,13 +90,17 @@ def cpu_baseline(model, offsets, data, n_conf, budget_s=15.0):
     t0 = time.perf_counter()
     orc.oracle_score(model.flat, lib, w, num_threads=cores)
     dt = time.perf_counter() - t0
+    work = {  # what the reference's algorithm does per ligand on this library (oracle counters, first 2048 ligands)
+        "gaussian_terms_per_ligand_conformer": float(probe_stats["n_terms"].mean()),
+        "tree_nodes_per_ligand_without_bound_test": float(probe_stats["n_tree"].mean()),
+    }
     return {
         "value": n * n_conf / dt,
         "unit": "ligand-conformers/s",
         "cores": cores,
         "kind": "port",
         "sample": f"first {n} ligands of the same library, OpenMP over ligands, {dt:.1f}s",
-    }
+    }, work
 
 
 def main():
@@ -260,7 +265,23 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(model, offsets, data, args.conformers)
+            out["cpu_baseline"], work = cpu_baseline(model, offsets, data, args.conformers)
+            # The bound that matters for the table kernel: Gaussian terms per second against the VALU issue rate,
+            # pricing a term at the 10 plain VALU slots it needs (address, 2 x multiply, subtract, exp ~ 5/3 slot,
+            # fma, compare, count; MI355X_MICROARCH.md: 256 CU x 4 SIMD x 16 lanes x 2.4 GHz = 3.93e13 lane-ops/s).
+            terms_per_s = work["gaussian_terms_per_ligand_conformer"] * value
+            out["roofline_valu"] = {
+                "bound": "valu",
+                "kernel": "tables_kernel_v2",
+                "achieved": terms_per_s / 1e12,
+                "peak": VALU_LANE_OPS / 10 / 1e12,
+                "unit": "T Gaussian terms/s",
+                "frac": terms_per_s / (VALU_LANE_OPS / 10),
+                "frac_of_table_phase_alone": terms_per_s / (VALU_LANE_OPS / 10) * (ms_per_step / max(ms_tables / max(args.steps, 1), 1e-9)),
+                **work,
+                "note": "whole-pass rate; frac_of_table_phase_alone rescales by pass time / table-phase time "
+                        "(the table phase overlaps the tree phase of the previous chunk)",
+            }
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

@@ -42,6 +42,7 @@ RESULT_DTYPE = np.dtype(
         ("p_sum", "<f8"),
         ("p_invalid", "<i8"),
         ("p_entries", "<i8"),
+        ("n_terms", "<i8"),
     ]
 )
 

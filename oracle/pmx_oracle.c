@@ -40,6 +40,7 @@ typedef struct {
     int64_t n_tree, n_leaf; /* tree nodes below the root; leaves */
     double s_sum, p_sum;    /* sum of self-table entries; sum of valid pair-table entries */
     int64_t p_invalid, p_entries;
+    int64_t n_terms; /* Gaussian terms evaluated per conformer (model node pairs over all ligand node pairs): work measure */
 } oracle_result;
 
 typedef struct {
@@ -73,7 +74,7 @@ typedef struct {
     float *S[MAX_LEVELS];             /* [k_i][C] */
     float *P[MAX_LEVELS][MAX_LEVELS]; /* i<j: [k_i][k_j][C] */
     double best[MAX_C];
-    int64_t n_tree, n_leaf;
+    int64_t n_tree, n_leaf, n_terms;
     /* DFS path */
     int sel[MAX_LEVELS];
 } ctx_t;
@@ -112,10 +113,11 @@ static void cluster_center_size(const ligand_t *L, int start, int end, int c, fl
 
 /* scoring/match_utils.py:26-69 (pair) and :87-120 (self): one (ligand node, ligand node) term.
  * Adds the likelihood to score[c]; if fails != NULL also counts a fail per conformer. */
-static void node_pair_term(const ctx_t *X, const node_match *a, const node_match *b, float *score, int16_t *fails) {
+static void node_pair_term(ctx_t *X, const node_match *a, const node_match *b, float *score, int16_t *fails) {
     const oracle_model *M = X->M;
     const int C = X->L.C, Nm = M->n_nodes;
     int num_match = a->nm * b->nm;
+    X->n_terms += num_match;
     /* weights = outer(w1, w2).reshape(-1); weights_sum = sum(weights)  (builtin sum, float32 steps) */
     float weights_sum = 0.f;
     for (int i = 0; i < a->nm; ++i)
@@ -337,6 +339,7 @@ static void score_ligand(const oracle_model *M, const uint8_t *rec, const float 
         R->score = sum / (double)L->C; /* graph_match.py:109 */
         R->n_tree = X->n_tree;
         R->n_leaf = X->n_leaf;
+        R->n_terms = X->n_terms;
     }
     for (int i = 0; i < X->nl; ++i) {
         free(X->S[i]);
