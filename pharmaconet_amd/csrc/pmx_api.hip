@@ -275,6 +275,7 @@ struct Workspace {
     int num_cu = 0;
     hipStream_t side = nullptr;
     hipEvent_t entry = nullptr;
+    uint32_t lds_attr_set = 0; // bit log2(G): the kernels of that conformer-group width may use all of the CU's LDS on this device
 };
 static std::map<int, Workspace> g_ws;
 static std::mutex g_mu;
@@ -521,15 +522,15 @@ template <int G>
 static int score_chunks(const pmx_model *model, const pmx_library *lib, const Weights &W, uint64_t first, uint64_t count,
                         float *scores_dev, int32_t *status_dev, hipStream_t stream, Workspace &ws) {
     const uint32_t cap = std::min<uint32_t>(chunk_size(), ws.chunk_cap);
-    static bool attr_set = false;
-    if (!attr_set) {
+    const uint32_t attr_bit = 1u << __builtin_ctz((unsigned)G);
+    if (!(ws.lds_attr_set & attr_bit)) { // once per device (the workspace is per device) and group width
         HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&tables_kernel_v2<G>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));
         HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&tree_kernel<G, false>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));
         HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&tree_kernel<G, true>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));
-        attr_set = true;
+        ws.lds_attr_set |= attr_bit;
     }
     // PMX_OVERLAP=0 runs both phases on the caller's stream (no concurrency between chunks)
     const bool overlap = env_long("PMX_OVERLAP", 1) != 0;
