@@ -109,7 +109,9 @@ int pmx_library_destroy(pmx_library *lib);
 int pmx_score(const pmx_model *model, const pmx_library *lib, const float weights[PMX_NUM_TYPES], uint64_t first,
               uint64_t count, float *scores_dev, int32_t *status_dev, void *stream);
 
-/* The same for several models over one library (one pocket after the other; scores_dev is [n_models][count]). */
+/* The same for several models over one library: one pocket after the other through one chunk pipeline (the table
+ * kernels of the next pocket's first chunk overlap the tree kernels of the previous pocket's last);
+ * scores_dev is [n_models][count], status_dev[count] is written once. */
 int pmx_score_multi(const pmx_model *const *models, int n_models, const pmx_library *lib,
                     const float weights[PMX_NUM_TYPES], uint64_t first, uint64_t count, float *scores_dev,
                     int32_t *status_dev, void *stream);

@@ -518,9 +518,12 @@ static int tree_phase(const pmx_model *model, const pmx_library *lib, int32_t *s
     return PMX_OK;
 }
 
+// Work items = (model, chunk), model-major: the table phase of item i + 1 overlaps the tree phase of item i, also across
+// the models of pmx_score_multi. scores_dev is [n_models][count]; the status (a property of the ligand record) is
+// reported once, by the first model.
 template <int G>
-static int score_chunks(const pmx_model *model, const pmx_library *lib, const Weights &W, uint64_t first, uint64_t count,
-                        float *scores_dev, int32_t *status_dev, hipStream_t stream, Workspace &ws) {
+static int score_chunks(const pmx_model *const *models, int n_models, const pmx_library *lib, const Weights &W, uint64_t first,
+                        uint64_t count, float *scores_dev, int32_t *status_dev, hipStream_t stream, Workspace &ws) {
     const uint32_t cap = std::min<uint32_t>(chunk_size(), ws.chunk_cap);
     const uint32_t attr_bit = 1u << __builtin_ctz((unsigned)G);
     if (!(ws.lds_attr_set & attr_bit)) { // once per device (the workspace is per device) and group width
@@ -539,14 +542,18 @@ static int score_chunks(const pmx_model *model, const pmx_library *lib, const We
         HIPCHECK(hipEventRecord(ws.entry, stream));
         HIPCHECK(hipStreamWaitEvent(side, ws.entry, 0));
     }
-    const uint64_t n_chunks = (count + cap - 1) / cap;
-    auto chunk_n = [&](uint64_t k) { return (uint32_t)std::min<uint64_t>(cap, count - k * cap); };
-    auto chunk_status = [&](uint64_t k) { return status_dev ? status_dev + k * cap : ws.slot[k & 1].status; };
-    int rc = table_phase<G>(model, lib, W, first, chunk_n(0), chunk_status(0), ws.slot[0], side);
-    for (uint64_t k = 0; k < n_chunks && rc == PMX_OK; ++k) {
-        if (k + 1 < n_chunks)
-            rc = table_phase<G>(model, lib, W, first + (k + 1) * cap, chunk_n(k + 1), chunk_status(k + 1), ws.slot[(k + 1) & 1], side);
-        if (rc == PMX_OK) rc = tree_phase<G>(model, lib, chunk_status(k), scores_dev + k * cap, ws.slot[k & 1], ws, stream);
+    const uint64_t n_chunks = (count + cap - 1) / cap, n_items = n_chunks * (uint64_t)n_models;
+    auto model_of = [&](uint64_t it) { return models[it / n_chunks]; };
+    auto chunk_n = [&](uint64_t it) { return (uint32_t)std::min<uint64_t>(cap, count - (it % n_chunks) * cap); };
+    auto chunk_first = [&](uint64_t it) { return first + (it % n_chunks) * cap; };
+    auto chunk_status = [&](uint64_t it) { return (status_dev && it < n_chunks) ? status_dev + it * cap : ws.slot[it & 1].status; };
+    auto chunk_scores = [&](uint64_t it) { return scores_dev + (it / n_chunks) * count + (it % n_chunks) * cap; };
+    int rc = table_phase<G>(model_of(0), lib, W, chunk_first(0), chunk_n(0), chunk_status(0), ws.slot[0], side);
+    for (uint64_t it = 0; it < n_items && rc == PMX_OK; ++it) {
+        if (it + 1 < n_items)
+            rc = table_phase<G>(model_of(it + 1), lib, W, chunk_first(it + 1), chunk_n(it + 1), chunk_status(it + 1),
+                                ws.slot[(it + 1) & 1], side);
+        if (rc == PMX_OK) rc = tree_phase<G>(model_of(it), lib, chunk_status(it), chunk_scores(it), ws.slot[it & 1], ws, stream);
     }
     if (rc != PMX_OK) { // leave no work in flight that still references the slots
         (void)hipStreamSynchronize(side);
@@ -561,59 +568,41 @@ static int next_pow2(int x) {
     return g;
 }
 
-extern "C" int pmx_score(const pmx_model *model, const pmx_library *lib, const float weights[PMX_NUM_TYPES], uint64_t first,
-                         uint64_t count, float *scores_dev, int32_t *status_dev, void *stream_) {
-    if (!model || !lib || !weights || (!scores_dev && count)) return fail(PMX_ERR_INVALID, "null argument");
-    if (model->device != lib->device) return fail(PMX_ERR_INVALID, "model and library live on different devices");
+extern "C" int pmx_score_multi(const pmx_model *const *models, int n_models, const pmx_library *lib,
+                               const float weights[PMX_NUM_TYPES], uint64_t first, uint64_t count, float *scores_dev,
+                               int32_t *status_dev, void *stream_) {
+    if (!models || n_models < 0 || !lib || !weights || (!scores_dev && count && n_models)) return fail(PMX_ERR_INVALID, "null argument");
+    for (int i = 0; i < n_models; ++i) {
+        if (!models[i]) return fail(PMX_ERR_INVALID, "null model");
+        if (models[i]->device != lib->device) return fail(PMX_ERR_INVALID, "model and library live on different devices");
+    }
     if (first > lib->info.n_ligands || count > lib->info.n_ligands - first) return fail(PMX_ERR_INVALID, "ligand range out of bounds");
     std::lock_guard<std::mutex> lock(g_mu);
     g_stats = pmx_score_stats{};
-    if (count == 0) return PMX_OK;
-    HIPCHECK(hipSetDevice(model->device));
+    if (count == 0 || n_models == 0) return PMX_OK;
+    HIPCHECK(hipSetDevice(lib->device));
     Workspace *ws = nullptr;
-    int rc = ensure_workspace(model->device, &ws);
+    int rc = ensure_workspace(lib->device, &ws);
     if (rc) return rc;
     Weights W;
     for (int t = 0; t < PMX_NUM_TYPES; ++t) W.w[t] = weights[t];
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int G = next_pow2(std::max(1, std::min(lib->info.max_conformers, PMX_MAX_CONFORMERS)));
     switch (G) {
-    case 1: return score_chunks<1>(model, lib, W, first, count, scores_dev, status_dev, stream, *ws);
-    case 2: return score_chunks<2>(model, lib, W, first, count, scores_dev, status_dev, stream, *ws);
-    case 4: return score_chunks<4>(model, lib, W, first, count, scores_dev, status_dev, stream, *ws);
-    case 8: return score_chunks<8>(model, lib, W, first, count, scores_dev, status_dev, stream, *ws);
-    case 16: return score_chunks<16>(model, lib, W, first, count, scores_dev, status_dev, stream, *ws);
-    case 32: return score_chunks<32>(model, lib, W, first, count, scores_dev, status_dev, stream, *ws);
-    default: return score_chunks<64>(model, lib, W, first, count, scores_dev, status_dev, stream, *ws);
+    case 1: return score_chunks<1>(models, n_models, lib, W, first, count, scores_dev, status_dev, stream, *ws);
+    case 2: return score_chunks<2>(models, n_models, lib, W, first, count, scores_dev, status_dev, stream, *ws);
+    case 4: return score_chunks<4>(models, n_models, lib, W, first, count, scores_dev, status_dev, stream, *ws);
+    case 8: return score_chunks<8>(models, n_models, lib, W, first, count, scores_dev, status_dev, stream, *ws);
+    case 16: return score_chunks<16>(models, n_models, lib, W, first, count, scores_dev, status_dev, stream, *ws);
+    case 32: return score_chunks<32>(models, n_models, lib, W, first, count, scores_dev, status_dev, stream, *ws);
+    default: return score_chunks<64>(models, n_models, lib, W, first, count, scores_dev, status_dev, stream, *ws);
     }
 }
 
-extern "C" int pmx_score_multi(const pmx_model *const *models, int n_models, const pmx_library *lib,
-                               const float weights[PMX_NUM_TYPES], uint64_t first, uint64_t count, float *scores_dev,
-                               int32_t *status_dev, void *stream) {
-    if (!models || n_models < 0) return fail(PMX_ERR_INVALID, "null argument");
-    pmx_score_stats acc = {};
-    for (int i = 0; i < n_models; ++i) {
-        int rc = pmx_score(models[i], lib, weights, first, count, scores_dev + (size_t)i * count, i == 0 ? status_dev : nullptr, stream);
-        if (rc) return rc;
-        acc.ms_sizes += g_stats.ms_sizes;
-        acc.ms_tables += g_stats.ms_tables;
-        acc.ms_tree += g_stats.ms_tree;
-        acc.ms_tasks += g_stats.ms_tasks;
-        acc.ms_total += g_stats.ms_total;
-        acc.table_bytes += g_stats.table_bytes;
-        acc.n_chunks += g_stats.n_chunks;
-        acc.n_tasks += g_stats.n_tasks;
-        acc.n_steps += g_stats.n_steps;
-        acc.n_iters += g_stats.n_iters;
-        acc.max_iters_ligand = std::max(acc.max_iters_ligand, g_stats.max_iters_ligand);
-        acc.max_iters_task = std::max(acc.max_iters_task, g_stats.max_iters_task);
-        acc.n_steps_first += g_stats.n_steps_first;
-        acc.n_rounds += g_stats.n_rounds;
-        acc.queue_overflow |= g_stats.queue_overflow;
-    }
-    g_stats = acc;
-    return PMX_OK;
+extern "C" int pmx_score(const pmx_model *model, const pmx_library *lib, const float weights[PMX_NUM_TYPES], uint64_t first,
+                         uint64_t count, float *scores_dev, int32_t *status_dev, void *stream) {
+    if (!model) return fail(PMX_ERR_INVALID, "null argument");
+    return pmx_score_multi(&model, 1, lib, weights, first, count, scores_dev, status_dev, stream);
 }
 
 // error hook for pmx_topk.hip (keeps the thread-local message in one translation unit)
