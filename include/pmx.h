@@ -104,7 +104,8 @@ int pmx_library_destroy(pmx_library *lib);
  * (graph_match.py:32-40,81-83) in type-id order. scores_dev[count] receives the float32 value
  * of the float the reference returns (0 for ligands without clusters or candidates,
  * graph_match.py:95-99); status_dev[count] (may be NULL) receives PMX_LIGAND_*.
- * Asynchronous on `stream` except for one small device-to-host read per chunk.
+ * The range is cut into PMX_PIPELINES (default 3) parts scored concurrently by internal host threads and streams;
+ * the results are ordered on `stream`. The call itself blocks on small device-to-host reads (one per chunk and task round).
  */
 int pmx_score(const pmx_model *model, const pmx_library *lib, const float weights[PMX_NUM_TYPES], uint64_t first,
               uint64_t count, float *scores_dev, int32_t *status_dev, void *stream);

@@ -9,6 +9,9 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <string>
+#include <thread>
+#include <utility>
 #include <vector>
 #include <time.h>
 
@@ -274,10 +277,12 @@ struct Workspace {
     size_t queue_bytes = 0;
     int num_cu = 0;
     hipStream_t side = nullptr;
+    hipStream_t own = nullptr;   // the tree-phase stream of a secondary pipeline (the first one uses the caller's)
     hipEvent_t entry = nullptr;
+    hipEvent_t done = nullptr;   // a secondary pipeline has finished its range
     uint32_t lds_attr_set = 0; // bit log2(G): the kernels of that conformer-group width may use all of the CU's LDS on this device
 };
-static std::map<int, Workspace> g_ws;
+static std::map<std::pair<int, int>, Workspace> g_ws; // (device, pipeline)
 static std::mutex g_mu;
 
 static uint32_t chunk_size() { // read per call: tests vary it to cut the library differently
@@ -292,8 +297,8 @@ static long env_long(const char *name, long dflt) {
     return std::atol(s);
 }
 
-static int ensure_workspace(int device, Workspace **out) {
-    Workspace &w = g_ws[device];
+static int ensure_workspace(int device, int pipeline, Workspace **out) {
+    Workspace &w = g_ws[std::make_pair(device, pipeline)];
     const uint32_t cap = chunk_size();
     if (w.chunk_cap < cap) {
         for (Slot &sl : w.slot) {
@@ -315,7 +320,9 @@ static int ensure_workspace(int device, Workspace **out) {
         HIPCHECK(hipGetDeviceProperties(&prop, device));
         w.num_cu = prop.multiProcessorCount;
         HIPCHECK(hipStreamCreateWithFlags(&w.side, hipStreamNonBlocking));
+        HIPCHECK(hipStreamCreateWithFlags(&w.own, hipStreamNonBlocking));
         HIPCHECK(hipEventCreateWithFlags(&w.entry, hipEventDisableTiming));
+        HIPCHECK(hipEventCreateWithFlags(&w.done, hipEventDisableTiming));
         for (Slot &sl : w.slot) {
             HIPCHECK(hipMalloc((void **)&sl.meta, 1024));
             HIPCHECK(hipHostMalloc((void **)&sl.meta_host, 1024));
@@ -325,7 +332,7 @@ static int ensure_workspace(int device, Workspace **out) {
         }
     }
     if (!w.queue) {
-        w.queue_bytes = (size_t)std::max<long>(16, env_long("PMX_TASKQ_MB", 4096)) << 20;
+        w.queue_bytes = (size_t)std::max<long>(16, env_long("PMX_TASKQ_MB", 2048)) << 20;
         HIPCHECK(hipMalloc((void **)&w.queue, w.queue_bytes));
     }
     *out = &w;
@@ -523,7 +530,8 @@ static int tree_phase(const pmx_model *model, const pmx_library *lib, int32_t *s
 // reported once, by the first model.
 template <int G>
 static int score_chunks(const pmx_model *const *models, int n_models, const pmx_library *lib, const Weights &W, uint64_t first,
-                        uint64_t count, float *scores_dev, int32_t *status_dev, hipStream_t stream, Workspace &ws) {
+                        uint64_t count, uint64_t model_stride, float *scores_dev, int32_t *status_dev, hipStream_t stream,
+                        Workspace &ws) {
     const uint32_t cap = std::min<uint32_t>(chunk_size(), ws.chunk_cap);
     const uint32_t attr_bit = 1u << __builtin_ctz((unsigned)G);
     if (!(ws.lds_attr_set & attr_bit)) { // once per device (the workspace is per device) and group width
@@ -547,7 +555,7 @@ static int score_chunks(const pmx_model *const *models, int n_models, const pmx_
     auto chunk_n = [&](uint64_t it) { return (uint32_t)std::min<uint64_t>(cap, count - (it % n_chunks) * cap); };
     auto chunk_first = [&](uint64_t it) { return first + (it % n_chunks) * cap; };
     auto chunk_status = [&](uint64_t it) { return (status_dev && it < n_chunks) ? status_dev + it * cap : ws.slot[it & 1].status; };
-    auto chunk_scores = [&](uint64_t it) { return scores_dev + (it / n_chunks) * count + (it % n_chunks) * cap; };
+    auto chunk_scores = [&](uint64_t it) { return scores_dev + (it / n_chunks) * model_stride + (it % n_chunks) * cap; };
     int rc = table_phase<G>(model_of(0), lib, W, chunk_first(0), chunk_n(0), chunk_status(0), ws.slot[0], side);
     for (uint64_t it = 0; it < n_items && rc == PMX_OK; ++it) {
         if (it + 1 < n_items)
@@ -581,22 +589,86 @@ extern "C" int pmx_score_multi(const pmx_model *const *models, int n_models, con
     g_stats = pmx_score_stats{};
     if (count == 0 || n_models == 0) return PMX_OK;
     HIPCHECK(hipSetDevice(lib->device));
-    Workspace *ws = nullptr;
-    int rc = ensure_workspace(lib->device, &ws);
-    if (rc) return rc;
     Weights W;
     for (int t = 0; t < PMX_NUM_TYPES; ++t) W.w[t] = weights[t];
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int G = next_pow2(std::max(1, std::min(lib->info.max_conformers, PMX_MAX_CONFORMERS)));
-    switch (G) {
-    case 1: return score_chunks<1>(models, n_models, lib, W, first, count, scores_dev, status_dev, stream, *ws);
-    case 2: return score_chunks<2>(models, n_models, lib, W, first, count, scores_dev, status_dev, stream, *ws);
-    case 4: return score_chunks<4>(models, n_models, lib, W, first, count, scores_dev, status_dev, stream, *ws);
-    case 8: return score_chunks<8>(models, n_models, lib, W, first, count, scores_dev, status_dev, stream, *ws);
-    case 16: return score_chunks<16>(models, n_models, lib, W, first, count, scores_dev, status_dev, stream, *ws);
-    case 32: return score_chunks<32>(models, n_models, lib, W, first, count, scores_dev, status_dev, stream, *ws);
-    default: return score_chunks<64>(models, n_models, lib, W, first, count, scores_dev, status_dev, stream, *ws);
+    auto run = [&](uint64_t lo, uint64_t n, hipStream_t q, Workspace &ws) -> int {
+        float *sc = scores_dev + lo;
+        int32_t *st = status_dev ? status_dev + lo : nullptr;
+        switch (G) {
+        case 1: return score_chunks<1>(models, n_models, lib, W, first + lo, n, count, sc, st, q, ws);
+        case 2: return score_chunks<2>(models, n_models, lib, W, first + lo, n, count, sc, st, q, ws);
+        case 4: return score_chunks<4>(models, n_models, lib, W, first + lo, n, count, sc, st, q, ws);
+        case 8: return score_chunks<8>(models, n_models, lib, W, first + lo, n, count, sc, st, q, ws);
+        case 16: return score_chunks<16>(models, n_models, lib, W, first + lo, n, count, sc, st, q, ws);
+        case 32: return score_chunks<32>(models, n_models, lib, W, first + lo, n, count, sc, st, q, ws);
+        default: return score_chunks<64>(models, n_models, lib, W, first + lo, n, count, sc, st, q, ws);
+        }
+    };
+    Workspace *ws0 = nullptr;
+    int rc = ensure_workspace(lib->device, 0, &ws0);
+    if (rc) return rc;
+    // Several independent chunk pipelines over equal parts of the range, each driven by its own host thread: the
+    // kernels of one fill the gaps of the others (kernel tails, host round trips, the phase the others are not in).
+    const uint64_t min_part = std::min<uint32_t>(chunk_size(), 65536);
+    const int P = (int)std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)std::max<long>(1, env_long("PMX_PIPELINES", 3)), 8, count / min_part}));
+    if (P == 1) return run(0, count, stream, *ws0);
+    struct Part {
+        Workspace *ws = nullptr;
+        uint64_t lo = 0, n = 0;
+        int rc = PMX_OK;
+        std::string err;
+        pmx_score_stats st = {};
+    };
+    std::vector<Part> parts((size_t)P);
+    for (int i = 0; i < P; ++i) {
+        parts[i].lo = count * (uint64_t)i / (uint64_t)P;
+        parts[i].n = count * (uint64_t)(i + 1) / (uint64_t)P - parts[i].lo;
+        rc = ensure_workspace(lib->device, i, &parts[i].ws);
+        if (rc) return rc;
+        if (i > 0) HIPCHECK(hipEventRecord(parts[i].ws->entry, stream)); // every pipeline starts after the caller's queued work
     }
+    std::vector<std::thread> threads;
+    for (int i = 1; i < P; ++i)
+        threads.emplace_back([&, i] {
+            Part &pt = parts[i];
+            if (hipSetDevice(lib->device) != hipSuccess || hipStreamWaitEvent(pt.ws->own, pt.ws->entry, 0) != hipSuccess) {
+                pt.rc = PMX_ERR_HIP;
+                pt.err = "pipeline thread: device setup failed";
+                return;
+            }
+            g_stats = pmx_score_stats{};
+            pt.rc = run(pt.lo, pt.n, pt.ws->own, *pt.ws);
+            if (pt.rc == PMX_OK && hipEventRecord(pt.ws->done, pt.ws->own) != hipSuccess) pt.rc = PMX_ERR_HIP;
+            if (pt.rc != PMX_OK) pt.err = g_err;
+            pt.st = g_stats;
+        });
+    rc = run(parts[0].lo, parts[0].n, stream, *ws0);
+    for (auto &t : threads) t.join();
+    if (rc != PMX_OK) return rc;
+    for (int i = 1; i < P; ++i)
+        if (parts[i].rc != PMX_OK) return fail(parts[i].rc, "%s", parts[i].err.c_str());
+    for (int i = 1; i < P; ++i) {
+        HIPCHECK(hipStreamWaitEvent(stream, parts[i].ws->done, 0)); // the caller's stream sees every part
+        const pmx_score_stats &st1 = parts[i].st;
+        g_stats.ms_sizes += st1.ms_sizes;
+        g_stats.ms_tables += st1.ms_tables;
+        g_stats.ms_tree += st1.ms_tree;
+        g_stats.ms_tasks += st1.ms_tasks;
+        g_stats.ms_total += st1.ms_total;
+        g_stats.table_bytes += st1.table_bytes;
+        g_stats.n_chunks += st1.n_chunks;
+        g_stats.n_tasks += st1.n_tasks;
+        g_stats.n_rounds += st1.n_rounds;
+        g_stats.queue_overflow |= st1.queue_overflow;
+        g_stats.n_steps += st1.n_steps;
+        g_stats.n_iters += st1.n_iters;
+        g_stats.max_iters_ligand = std::max(g_stats.max_iters_ligand, st1.max_iters_ligand);
+        g_stats.max_iters_task = std::max(g_stats.max_iters_task, st1.max_iters_task);
+        g_stats.n_steps_first += st1.n_steps_first;
+    }
+    return PMX_OK;
 }
 
 extern "C" int pmx_score(const pmx_model *model, const pmx_library *lib, const float weights[PMX_NUM_TYPES], uint64_t first,
