@@ -532,7 +532,10 @@ template <int G>
 static int score_chunks(const pmx_model *const *models, int n_models, const pmx_library *lib, const Weights &W, uint64_t first,
                         uint64_t count, uint64_t model_stride, float *scores_dev, int32_t *status_dev, hipStream_t stream,
                         Workspace &ws) {
-    const uint32_t cap = std::min<uint32_t>(chunk_size(), ws.chunk_cap);
+    // equal chunks: the range is cut into the fewest chunks of at most chunk_size() ligands, all of the same size
+    const uint32_t cap_max = std::min<uint32_t>(chunk_size(), ws.chunk_cap);
+    const uint64_t want_chunks = (count + cap_max - 1) / cap_max;
+    const uint32_t cap = (uint32_t)((count + want_chunks - 1) / std::max<uint64_t>(want_chunks, 1));
     const uint32_t attr_bit = 1u << __builtin_ctz((unsigned)G);
     if (!(ws.lds_attr_set & attr_bit)) { // once per device (the workspace is per device) and group width
         HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&tables_kernel_v2<G>),
