@@ -126,6 +126,7 @@ extern "C" int pmx_model_create(const pmx_model_desc *d, int device, pmx_model *
                 continue;
             }
             e[0] = (unsigned char)cnt;
+            for (int q = 1; q <= 12; ++q) e[q] = (unsigned char)Nm; // padding: the neutral column of the staged table
             int q = 1;
             for (int m = 0; m < Nm; ++m)
                 if (nodes >> m & 1) e[q++] = (unsigned char)m;
@@ -389,7 +390,7 @@ static int table_phase(const pmx_model *model, const pmx_library *lib, const Wei
     if (g_profiling) HIPCHECK(hipEventRecord(sl.ev[1], q));
     if (sl.table_total > 0) {
         // <= 8 ligands (waves) per block share one staged model table; the 160 KB of LDS always hold at least one
-        const size_t model_lds = (size_t)Nm * Nm * sizeof(float4) + 64 * 8 + 128 * 8;
+        const size_t model_lds = (size_t)Nm * (Nm + 1) * sizeof(float4) + 64 * 8 + 128 * 8; // edge table + one neutral column
         if (model_lds + tables_v2_wave_bytes<G>() + 1024 > kLdsPerCu) return fail(PMX_ERR_INVALID, "model tables do not fit LDS");
         const int v2_waves = (int)std::min<size_t>(8, (kLdsPerCu - 1024 - model_lds) / tables_v2_wave_bytes<G>());
         const size_t lds2 = model_lds + (size_t)v2_waves * tables_v2_wave_bytes<G>();

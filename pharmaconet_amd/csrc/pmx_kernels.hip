@@ -164,7 +164,7 @@ __device__ inline void cluster_center_size(const float *xyz, int C, int start, i
 // batches of three independent LDS reads + the arithmetic; the Gaussian is one v_exp_f32 (results below 2^-126
 // flush to zero, far under float32 resolution of the sums). Order: m ascending, n ascending, as the
 // reference (clusters of more than 12 compatible nodes are summed in column blocks of 12).
-__device__ inline void node_pair(const float4 *tab, int Nm, uint64_t A, uint64_t B, float d, float &acc, int &npass) {
+__device__ inline void node_pair(const float4 *tab, int Ns, uint64_t A, uint64_t B, float d, float &acc, int &npass) {
     constexpr int W = 3, NCOL = 12; // batch width and columns decoded per pass: cluster sizes of 3, 6, 9 nodes waste nothing
     while (B) {
         int col[NCOL];
@@ -181,7 +181,7 @@ __device__ inline void node_pair(const float4 *tab, int Nm, uint64_t A, uint64_t
         // weights of the absent columns are zero: fma(0, x, acc) leaves acc unchanged, so the reads of a batch
         // can be issued together and nothing branches per term
         for (uint64_t am = A; am; am &= am - 1) {
-            const float4 *row = tab + (__ffsll((unsigned long long)am) - 1) * Nm;
+            const float4 *row = tab + (__ffsll((unsigned long long)am) - 1) * Ns;
 #pragma unroll
             for (int y0 = 0; y0 < NCOL; y0 += W) {
                 if (y0 < nc) {
@@ -203,11 +203,13 @@ __device__ inline void node_pair(const float4 *tab, int Nm, uint64_t A, uint64_t
 }
 
 // The same term with the two node sets given as the model's precomputed lists (DevModel::clist: byte 0 = count,
-// bytes 1..12 = node numbers ascending): no mask walking. Only for sets of at most 12 nodes (count != 0xff).
-__device__ inline void node_pair_lists(const float4 *tab, int Nm, const uint4 la, const uint4 lb, float d, float &acc, int &npass) {
+// bytes 1..12 = node numbers ascending, padded with Nm): no mask walking. Only for sets of at most 12 nodes
+// (count != 0xff). `tab` has Ns = Nm + 1 columns; column Nm is neutral ({0, 0, -1, 0}: contributes exactly 0 to
+// the sum and never counts as a pass), so the padding of the last batch needs no per-term masking.
+__device__ inline void node_pair_lists(const float4 *tab, int Ns, const uint4 la, const uint4 lb, float d, float &acc, int &npass) {
     constexpr int W = 3, NCOL = 12;
     const int na = (int)(la.x & 255u), nc = (int)(lb.x & 255u);
-    int col[NCOL];
+    int col[NCOL]; // absent columns hold the neutral column (weight 0, threshold -1): no masking per term
     col[0] = (lb.x >> 8) & 255u, col[1] = (lb.x >> 16) & 255u, col[2] = lb.x >> 24;
     col[3] = lb.y & 255u, col[4] = (lb.y >> 8) & 255u, col[5] = (lb.y >> 16) & 255u, col[6] = lb.y >> 24;
     col[7] = lb.z & 255u, col[8] = (lb.z >> 8) & 255u, col[9] = (lb.z >> 16) & 255u, col[10] = lb.z >> 24;
@@ -215,7 +217,7 @@ __device__ inline void node_pair_lists(const float4 *tab, int Nm, const uint4 la
     // rows: a 96-bit shift register over bytes 1..12 of la
     uint32_t s0 = (la.x >> 8) | (la.y << 24), s1 = (la.y >> 8) | (la.z << 24), s2 = (la.z >> 8) | (la.w << 24);
     for (int r = 0; r < na; ++r) {
-        const float4 *row = tab + (int)(s0 & 255u) * Nm;
+        const float4 *row = tab + (int)(s0 & 255u) * Ns;
         s0 = (s0 >> 8) | (s1 << 24);
         s1 = (s1 >> 8) | (s2 << 24);
         s2 >>= 8;
@@ -227,11 +229,10 @@ __device__ inline void node_pair_lists(const float4 *tab, int Nm, const uint4 la
                 for (int y = 0; y < W; ++y) e[y] = row[col[y0 + y]];
 #pragma unroll
                 for (int y = 0; y < W; ++y) {
-                    const bool on = y0 + y < nc;
                     const float t = fabsf(d - e[y].x);
                     const float q = t * e[y].y;
-                    acc = __builtin_fmaf(on ? e[y].w : 0.f, __builtin_amdgcn_exp2f(-(q * q)), acc);
-                    npass += (on && t <= e[y].z) ? 1 : 0;
+                    acc = __builtin_fmaf(e[y].w, __builtin_amdgcn_exp2f(-(q * q)), acc);
+                    npass += (t <= e[y].z) ? 1 : 0;
                 }
             }
         }
@@ -245,11 +246,11 @@ __device__ inline int cluster_node_pair(const DevModel &M, const float4 *tab, co
     const int na = (int)(la.x & 255u), nb = (int)(lb.x & 255u);
     if (na == 0 || nb == 0) return 0;
     if (na != 255 && nb != 255) {
-        node_pair_lists(tab, M.Nm, la, lb, d, acc, npass);
+        node_pair_lists(tab, M.Nm + 1, la, lb, d, acc, npass);
         return na * nb;
     }
     const uint64_t A = cnodes[a] & tnodes[tmu], B = cnodes[b] & tnodes[tmv];
-    node_pair(tab, M.Nm, A, B, d, acc, npass);
+    node_pair(tab, M.Nm + 1, A, B, d, acc, npass);
     return __popcll(A) * __popcll(B);
 }
 
@@ -284,7 +285,8 @@ __global__ __launch_bounds__(512, 6) void tables_kernel_v2(DevModel M, DevLibrar
     constexpr int GPW = 64 / G; // slots per wave
     const int Nm = M.Nm;
     float4 *tab = reinterpret_cast<float4 *>(smem);
-    uint64_t *cnodes = reinterpret_cast<uint64_t *>(smem + (size_t)Nm * Nm * sizeof(float4));
+    const int Ns = Nm + 1; // row stride: one neutral column after the model's nodes (see node_pair_lists)
+    uint64_t *cnodes = reinterpret_cast<uint64_t *>(smem + (size_t)Nm * Ns * sizeof(float4));
     uint64_t *tnodes = cnodes + 64;
     unsigned char *wave_base = reinterpret_cast<unsigned char *>(tnodes + 128) + (size_t)(threadIdx.x >> 6) * tables_v2_wave_bytes<G>();
     WaveLevels &WL = *reinterpret_cast<WaveLevels *>(wave_base);
@@ -292,10 +294,13 @@ __global__ __launch_bounds__(512, 6) void tables_kernel_v2(DevModel M, DevLibrar
     unsigned *acc_fail = reinterpret_cast<unsigned *>(acc_score + kTabEntryChunk * G);
     uint8_t *near_list = reinterpret_cast<uint8_t *>(acc_fail + kTabEntryChunk * G); // [kTabEntryChunk]
 
-    for (int i = threadIdx.x; i < Nm * Nm; i += blockDim.x) {
-        float4 e = M.edge[i];
-        const float wm = W.w[M.node_type[i / Nm]], wn = W.w[M.node_type[i % Nm]];
-        e.w = (wm * wn) / e.w; // weights / stds (match_utils.py:65)
+    for (int i = threadIdx.x; i < Nm * Ns; i += blockDim.x) {
+        const int m = i / Ns, n = i - m * Ns;
+        float4 e = make_float4(0.f, 0.f, -1.f, 0.f);
+        if (n < Nm) {
+            e = M.edge[m * Nm + n];
+            e.w = (W.w[M.node_type[m]] * W.w[M.node_type[n]]) / e.w; // weights / stds (match_utils.py:65)
+        }
         tab[i] = e;
     }
     for (int i = threadIdx.x; i < 64; i += blockDim.x) cnodes[i] = M.cnodes[i];
