@@ -17,6 +17,7 @@
 
 #include "pmx.h"
 #include "pmx_kernels.hip"
+#include "pmx_match.hip"
 
 using namespace pmx;
 
@@ -47,10 +48,12 @@ extern "C" int pmx_set_profiling(int enabled) {
     g_profiling = enabled;
     return PMX_OK;
 }
+struct FusedWs;
+static int fused_stats(pmx_score_stats *out);
 extern "C" int pmx_score_stats_get(pmx_score_stats *out) {
     if (!out) return fail(PMX_ERR_INVALID, "null stats");
     *out = g_stats;
-    return PMX_OK;
+    return fused_stats(out);
 }
 
 // -------------------------------------------------------------------------------------- model
@@ -574,6 +577,118 @@ static int score_chunks(const pmx_model *const *models, int n_models, const pmx_
     return rc;
 }
 
+// ------------------------------------------------------------------------------- fused matcher (pmx_match.hip)
+// Everything is stream-ordered: bin the call's ligands by the LDS their tables need, then one persistent launch per
+// size class. No device-to-host read happens inside the call.
+struct FusedWs {
+    BinInfo *bins = nullptr;
+    uint32_t *caps_dev = nullptr;
+    uint32_t *lists = nullptr;
+    uint64_t lists_cap = 0; // ligands per class list
+    float4 *wtab = nullptr;
+    float *wsum = nullptr;
+    unsigned long long *stats = nullptr;
+    uint8_t *arena = nullptr;
+    size_t arena_bytes = 0;
+    int num_cu = 0;
+    uint32_t attr_set = 0;
+    hipStream_t stream = nullptr; // the stream of the last call (stats are read after synchronising it)
+};
+static std::map<std::pair<int, hipStream_t>, FusedWs> g_fused; // (device, stream)
+static thread_local FusedWs *g_last_fused = nullptr;
+
+static int ensure_fused(int device, hipStream_t stream, uint64_t count, FusedWs **out) {
+    FusedWs *w;
+    {
+        std::lock_guard<std::mutex> lock(g_mu);
+        w = &g_fused[std::make_pair(device, stream)];
+    }
+    if (!w->bins) {
+        hipDeviceProp_t prop;
+        HIPCHECK(hipGetDeviceProperties(&prop, device));
+        w->num_cu = prop.multiProcessorCount;
+        HIPCHECK(hipMalloc((void **)&w->bins, sizeof(BinInfo)));
+        HIPCHECK(hipMalloc((void **)&w->caps_dev, sizeof(uint32_t) * kNumBins));
+        HIPCHECK(hipMalloc((void **)&w->wtab, (size_t)PMX_MAX_MODEL_NODES * PMX_MAX_MODEL_NODES * sizeof(float4)));
+        HIPCHECK(hipMalloc((void **)&w->wsum, (size_t)PMX_MAX_MODEL_CLUSTERS * 128 * sizeof(float)));
+        HIPCHECK(hipMalloc((void **)&w->stats, 16 * sizeof(unsigned long long)));
+        w->arena_bytes = (size_t)std::max<long>(16, env_long("PMX_ARENA_MB", 1024)) << 20;
+        HIPCHECK(hipMalloc((void **)&w->arena, w->arena_bytes));
+    }
+    if (w->lists_cap < count) {
+        if (w->lists) {
+            HIPCHECK(hipStreamSynchronize(stream));
+            (void)hipFree(w->lists);
+            w->lists = nullptr;
+            w->lists_cap = 0;
+        }
+        HIPCHECK(hipMalloc((void **)&w->lists, (size_t)(kNumBins + 1) * count * sizeof(uint32_t)));
+        w->lists_cap = count;
+    }
+    w->stream = stream;
+    *out = w;
+    return PMX_OK;
+}
+
+template <int G>
+static int score_fused(const pmx_model *model, const pmx_library *lib, const Weights &W, uint64_t first, uint64_t count, float *scores_dev,
+                       int32_t *status_dev, hipStream_t stream, FusedWs &ws) {
+    if (count > 0xfffffff0ull) return fail(PMX_ERR_INVALID, "more than 2^32 ligands in one call");
+    const int Nm = model->dm.Nm, K = model->dm.K;
+    const uint32_t n = (uint32_t)count;
+    const uint32_t model_lds = model_lds_bytes(Nm);
+    const uint32_t max_cap = ((uint32_t)kLdsPerCu - model_lds - 64u) & ~15u;
+    if (model_lds + sizeof(MatchCtx) + 1024 > kLdsPerCu) return fail(PMX_ERR_INVALID, "model tables do not fit LDS");
+    static const uint32_t kCaps[kNumBins] = {6144, 8192, 12288, 16384, 24576, 32768, 49152, 65536, 98304, 0xffffffffu};
+    uint32_t caps[kNumBins];
+    for (int b = 0; b < kNumBins; ++b) caps[b] = std::min(kCaps[b], max_cap);
+    HIPCHECK(hipMemcpyAsync(ws.caps_dev, caps, sizeof(caps), hipMemcpyHostToDevice, stream));
+    const uint32_t attr_bit = 1u << __builtin_ctz((unsigned)G);
+    if (!(ws.attr_set & attr_bit)) {
+        HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&match_kernel<G, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));
+        HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&match_kernel<G, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));
+        ws.attr_set |= attr_bit;
+    }
+    bins_init_kernel<<<dim3(1), dim3(64), 0, stream>>>(ws.bins, ws.caps_dev, ws.stats);
+    {
+        const int work = std::max(Nm * Nm, K * 128);
+        fold_weights_kernel<<<dim3((work + 255) / 256), dim3(256), 0, stream>>>(model->dm, W, ws.wtab, ws.wsum);
+    }
+    bin_kernel<G><<<dim3((n + 255) / 256), dim3(256), 0, stream>>>(lib->dl, model->dm.tclus, first, n, ws.bins, ws.lists, status_dev, scores_dev);
+    HIPCHECK(hipGetLastError());
+    MatchParams mp;
+    mp.M = model->dm;
+    mp.wtab = ws.wtab;
+    mp.wsum = ws.wsum;
+    mp.lib = lib->dl;
+    mp.first = first;
+    mp.bins = ws.bins;
+    mp.arena = ws.arena;
+    mp.arena_bytes = ws.arena_bytes;
+    mp.scores = scores_dev;
+    mp.stats = ws.stats;
+    mp.flags = (uint32_t)env_long("PMX_TREE_FLAGS", 0);
+    const int blocks_per_cu = (int)std::max<long>(1, env_long("PMX_BLOCKS_PER_CU", 1));
+    for (int b = kNumBins - 1; b >= 0; --b) { // the heaviest ligands first
+        if (b > 0 && caps[b] == caps[b - 1]) continue; // clamped duplicate: bin_kernel never fills it
+        const uint32_t waves = std::max<uint32_t>(1, std::min<uint32_t>(16, ((uint32_t)kLdsPerCu - model_lds) / caps[b]));
+        mp.list = ws.lists + (size_t)b * n;
+        mp.bin = (uint32_t)b;
+        mp.wave_bytes = caps[b];
+        const size_t lds = model_lds + (size_t)waves * caps[b];
+        match_kernel<G, true><<<dim3(ws.num_cu * blocks_per_cu), dim3(64 * waves), lds, stream>>>(mp);
+    }
+    { // tables beyond the largest class stay in HBM
+        mp.list = ws.lists + (size_t)kNumBins * n;
+        mp.bin = kBinBig;
+        mp.wave_bytes = 0;
+        const size_t lds = model_lds + sizeof(MatchCtx);
+        match_kernel<G, false><<<dim3(ws.num_cu * 4), dim3(64), lds, stream>>>(mp);
+    }
+    HIPCHECK(hipGetLastError());
+    return PMX_OK;
+}
+
 static int next_pow2(int x) {
     int g = 1;
     while (g < x) g <<= 1;
@@ -589,6 +704,33 @@ extern "C" int pmx_score_multi(const pmx_model *const *models, int n_models, con
         if (models[i]->device != lib->device) return fail(PMX_ERR_INVALID, "model and library live on different devices");
     }
     if (first > lib->info.n_ligands || count > lib->info.n_ligands - first) return fail(PMX_ERR_INVALID, "ligand range out of bounds");
+    if (env_long("PMX_ENGINE", 2) == 2) {
+        g_stats = pmx_score_stats{};
+        if (count == 0 || n_models == 0) return PMX_OK;
+        HIPCHECK(hipSetDevice(lib->device));
+        Weights W;
+        for (int t = 0; t < PMX_NUM_TYPES; ++t) W.w[t] = weights[t];
+        hipStream_t stream = static_cast<hipStream_t>(stream_);
+        const int G = next_pow2(std::max(1, std::min(lib->info.max_conformers, PMX_MAX_CONFORMERS)));
+        FusedWs *ws = nullptr;
+        int rc = ensure_fused(lib->device, stream, count, &ws);
+        if (rc) return rc;
+        g_last_fused = ws;
+        for (int m = 0; m < n_models && rc == PMX_OK; ++m) {
+            float *sc = scores_dev + (size_t)m * count;
+            int32_t *st = m == 0 ? status_dev : nullptr;
+            switch (G) {
+            case 1: rc = score_fused<1>(models[m], lib, W, first, count, sc, st, stream, *ws); break;
+            case 2: rc = score_fused<2>(models[m], lib, W, first, count, sc, st, stream, *ws); break;
+            case 4: rc = score_fused<4>(models[m], lib, W, first, count, sc, st, stream, *ws); break;
+            case 8: rc = score_fused<8>(models[m], lib, W, first, count, sc, st, stream, *ws); break;
+            case 16: rc = score_fused<16>(models[m], lib, W, first, count, sc, st, stream, *ws); break;
+            case 32: rc = score_fused<32>(models[m], lib, W, first, count, sc, st, stream, *ws); break;
+            default: rc = score_fused<64>(models[m], lib, W, first, count, sc, st, stream, *ws); break;
+            }
+        }
+        return rc;
+    }
     std::lock_guard<std::mutex> lock(g_mu);
     g_stats = pmx_score_stats{};
     if (count == 0 || n_models == 0) return PMX_OK;
@@ -679,6 +821,18 @@ extern "C" int pmx_score(const pmx_model *model, const pmx_library *lib, const f
                          uint64_t count, float *scores_dev, int32_t *status_dev, void *stream) {
     if (!model) return fail(PMX_ERR_INVALID, "null argument");
     return pmx_score_multi(&model, 1, lib, weights, first, count, scores_dev, status_dev, stream);
+}
+
+static int fused_stats(pmx_score_stats *out) {
+    FusedWs *w = g_last_fused;
+    if (!w || !w->stats) return PMX_OK;
+    unsigned long long st[16];
+    HIPCHECK(hipStreamSynchronize(w->stream));
+    HIPCHECK(hipMemcpy(st, w->stats, sizeof(st), hipMemcpyDeviceToHost));
+    out->n_steps = st[0];
+    out->n_iters = st[1];
+    out->table_bytes = st[2];
+    return PMX_OK;
 }
 
 // error hook for pmx_topk.hip (keeps the thread-local message in one translation unit)
