@@ -61,6 +61,7 @@ struct pmx_model {
     int device;
     DevModel dm;
     void *blob;
+    uint8_t node_type[PMX_MAX_MODEL_NODES]; // host copy
 };
 
 // Largest float T with fl(T / std) < 2 under round-to-nearest-even float32 division: the quotient
@@ -89,7 +90,8 @@ extern "C" int pmx_model_create(const pmx_model_desc *d, int device, pmx_model *
     const size_t off_tclus = off_tnodes + 128 * 8;
     const size_t off_cpair = off_tclus + 128 * 8;
     const size_t off_clist = off_cpair + round16(n_pair * sizeof(float2));
-    const size_t total = off_clist + (size_t)std::max(K, 1) * 128 * 16 + 16;
+    const size_t off_olist = off_clist + (size_t)std::max(K, 1) * 128 * 16;
+    const size_t total = off_olist + (size_t)std::max(K, 1) * 128 * 32 + 16;
     std::vector<unsigned char> host(total, 0);
     float4 *edge = reinterpret_cast<float4 *>(host.data() + off_edge);
     uint8_t *ntype = host.data() + off_type;
@@ -135,6 +137,16 @@ extern "C" int pmx_model_create(const pmx_model_desc *d, int device, pmx_model *
                 if (nodes >> m & 1) e[q++] = (unsigned char)m;
         }
     for (int a = 0; a < K; ++a)
+        for (int mask = 0; mask < 128; ++mask) {
+            uint16_t *e = reinterpret_cast<uint16_t *>(host.data() + off_olist + ((size_t)a * 128 + mask) * 32);
+            const uint64_t nodes = cnodes[a] & tnodes[mask];
+            const int cnt = __builtin_popcountll(nodes);
+            e[0] = cnt > 12 ? (uint16_t)0xffff : (uint16_t)cnt;
+            int q = 1;
+            for (int m = 0; m < Nm && cnt <= 12; ++m)
+                if (nodes >> m & 1) e[q++] = (uint16_t)(m * 16);
+        }
+    for (int a = 0; a < K; ++a)
         for (int b = 0; b < K; ++b) {
             const double *ca = d->cluster_center + 3 * a, *cb = d->cluster_center + 3 * b;
             const double dist = std::sqrt((ca[0] - cb[0]) * (ca[0] - cb[0]) + (ca[1] - cb[1]) * (ca[1] - cb[1]) +
@@ -152,6 +164,7 @@ extern "C" int pmx_model_create(const pmx_model_desc *d, int device, pmx_model *
     pmx_model *m = new pmx_model();
     m->device = device;
     m->blob = blob;
+    std::memcpy(m->node_type, ntype, sizeof(m->node_type));
     unsigned char *b8 = static_cast<unsigned char *>(blob);
     m->dm.Nm = Nm;
     m->dm.K = K;
@@ -162,6 +175,7 @@ extern "C" int pmx_model_create(const pmx_model_desc *d, int device, pmx_model *
     m->dm.tclus = reinterpret_cast<const uint64_t *>(b8 + off_tclus);
     m->dm.cpair = reinterpret_cast<const float2 *>(b8 + off_cpair);
     m->dm.clist = reinterpret_cast<const uint4 *>(b8 + off_clist);
+    m->dm.olist = reinterpret_cast<const uint4 *>(b8 + off_olist);
     *out = m;
     return PMX_OK;
 }
@@ -586,10 +600,11 @@ struct FusedWs {
     uint32_t *lists = nullptr;
     uint64_t lists_cap = 0; // ligands per class list
     float4 *wtab = nullptr;
-    float *wsum = nullptr;
     unsigned long long *stats = nullptr;
     uint8_t *arena = nullptr;
     size_t arena_bytes = 0;
+    uint8_t *roots = nullptr;
+    size_t roots_bytes = 0;
     int num_cu = 0;
     uint32_t attr_set = 0;
     hipStream_t stream = nullptr; // the stream of the last call (stats are read after synchronising it)
@@ -610,10 +625,11 @@ static int ensure_fused(int device, hipStream_t stream, uint64_t count, FusedWs 
         HIPCHECK(hipMalloc((void **)&w->bins, sizeof(BinInfo)));
         HIPCHECK(hipMalloc((void **)&w->caps_dev, sizeof(uint32_t) * kNumBins));
         HIPCHECK(hipMalloc((void **)&w->wtab, (size_t)PMX_MAX_MODEL_NODES * PMX_MAX_MODEL_NODES * sizeof(float4)));
-        HIPCHECK(hipMalloc((void **)&w->wsum, (size_t)PMX_MAX_MODEL_CLUSTERS * 128 * sizeof(float)));
-        HIPCHECK(hipMalloc((void **)&w->stats, 16 * sizeof(unsigned long long)));
+        HIPCHECK(hipMalloc((void **)&w->stats, 128 * sizeof(unsigned long long)));
         w->arena_bytes = (size_t)std::max<long>(16, env_long("PMX_ARENA_MB", 1024)) << 20;
         HIPCHECK(hipMalloc((void **)&w->arena, w->arena_bytes));
+        w->roots_bytes = (size_t)std::max<long>(16, env_long("PMX_ROOTS_MB", 2048)) << 20;
+        HIPCHECK(hipMalloc((void **)&w->roots, w->roots_bytes));
     }
     if (w->lists_cap < count) {
         if (w->lists) {
@@ -622,7 +638,7 @@ static int ensure_fused(int device, hipStream_t stream, uint64_t count, FusedWs 
             w->lists = nullptr;
             w->lists_cap = 0;
         }
-        HIPCHECK(hipMalloc((void **)&w->lists, (size_t)(kNumBins + 1) * count * sizeof(uint32_t)));
+        HIPCHECK(hipMalloc((void **)&w->lists, (size_t)2 * (kNumBins + 1) * count * sizeof(uint32_t)));
         w->lists_cap = count;
     }
     w->stream = stream;
@@ -636,54 +652,82 @@ static int score_fused(const pmx_model *model, const pmx_library *lib, const Wei
     if (count > 0xfffffff0ull) return fail(PMX_ERR_INVALID, "more than 2^32 ligands in one call");
     const int Nm = model->dm.Nm, K = model->dm.K;
     const uint32_t n = (uint32_t)count;
-    const uint32_t model_lds = model_lds_bytes(Nm);
-    const uint32_t max_cap = ((uint32_t)kLdsPerCu - model_lds - 64u) & ~15u;
-    if (model_lds + sizeof(MatchCtx) + 1024 > kLdsPerCu) return fail(PMX_ERR_INVALID, "model tables do not fit LDS");
+    const uint32_t model_lds = model_lds_bytes(Nm, K);
+    constexpr uint32_t wave_state = (PMX_MAX_LEVELS + 1 + 43) * G * 8; // a helper wave's path totals + lookahead sums (typical ksumtot)
+    const uint32_t coop_fixed = model_lds + (uint32_t)sizeof(CoopShared);
+    if (coop_fixed + sizeof(MatchCtx) + 1024 > kLdsPerCu) return fail(PMX_ERR_INVALID, "model tables do not fit LDS");
+    const uint32_t max_cap = ((uint32_t)kLdsPerCu - coop_fixed - 64u) & ~15u;
     static const uint32_t kCaps[kNumBins] = {6144, 8192, 12288, 16384, 24576, 32768, 49152, 65536, 98304, 0xffffffffu};
     uint32_t caps[kNumBins];
     for (int b = 0; b < kNumBins; ++b) caps[b] = std::min(kCaps[b], max_cap);
     HIPCHECK(hipMemcpyAsync(ws.caps_dev, caps, sizeof(caps), hipMemcpyHostToDevice, stream));
+    // classes whose tables leave room for fewer than four ligands per CU are scored by whole blocks from the start
+    const uint32_t coop_kb = (uint32_t)std::max<long>(1, env_long("PMX_COOP_KB", 32));
+    uint32_t coop_from = kNumBins;
+    for (int b = kNumBins - 1; b >= 0; --b)
+        if (caps[b] >= coop_kb * 1024u) coop_from = (uint32_t)b;
     const uint32_t attr_bit = 1u << __builtin_ctz((unsigned)G);
     if (!(ws.attr_set & attr_bit)) {
         HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&match_kernel<G, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));
-        HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&match_kernel<G, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));
+        HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&coop_kernel<G, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));
+        HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&coop_kernel<G, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));
         ws.attr_set |= attr_bit;
     }
-    bins_init_kernel<<<dim3(1), dim3(64), 0, stream>>>(ws.bins, ws.caps_dev, ws.stats);
-    {
-        const int work = std::max(Nm * Nm, K * 128);
-        fold_weights_kernel<<<dim3((work + 255) / 256), dim3(256), 0, stream>>>(model->dm, W, ws.wtab, ws.wsum);
-    }
-    bin_kernel<G><<<dim3((n + 255) / 256), dim3(256), 0, stream>>>(lib->dl, model->dm.tclus, first, n, ws.bins, ws.lists, status_dev, scores_dev);
+    uint32_t *lists = ws.lists, *hlists = ws.lists + (size_t)(kNumBins + 1) * n;
+    bins_init_kernel<<<dim3(1), dim3(64), 0, stream>>>(ws.bins, ws.caps_dev, coop_from, ws.stats);
+    fold_weights_kernel<<<dim3((Nm * Nm + 255) / 256), dim3(256), 0, stream>>>(model->dm, W, ws.wtab);
+    bin_kernel<G><<<dim3((n + 255) / 256), dim3(256), 0, stream>>>(lib->dl, model->dm.tclus, first, n, ws.bins, lists, hlists, status_dev, scores_dev);
     HIPCHECK(hipGetLastError());
     MatchParams mp;
     mp.M = model->dm;
     mp.wtab = ws.wtab;
-    mp.wsum = ws.wsum;
+    mp.nzw = 0;
+    for (int m = 0; m < Nm; ++m)
+        if (W.w[model->node_type[m]] != 0.f) mp.nzw |= 1ull << m;
     mp.lib = lib->dl;
     mp.first = first;
     mp.bins = ws.bins;
     mp.arena = ws.arena;
     mp.arena_bytes = ws.arena_bytes;
+    mp.roots = ws.roots;
     mp.scores = scores_dev;
     mp.stats = ws.stats;
     mp.flags = (uint32_t)env_long("PMX_TREE_FLAGS", 0);
-    const int blocks_per_cu = (int)std::max<long>(1, env_long("PMX_BLOCKS_PER_CU", 1));
-    for (int b = kNumBins - 1; b >= 0; --b) { // the heaviest ligands first
+    mp.budget = (uint32_t)std::max<long>(16, env_long("PMX_BUDGET", 2048));
+    // one wavefront per ligand: the classes with small tables, largest first
+    for (int b = (int)coop_from - 1; b >= 0; --b) {
         if (b > 0 && caps[b] == caps[b - 1]) continue; // clamped duplicate: bin_kernel never fills it
         const uint32_t waves = std::max<uint32_t>(1, std::min<uint32_t>(16, ((uint32_t)kLdsPerCu - model_lds) / caps[b]));
-        mp.list = ws.lists + (size_t)b * n;
+        mp.list = lists + (size_t)b * n;
+        mp.hlist = hlists + (size_t)b * n;
         mp.bin = (uint32_t)b;
         mp.wave_bytes = caps[b];
+        mp.roots_cap = 0;
+        mp.pool_bytes = 0;
         const size_t lds = model_lds + (size_t)waves * caps[b];
-        match_kernel<G, true><<<dim3(ws.num_cu * blocks_per_cu), dim3(64 * waves), lds, stream>>>(mp);
+        match_kernel<G, true><<<dim3(ws.num_cu), dim3(64 * waves), lds, stream>>>(mp);
     }
-    { // tables beyond the largest class stay in HBM
-        mp.list = ws.lists + (size_t)kNumBins * n;
-        mp.bin = kBinBig;
-        mp.wave_bytes = 0;
-        const size_t lds = model_lds + sizeof(MatchCtx);
-        match_kernel<G, false><<<dim3(ws.num_cu * 4), dim3(64), lds, stream>>>(mp);
+    // one block per ligand: large tables, and the trees the wavefronts above gave up on
+    const uint32_t max_coop_waves = (uint32_t)std::max<long>(1, std::min<long>(16, env_long("PMX_COOP_WAVES", 8)));
+    for (int b = kNumBins; b >= 0; --b) {
+        const bool hbm = b == kNumBins;
+        if (!hbm && b > 0 && caps[b] == caps[b - 1]) continue;
+        const uint32_t cap = hbm ? (uint32_t)sizeof(MatchCtx) : caps[b];
+        const uint32_t room = (uint32_t)kLdsPerCu - model_lds - (uint32_t)sizeof(CoopShared) - cap;
+        const uint32_t waves = std::max<uint32_t>(1, std::min<uint32_t>(max_coop_waves, 1 + room / wave_state));
+        mp.pool_bytes = (waves - 1) * wave_state;
+        const size_t lds = model_lds + sizeof(CoopShared) + cap + mp.pool_bytes;
+        const uint32_t per_cu = std::max<uint32_t>(1, std::min<uint32_t>({(uint32_t)(kLdsPerCu / lds), 32u / waves, 8u}));
+        const uint32_t grid = (uint32_t)ws.num_cu * per_cu;
+        mp.list = nullptr;
+        mp.hlist = hlists + (size_t)b * n;
+        mp.bin = (uint32_t)b;
+        mp.wave_bytes = hbm ? 0u : caps[b];
+        mp.roots_cap = (uint32_t)std::min<size_t>(ws.roots_bytes / ((size_t)grid * root_bytes<G>()), 0x7fffffffu);
+        if (hbm)
+            coop_kernel<G, false><<<dim3(grid), dim3(64 * waves), lds, stream>>>(mp);
+        else
+            coop_kernel<G, true><<<dim3(grid), dim3(64 * waves), lds, stream>>>(mp);
     }
     HIPCHECK(hipGetLastError());
     return PMX_OK;
@@ -826,9 +870,20 @@ extern "C" int pmx_score(const pmx_model *model, const pmx_library *lib, const f
 static int fused_stats(pmx_score_stats *out) {
     FusedWs *w = g_last_fused;
     if (!w || !w->stats) return PMX_OK;
-    unsigned long long st[16];
+    unsigned long long st[128];
     HIPCHECK(hipStreamSynchronize(w->stream));
     HIPCHECK(hipMemcpy(st, w->stats, sizeof(st), hipMemcpyDeviceToHost));
+    if (trace_on()) {
+        fprintf(stderr, "[pmx] steps %llu batches %llu wave-terms %llu max steps/ligand %llu\n", st[0], st[1], st[2], st[3]);
+        for (int b = 0; b < 12; ++b)
+            fprintf(stderr, "[pmx]   steps in [4^%d,4^%d): %llu ligands, %llu steps, %llu of them at frames with < 4 matches\n", b, b + 1, st[4 + b], st[16 + b], st[32 + b]);
+        fprintf(stderr, "[pmx] steps walked by cooperating blocks: %llu\n", st[74]);
+        fprintf(stderr, "[pmx] wave cycles: tables %llu walk %llu | setup %llu batches %llu finish %llu bounds %llu\n", st[44], st[45], st[70], st[71], st[72], st[73]);
+        for (int b = 0; b <= kNumBins; ++b)
+            fprintf(stderr, "[pmx]   class %d: tables %llu walk %llu | wave-terms %llu steps %llu batches %llu batch cycles %llu -> %.1f cycles/wave-term %.1f cycles/step\n", b,
+                    st[46 + 2 * b], st[47 + 2 * b], st[80 + 4 * b], st[81 + 4 * b], st[82 + 4 * b], st[83 + 4 * b],
+                    (double)st[83 + 4 * b] / (double)std::max<unsigned long long>(st[80 + 4 * b], 1), (double)st[47 + 2 * b] / (double)std::max<unsigned long long>(st[81 + 4 * b], 1));
+    }
     out->n_steps = st[0];
     out->n_iters = st[1];
     out->table_bytes = st[2];

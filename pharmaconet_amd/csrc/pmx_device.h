@@ -25,6 +25,9 @@ struct DevModel {
     // [K * 128] nodes of cluster a compatible with ligand type mask t, as a list: byte 0 = count (0xff: more than
     // 12, use the masks), bytes 1..12 = node numbers ascending (the reference's order, graph_match.py:148-150)
     const uint4 *clist;
+    // [K * 128][2] the same lists as 16-bit byte offsets into a row of the staged edge table (node * 16): word 0 = count
+    // (0xffff: more than 12), words 1..12 = offsets ascending
+    const uint4 *olist;
 };
 
 struct DevLibrary {
