@@ -653,7 +653,7 @@ static int score_fused(const pmx_model *model, const pmx_library *lib, const Wei
     const int Nm = model->dm.Nm, K = model->dm.K;
     const uint32_t n = (uint32_t)count;
     const uint32_t model_lds = model_lds_bytes(Nm, K);
-    constexpr uint32_t wave_state = (PMX_MAX_LEVELS + 1 + 43) * G * 8; // a helper wave's path totals + lookahead sums (typical ksumtot)
+    constexpr uint32_t wave_state = std::max<uint32_t>(1024, (PMX_MAX_LEVELS + 1 + 43) * G * 8); // a helper wave's build buffers, then its path totals + lookahead sums (typical ksumtot)
     const uint32_t coop_fixed = model_lds + (uint32_t)sizeof(CoopShared);
     if (coop_fixed + sizeof(MatchCtx) + 1024 > kLdsPerCu) return fail(PMX_ERR_INVALID, "model tables do not fit LDS");
     const uint32_t max_cap = ((uint32_t)kLdsPerCu - coop_fixed - 64u) & ~15u;
@@ -694,6 +694,13 @@ static int score_fused(const pmx_model *model, const pmx_library *lib, const Wei
     mp.stats = ws.stats;
     mp.flags = (uint32_t)env_long("PMX_TREE_FLAGS", 0);
     mp.budget = (uint32_t)std::max<long>(16, env_long("PMX_BUDGET", 2048));
+    mp.seed_mode = (int)env_long("PMX_SEED_BEST", 0);
+    mp.seed = nullptr;
+    if (mp.seed_mode) {
+        static double *seedbuf = nullptr;
+        if (!seedbuf) HIPCHECK(hipMalloc((void **)&seedbuf, (size_t)n * G * 8));
+        mp.seed = seedbuf;
+    }
     // one wavefront per ligand: the classes with small tables, largest first
     for (int b = (int)coop_from - 1; b >= 0; --b) {
         if (b > 0 && caps[b] == caps[b - 1]) continue; // clamped duplicate: bin_kernel never fills it
@@ -878,6 +885,8 @@ static int fused_stats(pmx_score_stats *out) {
         for (int b = 0; b < 12; ++b)
             fprintf(stderr, "[pmx]   steps in [4^%d,4^%d): %llu ligands, %llu steps, %llu of them at frames with < 4 matches\n", b, b + 1, st[4 + b], st[16 + b], st[32 + b]);
         fprintf(stderr, "[pmx] steps walked by cooperating blocks: %llu\n", st[74]);
+        fprintf(stderr, "[pmx] coop blocks: %llu ligands; block cycles setup %llu build %llu finish+bounds %llu top %llu subtrees %llu; roots %llu (max %llu) overflowed ligands %llu\n",
+                st[107], st[100], st[101], st[102], st[103], st[104], st[105], st[108], st[106]);
         fprintf(stderr, "[pmx] wave cycles: tables %llu walk %llu | setup %llu batches %llu finish %llu bounds %llu\n", st[44], st[45], st[70], st[71], st[72], st[73]);
         for (int b = 0; b <= kNumBins; ++b)
             fprintf(stderr, "[pmx]   class %d: tables %llu walk %llu | wave-terms %llu steps %llu batches %llu batch cycles %llu -> %.1f cycles/wave-term %.1f cycles/step\n", b,

@@ -117,6 +117,8 @@ struct MatchParams {
     uint32_t roots_cap;  // roots per block
     uint32_t budget;     // match_kernel: tree steps after which a ligand is passed on to coop_kernel
     uint32_t pool_bytes; // coop_kernel: LDS behind the tables for the helper waves' walk state
+    double *seed;        // experiment (PMX_SEED_BEST): per-conformer maxima of a previous pass [count][G]; mode 1 = record, 2 = seed
+    int seed_mode;
     float *scores;
     unsigned long long *stats; // [0] tree steps [1] pairs batches [2] lane-terms / 64 (diagnostics)
     uint32_t flags;      // 4: no bound test
@@ -269,6 +271,10 @@ struct Matcher {
     bool lane_live;
     uint32_t T, ksumtot;
     int Nm;
+    uint16_t *pairbuf;      // this wave's pair buffer and column lists (its own copies when several waves build one ligand)
+    uint4 *lists;
+    uint32_t cur_li = 0;
+    int bw = 0, bn = 1;     // this wave takes the table entries (x, y) with (x * kJ + y) % bn == bw
     unsigned long long n_steps = 0, n_batches = 0, n_terms = 0, n_top = 0, cyc_tab = 0, cyc_walk = 0, cyc_setup = 0, cyc_batch = 0, cyc_finish = 0, cyc_bounds = 0;
 
     __device__ Matcher(const MatchParams &p_, const float4 *tab_, const uint64_t *cn_, const uint64_t *tn_, const float2 *cp_, unsigned char *ctx)
@@ -278,6 +284,8 @@ struct Matcher {
         int m = 0;
         for (int t = 0; t < PMX_NUM_TYPES; ++t) m |= (int)((p_.M.tclus[1 << t] >> lane) & 1ull) << t;
         ctm = lane < p_.M.K ? m : 0;
+        pairbuf = X.pairbuf;
+        lists = X.lists;
     }
 
     __device__ __forceinline__ void lds_sync() {
@@ -295,6 +303,7 @@ struct Matcher {
     // level scan (graph_match.py:124-137, :87-88) then runs on registers.
     __device__ bool setup(uint32_t li, unsigned char *tables) {
         r = parse_record(p.lib.data + p.lib.offsets[p.first + li]);
+        cur_li = li;
         r.n = uni(r.n);
         r.C = uni(r.C);
         r.ncl = uni(r.ncl);
@@ -387,6 +396,7 @@ struct Matcher {
         const uint32_t p_bytes = (uint32_t)round16(uint64_t(T) * G * 4), s_bytes = (uint32_t)round16(uint64_t(ksumtot) * G * 4);
         Pt = reinterpret_cast<float *>(tables);
         St = reinterpret_cast<float *>(tables + p_bytes);
+        Ft = reinterpret_cast<uint32_t *>(tables + p_bytes + s_bytes);
         Rt = reinterpret_cast<double *>(tables + p_bytes + s_bytes);
         Tt = own_tt;
         La = Tt + (size_t)(nl + 1) * G;
@@ -426,8 +436,8 @@ struct Matcher {
     // `slot` = position of the column cluster among its level's candidates (its list is staged in LDS when < kListSlots)
     template <bool PASS>
     __device__ __forceinline__ void rows_any(uint64_t A, uint64_t B, int slot, int list, const float d, float &acc, unsigned &np) const {
-        const uint4 l0 = slot < kListSlots ? X.lists[2 * slot] : p.M.olist[2 * list];
-        const uint4 l1 = slot < kListSlots ? X.lists[2 * slot + 1] : p.M.olist[2 * list + 1];
+        const uint4 l0 = slot < kListSlots ? lists[2 * slot] : p.M.olist[2 * list];
+        const uint4 l1 = slot < kListSlots ? lists[2 * slot + 1] : p.M.olist[2 * list + 1];
         const uint4 u0 = make_uint4((uint32_t)uni((int)l0.x), (uint32_t)uni((int)l0.y), (uint32_t)uni((int)l0.z), (uint32_t)uni((int)l0.w));
         const uint4 u1 = make_uint4((uint32_t)uni((int)l1.x), (uint32_t)uni((int)l1.y), (uint32_t)uni((int)l1.z), (uint32_t)uni((int)l1.w));
         switch ((int)(u0.x & 0xffffu)) {
@@ -452,7 +462,7 @@ struct Matcher {
     // scoring_matching_pair's inner loops (match_utils.py:26-69) for this lane's (u, v, conformer)
     __device__ void pair_batch(int b0, int cnt, float d, uint64_t cand1, int t1, uint64_t cand2, int t2) {
         const bool act = s < cnt;
-        const int pr = X.pairbuf[b0 + (act ? s : 0)];
+        const int pr = pairbuf[b0 + (act ? s : 0)];
         const int u = pr & 255, v = pr >> 8;
         const int i = X.nodelevel[u], j = X.nodelevel[v];
         const int kI = __popcll(cand1), kJ = __popcll(cand2);
@@ -471,6 +481,7 @@ struct Matcher {
                 const int b = __ffsll((unsigned long long)bm) - 1;
                 const uint64_t B = uni64(cnodes[b]) & T2;
                 if (!B) continue;
+                if (bn > 1 && (x * kJ + y) % bn != bw) continue; // another wave of the block builds this entry
                 float acc = 0.f;
                 unsigned np = 0u;
                 rows_any<true>(A, B, y, b * 128 + t2, d, acc, np);
@@ -487,7 +498,7 @@ struct Matcher {
     // (scoring_matching_self, match_utils.py:87-120)
     __device__ void self_batch(int b0, int cnt, float d, uint64_t cand1, int t1, int t2) {
         const bool act = s < cnt;
-        const int pr = X.pairbuf[b0 + (act ? s : 0)];
+        const int pr = pairbuf[b0 + (act ? s : 0)];
         const int u = pr & 255;
         const int i = X.nodelevel[u];
         const uint32_t sbase = X.ksum[i];
@@ -500,6 +511,7 @@ struct Matcher {
             const uint64_t ca = uni64(cnodes[a]);
             const uint64_t A = ca & T1, B = ca & T2;
             if (!A || !B) continue;
+            if (bn > 1 && x % bn != bw) continue;
             float acc = 0.f;
             unsigned dummy = 0u;
             rows_any<false>(A, B, x, a * 128 + t2, d, acc, dummy);
@@ -514,7 +526,7 @@ struct Matcher {
     // distance of the pair this lane takes in the batch starting at b0 (garbage but harmless for lanes beyond the batch)
     __device__ __forceinline__ float batch_dist(int b0, int npairs) const {
         const int idx = b0 + s < npairs ? b0 + s : b0;
-        const int pr = X.pairbuf[idx];
+        const int pr = pairbuf[idx];
         return dist(pr & 255, pr >> 8);
     }
     template <typename F>
@@ -533,9 +545,9 @@ struct Matcher {
         }
         const int rest = npairs - done;
         if (done && rest) {
-            const int tmp = lane < rest ? (int)X.pairbuf[done + lane] : 0;
+            const int tmp = lane < rest ? (int)pairbuf[done + lane] : 0;
             lds_sync();
-            if (lane < rest) X.pairbuf[lane] = (uint16_t)tmp;
+            if (lane < rest) pairbuf[lane] = (uint16_t)tmp;
             lds_sync();
         }
         npairs = rest;
@@ -573,7 +585,7 @@ struct Matcher {
                     const int y = lane >> 1;
                     uint64_t bm = cand2;
                     for (int q = 0; q < y && bm; ++q) bm &= bm - 1;
-                    if (y < kListSlots && bm) X.lists[lane] = p.M.olist[2 * ((__ffsll((unsigned long long)bm) - 1) * 128 + t2) + (lane & 1)];
+                    if (y < kListSlots && bm) lists[lane] = p.M.olist[2 * ((__ffsll((unsigned long long)bm) - 1) * 128 + t2) + (lane & 1)];
                     lds_sync();
                 }
                 // pairs across ligand clusters: u in g1, v in g2 in a later cluster (match_utils.py:26-31 via graph_match.py:233-279)
@@ -584,7 +596,7 @@ struct Matcher {
                     const unsigned long long vm = endu >= 64 ? 0ull : (g2 & (~0ull << endu));
                     if (!vm) continue;
                     if (npairs + 64 > kPairBuf) run_batches(npairs, false, [&](int b0, int cnt, float d) { pair_batch(b0, cnt, d, cand1, t1, cand2, t2); });
-                    if ((vm >> lane) & 1) X.pairbuf[npairs + __popcll(vm & lt)] = (uint16_t)(u | (lane << 8));
+                    if ((vm >> lane) & 1) pairbuf[npairs + __popcll(vm & lt)] = (uint16_t)(u | (lane << 8));
                     npairs += __popcll(vm);
                 }
                 if (npairs) run_batches(npairs, true, [&](int b0, int cnt, float d) { pair_batch(b0, cnt, d, cand1, t1, cand2, t2); });
@@ -598,7 +610,7 @@ struct Matcher {
                         const unsigned long long vm = g2 & inlevel;
                         if (!vm) continue;
                         if (npairs + 64 > kPairBuf) run_batches(npairs, false, [&](int b0, int cnt, float d) { self_batch(b0, cnt, d, cand1, t1, t2); });
-                        if ((vm >> lane) & 1) X.pairbuf[npairs + __popcll(vm & lt)] = (uint16_t)(u | (lane << 8));
+                        if ((vm >> lane) & 1) pairbuf[npairs + __popcll(vm & lt)] = (uint16_t)(u | (lane << 8));
                         npairs += __popcll(vm);
                     }
                     if (npairs) run_batches(npairs, true, [&](int b0, int cnt, float d) { self_batch(b0, cnt, d, cand1, t1, t2); });
@@ -606,9 +618,11 @@ struct Matcher {
             }
         }
         lds_sync();
-        const unsigned long long tf0 = __builtin_amdgcn_s_memtime();
-        finish_tables();
-        cyc_finish += __builtin_amdgcn_s_memtime() - tf0;
+        if (bn == 1) {
+            const unsigned long long tf0 = __builtin_amdgcn_s_memtime();
+            finish_tables();
+            cyc_finish += __builtin_amdgcn_s_memtime() - tf0;
+        }
     }
 
     // ---- cluster-distance prefilter (graph_match.py:263-268) and the fail rule (match_utils.py:71-74) turn the
@@ -757,48 +771,46 @@ struct Matcher {
     }
 
     // Enter frame F: a node with nm matches, conformer mask `alive` and totals t, whose ancestors are those the lookahead
-    // of level F was computed for plus, if prow >= 0, the match whose pair-table row for level F starts at entry prow.
+    // of level F was computed for plus, if has_row, the match whose pair-table row for level F starts at entry prow.
     // Candidates that exist -> E; those worth entering -> todo (all of E while nm < 4; with nm >= 4 those whose subtree can
     // still raise a maximum - the others count as children that returned 1). A frame whose children are leaves is
-    // finished here: returns true and its return value (tree.py:102).
-    __device__ __forceinline__ bool enter(Walk &w, int F, int nm, unsigned long long alive, double t, int prow, bool matched, int &ret) {
+    // finished here: returns true and its return value (tree.py:102). Written without branches around the loads: the
+    // common case (at most NP candidates) is one straight line.
+    __device__ __forceinline__ bool enter(Walk &w, const int F, const int nm, const unsigned long long alive, const double t, const int prow,
+                                          const bool has_row, const bool matched, int &ret) {
         const int kF = lane_get(w.lv_k, F), ksF = lane_get(w.lv_ks, F);
-        const bool leaves = F == nl - 1, totals = leaves || nm >= 4;
+        const bool leaves = F == nl - 1;
         const double before = w.best;
-        const double rb = (totals && !leaves) ? Rt[(size_t)(F + 1) * G + c] : 0.0;
+        const double rb = Rt[(size_t)(F + 1) * G + c]; // row nl of R is 0
+        const bool mine = (alive >> c) & 1;
         unsigned long long E = 0, L = 0;
         for (int b0 = 0; b0 < kF; b0 += NP) {
             const bool on = b0 + s < kF;
             const int off = on ? b0 * G + lane : c;
             const double la = La[ksF * G + off];
-            const float pn = prow >= 0 ? Pt[prow * G + off] : 1.f;
-            const float self = totals ? St[ksF * G + off] : 0.f;
-            const bool ok = on && ((alive >> c) & 1) && (la == la) && (pn > 0.f);
-            const unsigned long long e = any_per_candidate(ok);
-            E |= e << b0;
-            if (!totals) {
-                L |= e << b0;
-                continue;
-            }
-            const double pair = prow >= 0 ? la + (double)pn : la;
-            const double tc = t + (double)self + pair; // tree.py:38-41
+            const float pn = Pt[prow * G + off];
+            const float self = St[ksF * G + off];
+            const float pnv = has_row ? pn : 1.f;
+            const bool ok = on && mine && (la == la) && (pnv > 0.f);
+            const double tc = t + (double)self + (la + (double)(has_row ? pn : 0.f)); // tree.py:38-41
+            E |= any_per_candidate(ok) << b0;
             if (leaves) { // per-conformer maximum over leaves (graph_match.py:105-108)
-                if (ok && tc > w.best) w.best = tc;
+                w.best = (ok && tc > w.best) ? tc : w.best;
             } else {
                 L |= any_per_candidate(ok && (tc + rb) * kBoundSlack > w.best) << b0;
             }
         }
         if (leaves) {
             const int mx = E ? 1 : 0;
-            if (!E || nm + mx < 5) { // the skip leaf carries this node's totals (tree.py:98-101, :42-43)
-                if (((alive >> c) & 1) && t > w.best) w.best = t;
-            }
+            if (!E || nm + mx < 5) w.best = (mine && t > w.best) ? t : w.best; // the skip leaf carries this node's totals (tree.py:98-101, :42-43)
             if (NP > 1 && __ballot(w.best > before)) pool_best(w);
             ret = mx + (matched ? 1 : 0);
             return true;
         }
+        if (nm < 4) L = E;
         lane_set(w.fr_lo, F, (int)(uint32_t)L);
         lane_set(w.fr_hi, F, (int)(uint32_t)(L >> 32));
+        // candidates dropped by the bound test count as children that returned 1 (their subtrees hold >= 5 matches)
         lane_set(w.fr_info, F, (nm << 16) | (matched ? F_MATCHED : 0) | (E ? F_ANY : 0) | ((E & ~L) ? 1 : 0));
         return false;
     }
@@ -820,90 +832,86 @@ struct Matcher {
         for (;;) {
             ++n_steps;
             if (MODE == WALK_PLAIN && budget-- == 0) return false;
-            int info = lane_get(w.fr_info, f);
+            const int info = lane_get(w.fr_info, f);
             const unsigned long long todo = (unsigned long long)(uint32_t)lane_get(w.fr_lo, f) | ((unsigned long long)(uint32_t)lane_get(w.fr_hi, f) << 32);
             const int nm = (info >> 16) & 255;
-            if (nm < 4) ++n_top;
+            const int mx = info & 255;
             const unsigned long long alive =
                 (unsigned long long)(uint32_t)lane_get(w.al_lo, nm) | ((unsigned long long)(uint32_t)lane_get(w.al_hi, nm) << 32);
             const int F = f + 1;
-            if (todo || (!(info & F_SKIP) && (!(info & F_ANY) || nm + (info & 255) < 5))) {
-                if (!(info & F_LA)) { // this frame's lookahead onto level F, once
-                    lookahead(w, F, nm);
-                    info |= F_LA;
-                    lane_set(w.fr_info, f, info);
-                    lds_sync();
-                }
-            }
-            if (todo) { // next candidate child (tree.py:94-97)
-                const int b = __ffsll(todo) - 1;
-                const unsigned long long left = todo & (todo - 1);
-                lane_set(w.fr_lo, f, (int)(uint32_t)left);
-                lane_set(w.fr_hi, f, (int)(uint32_t)(left >> 32));
-                const int kf = lane_get(w.lv_k, f), ksf = lane_get(w.lv_ks, f), kF = lane_get(w.lv_k, F), ksF = lane_get(w.lv_ks, F);
-                const int rowf = lane_get(w.lv_row, f);
-                // the child's total and conformer mask: parent + self + accumulated pair (tree.py:38-41, :78-82); all lanes
-                // of a conformer compute it redundantly: the parent frame's lookahead onto level f, plus - when this frame's
-                // node is itself a match - that match's row
-                const int offf = (ksf + b) * G + c;
-                const double la = La[offf];
-                float pm = 1.f;
-                if (info & F_MATCHED) {
-                    const int q = nm - 1;
-                    const int eb = lane_get(w.mt_base, q) + (lane_get(w.mt_ka, q) & 255) * ksf + ((lane_get(w.mt_ka, q) >> 8) & 255) * kf;
-                    pm = Pt[(eb + b) * G + c];
-                }
-                const double tpar = Tt[(size_t)nm * G + c];
-                const float selff = St[offf];
-                const double rbf = Rt[(size_t)F * G + c];
-                const bool okf = ((alive >> c) & 1) && (la == la) && (pm > 0.f);
-                const double pairf = (info & F_MATCHED) ? la + (double)pm : la;
-                const double t = tpar + (double)selff + pairf;
-                const unsigned long long bal = __ballot(okf);
-                const unsigned long long cmask = (G == 64) ? bal : (bal & ((1ull << G) - 1ull));
-                if (nm >= 4) { // the child holds >= 5 matches: dropping its subtree cannot change a skip decision
-                    if (!__ballot(okf && (t + rbf) * kBoundSlack > w.best)) { // the maxima may have grown since the frame was entered
-                        if ((info & 255) < 1) lane_set(w.fr_info, f, (info & ~255) | 1);
-                        continue;
-                    }
-                    if (MODE == WALK_COLLECT && nm == 4 && sink(f, b, cmask, t, w)) { // given away: it returns at least 1
-                        if ((info & 255) < 1) lane_set(w.fr_info, f, (info & ~255) | 1);
-                        continue;
-                    }
-                }
-                // descend
-                if (s == 0) Tt[(size_t)(nm + 1) * G + c] = t;
-                lane_set(w.al_lo, nm + 1, (int)(uint32_t)cmask);
-                lane_set(w.al_hi, nm + 1, (int)(uint32_t)(cmask >> 32));
-                lane_set(w.mt_base, nm, rowf - kf * ksF); // ksum[f + 1] = ksum[F]
-                lane_set(w.mt_ka, nm, kf | (b << 8) | (f << 16));
-                int r1 = 0;
-                if (enter(w, F, nm + 1, cmask, t, rowf + b * kF, true, r1)) {
-                    if (r1 > (info & 255)) lane_set(w.fr_info, f, (info & ~255) | r1);
-                } else {
-                    f = F;
-                }
+            const bool skip = !todo && !(info & F_SKIP) && (!(info & F_ANY) || nm + mx < 5); // tree.py:98-101
+            if (!todo && !skip) { // all children done: return max_num_matches + matched (tree.py:102)
+                const int r1 = mx + ((info & F_MATCHED) ? 1 : 0);
+                if (f == f0) return true;
+                --f;
+                const int pinfo = lane_get(w.fr_info, f);
+                if (r1 > (pinfo & 255)) lane_set(w.fr_info, f, (pinfo & ~255) | r1);
                 continue;
             }
-            const int mx = info & 255;
-            if (!(info & F_SKIP) && (!(info & F_ANY) || nm + mx < 5)) { // skip child (tree.py:98-101)
-                info |= F_SKIP;
-                lane_set(w.fr_info, f, info);
+            if (!(info & F_LA)) { // this frame's lookahead onto level F, once
+                lookahead(w, F, nm);
+                lds_sync();
+            }
+            int newinfo = info | F_LA | (skip ? F_SKIP : 0);
+            if (skip) { // skip child: same matches, same conformers, same totals
                 const double t = Tt[(size_t)nm * G + c];
                 int r1 = 0;
-                if (enter(w, F, nm, alive, t, -1, false, r1)) {
-                    if (r1 > mx) lane_set(w.fr_info, f, (info & ~255) | r1);
+                if (enter(w, F, nm, alive, t, 0, false, false, r1)) {
+                    if (r1 > mx) newinfo = (newinfo & ~255) | r1;
+                    lane_set(w.fr_info, f, newinfo);
                 } else {
+                    lane_set(w.fr_info, f, newinfo);
                     f = F;
                 }
                 continue;
             }
-            // all children done: return max_num_matches + matched (tree.py:102)
-            const int r1 = mx + ((info & F_MATCHED) ? 1 : 0);
-            if (f == f0) return true;
-            --f;
-            const int pinfo = lane_get(w.fr_info, f);
-            if (r1 > (pinfo & 255)) lane_set(w.fr_info, f, (pinfo & ~255) | r1);
+            // next candidate child (tree.py:94-97)
+            const int b = __ffsll(todo) - 1;
+            const unsigned long long left = todo & (todo - 1);
+            lane_set(w.fr_lo, f, (int)(uint32_t)left);
+            lane_set(w.fr_hi, f, (int)(uint32_t)(left >> 32));
+            const int kf = lane_get(w.lv_k, f), ksf = lane_get(w.lv_ks, f), kF = lane_get(w.lv_k, F), ksF = lane_get(w.lv_ks, F);
+            const int rowf = lane_get(w.lv_row, f);
+            // the child's total and conformer mask: parent + self + accumulated pair (tree.py:38-41, :78-82); all lanes of a
+            // conformer compute it redundantly: the parent frame's lookahead onto level f, plus - when this frame's node is
+            // itself a match - that match's row
+            const bool fm = (info & F_MATCHED) != 0;
+            const int qm = nm > 0 ? nm - 1 : 0;
+            const int ka = lane_get(w.mt_ka, qm);
+            const int eb = fm ? lane_get(w.mt_base, qm) + (ka & 255) * ksf + ((ka >> 8) & 255) * kf : 0;
+            const int offf = (ksf + b) * G + c;
+            const double la = La[offf];
+            const float pm = Pt[(eb + b) * G + c];
+            const double tpar = Tt[(size_t)nm * G + c];
+            const float selff = St[offf];
+            const double rbf = Rt[(size_t)F * G + c];
+            const bool okf = ((alive >> c) & 1) && (la == la) && ((fm ? pm : 1.f) > 0.f);
+            const double t = tpar + (double)selff + (la + (double)(fm ? pm : 0.f));
+            const unsigned long long bal = __ballot(okf);
+            const unsigned long long cmask = (G == 64) ? bal : (bal & ((1ull << G) - 1ull));
+            if (nm >= 4) { // the child holds >= 5 matches: dropping its subtree cannot change a skip decision
+                bool gone = !__ballot(okf && (t + rbf) * kBoundSlack > w.best); // the maxima may have grown since the frame was entered
+                if (MODE == WALK_COLLECT && !gone && nm == 4) gone = sink(f, b, cmask, t, w); // given away: it returns at least 1
+                if (gone) {
+                    if (mx < 1) newinfo = (newinfo & ~255) | 1;
+                    lane_set(w.fr_info, f, newinfo);
+                    continue;
+                }
+            }
+            // descend
+            if (s == 0) Tt[(size_t)(nm + 1) * G + c] = t;
+            lane_set(w.al_lo, nm + 1, (int)(uint32_t)cmask);
+            lane_set(w.al_hi, nm + 1, (int)(uint32_t)(cmask >> 32));
+            lane_set(w.mt_base, nm, rowf - kf * ksF); // ksum[f + 1] = ksum[F]
+            lane_set(w.mt_ka, nm, kf | (b << 8) | (f << 16));
+            int r1 = 0;
+            if (enter(w, F, nm + 1, cmask, t, rowf + b * kF, true, true, r1)) {
+                if (r1 > mx) newinfo = (newinfo & ~255) | r1;
+                lane_set(w.fr_info, f, newinfo);
+            } else {
+                lane_set(w.fr_info, f, newinfo);
+                f = F;
+            }
         }
     }
 
@@ -925,11 +933,13 @@ struct Matcher {
         if (s == 0) Tt[c] = 0.0;
         lookahead(w, 0, 0); // no ancestors: zeros
         lds_sync();
+        if (p.seed_mode == 2) w.best = p.seed[(size_t)cur_li * G + c] * (1.0 - 1e-7);
         int ret = 0;
-        if (!enter(w, 0, 0, allc, 0.0, -1, false, ret)) {
+        if (!enter(w, 0, 0, allc, 0.0, 0, false, false, ret)) {
             if (!walk_loop<WALK_PLAIN>(w, 0, budget, [](int, int, unsigned long long, double, Walk &) { return false; })) return false;
         }
         pool_best(w);
+        if (p.seed_mode == 1 && s == 0) p.seed[(size_t)cur_li * G + c] = w.best;
         score = mean_score(w.best);
         return true;
     }
@@ -947,7 +957,7 @@ struct Matcher {
         lds_sync();
         uint32_t nroots = 0;
         int ret = 0;
-        if (!enter(w, 0, 0, allc, 0.0, -1, false, ret)) {
+        if (!enter(w, 0, 0, allc, 0.0, 0, false, false, ret)) {
             (void)walk_loop<WALK_COLLECT>(w, 0, 0, [&](int f, int b, unsigned long long cmask, double t, Walk &ww) -> bool {
                 if (nroots >= roots_cap) {
                     S.overflow = 1;
@@ -1010,7 +1020,7 @@ struct Matcher {
             int ret = 0;
             const int jr = uni((int)rh->path[2 * (nm0 - 1)]), ar = uni((int)rh->path[2 * (nm0 - 1) + 1]);
             const int prow = (int)X.rowbase[jr] + ar * (int)X.lk[f0]; // rowbase[j] + a * k[j + 1], j + 1 = f0
-            if (!enter(w, f0, nm0, mask, t, uni(prow), true, ret))
+            if (!enter(w, f0, nm0, mask, t, uni(prow), true, true, ret))
                 (void)walk_loop<WALK_PLAIN>(w, f0, ~0ull, [](int, int, unsigned long long, double, Walk &) { return false; });
             pool_best(w);
             if (s == 0 && w.best > before) atomicMax(&S.best[c], (unsigned long long)__double_as_longlong(w.best));
@@ -1141,25 +1151,44 @@ __global__ __launch_bounds__(1024) void coop_kernel(const MatchParams p) {
         const uint32_t pos = S.item;
         if (pos >= count) break;
         const uint32_t li = p.hlist[pos];
+        const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+        // helper waves keep their pair buffer / column lists (build) and later their walk state in a pool behind the tables
+        const uint32_t helper_bytes = nwaves > 1 ? p.pool_bytes / (uint32_t)(nwaves - 1) : 0u;
+        unsigned char *own = reinterpret_cast<unsigned char *>(pool) + (size_t)(wave > 0 ? wave - 1 : 0) * helper_bytes;
         if (wave == 0) {
             const bool has_tree = mt.setup(li, tables);
-            if (has_tree) {
-                mt.build_tables();
-                mt.build_bounds();
-                if (lane == 0) {
-                    mt.X.meta[0] = (uint32_t)mt.nl;
-                    mt.X.meta[1] = mt.T;
-                    mt.X.meta[2] = mt.ksumtot;
-                    S.has_tree = 1;
-                }
-                mt.coop_top(S, roots, p.roots_cap);
-                __threadfence_block();
-            } else if (lane == 0) {
-                p.scores[li] = 0.f;
+            if (lane == 0) {
+                mt.X.meta[0] = (uint32_t)mt.nl;
+                mt.X.meta[1] = mt.T;
+                mt.X.meta[2] = mt.ksumtot;
+                S.has_tree = has_tree ? 1u : 0u;
+                if (!has_tree) p.scores[li] = 0.f;
             }
         }
         __syncthreads();
         if (!S.has_tree) continue;
+        const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+        // every wave builds its share of the table entries (disjoint entries: the sums do not depend on the number of waves)
+        mt.bn = nwaves;
+        mt.bw = wave;
+        if (wave != 0) {
+            mt.attach(li, tables, reinterpret_cast<double *>(own));
+            mt.pairbuf = reinterpret_cast<uint16_t *>(own);
+            mt.lists = reinterpret_cast<uint4 *>(own + 2 * kPairBuf);
+        }
+        mt.build_tables();
+        __syncthreads();
+        const unsigned long long c2 = __builtin_amdgcn_s_memtime();
+        unsigned long long c3 = c2;
+        if (wave == 0) {
+            mt.finish_tables();
+            mt.build_bounds();
+            c3 = __builtin_amdgcn_s_memtime();
+            mt.coop_top(S, roots, p.roots_cap);
+            __threadfence_block();
+        }
+        __syncthreads();
+        const unsigned long long c4 = __builtin_amdgcn_s_memtime();
         bool takes_part = true;
         if (wave != 0) {
             const uint32_t need = (mt.X.meta[0] + 1 + mt.X.meta[2]) * G; // doubles: (nl + 1 + ksumtot) * G
@@ -1168,6 +1197,19 @@ __global__ __launch_bounds__(1024) void coop_kernel(const MatchParams p) {
         }
         if (takes_part) mt.coop_subtrees(S, roots);
         __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned long long c5 = __builtin_amdgcn_s_memtime();
+            atomicAdd(&p.stats[100], c1 - c0);
+            atomicAdd(&p.stats[101], c2 - c1);
+            atomicAdd(&p.stats[102], c3 - c2);
+            atomicAdd(&p.stats[103], c4 - c3);
+            atomicAdd(&p.stats[104], c5 - c4);
+            atomicAdd(&p.stats[105], (unsigned long long)S.nroots);
+            atomicAdd(&p.stats[106], (unsigned long long)S.overflow);
+            atomicAdd(&p.stats[107], 1ull);
+            atomicMax(&p.stats[108], (unsigned long long)S.nroots);
+            S.overflow = 0;
+        }
         if (wave == 0) {
             const double best = __longlong_as_double((long long)S.best[lane % G]);
             const float score = mt.mean_score(best);
