@@ -277,6 +277,11 @@ struct Slot {
     size_t arena_cap = 0;
     uint32_t *meta = nullptr;      // device: [0] max levels, [1] fetch counter, [2..3] table bytes (u64), [4] task queue tail, [5] queue overflow
     uint32_t *meta_host = nullptr; // pinned mirror
+    BinInfo *bins = nullptr;               // table phase: LDS size classes of the chunk's ligands
+    uint32_t *caps_dev = nullptr;
+    uint32_t *lists = nullptr;             // [kNumBins + 1][chunk_cap]
+    float4 *wtab = nullptr;                // the call's weights folded into the model's edge table
+    unsigned long long *bstats = nullptr;
     unsigned long long *bestbuf = nullptr; // [chunk_cap][64] per-conformer maxima of split ligands
     uint8_t *deferred = nullptr;           // [chunk_cap]
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // profiling: sizes | tables | tree start | tier 1 | tasks
@@ -325,6 +330,8 @@ static int ensure_workspace(int device, int pipeline, Workspace **out) {
             if (sl.taboff) (void)hipFree(sl.taboff);
             if (sl.bestbuf) (void)hipFree(sl.bestbuf);
             if (sl.deferred) (void)hipFree(sl.deferred);
+            if (sl.lists) (void)hipFree(sl.lists);
+            HIPCHECK(hipMalloc((void **)&sl.lists, (size_t)(kNumBins + 1) * cap * 4));
             HIPCHECK(hipMalloc((void **)&sl.units, (size_t)cap * 4));
             HIPCHECK(hipMalloc((void **)&sl.status, (size_t)cap * 4));
             HIPCHECK(hipMalloc((void **)&sl.taboff, ((size_t)cap + 1) * 8));
@@ -343,6 +350,10 @@ static int ensure_workspace(int device, int pipeline, Workspace **out) {
         HIPCHECK(hipEventCreateWithFlags(&w.done, hipEventDisableTiming));
         for (Slot &sl : w.slot) {
             HIPCHECK(hipMalloc((void **)&sl.meta, 1024));
+            HIPCHECK(hipMalloc((void **)&sl.bins, sizeof(BinInfo)));
+            HIPCHECK(hipMalloc((void **)&sl.caps_dev, sizeof(uint32_t) * kNumBins));
+            HIPCHECK(hipMalloc((void **)&sl.wtab, (size_t)PMX_MAX_MODEL_NODES * PMX_MAX_MODEL_NODES * sizeof(float4)));
+            HIPCHECK(hipMalloc((void **)&sl.bstats, 128 * sizeof(unsigned long long)));
             HIPCHECK(hipHostMalloc((void **)&sl.meta_host, 1024));
             for (auto &ev : sl.ev) HIPCHECK(hipEventCreate(&ev));
             HIPCHECK(hipEventCreateWithFlags(&sl.tables_done, hipEventDisableTiming));
@@ -377,7 +388,7 @@ static bool trace_on() {
 // tables -> search bounds.
 template <int G>
 static int table_phase(const pmx_model *model, const pmx_library *lib, const Weights &W, uint64_t lig0, uint32_t n,
-                       int32_t *status, Slot &sl, hipStream_t q) {
+                       int32_t *status, Slot &sl, hipStream_t q, int ws_num_cu) {
     const int Nm = model->dm.Nm;
     if (sl.walked) HIPCHECK(hipStreamWaitEvent(q, sl.walk_done, 0)); // the slot's previous chunk has been walked
     sl.n = n;
@@ -405,16 +416,74 @@ static int table_phase(const pmx_model *model, const pmx_library *lib, const Wei
         sl.arena_cap = want;
     }
     if (g_profiling) HIPCHECK(hipEventRecord(sl.ev[1], q));
-    if (sl.table_total > 0) {
+    if (sl.table_total > 0 && env_long("PMX_TABLES", 2) == 3) {
+        // tables_kernel_v3: ligands binned by the LDS their tables need, one persistent launch per size class
+        const int K = model->dm.K;
+        const uint32_t model_lds = model_lds_bytes(Nm, K);
+        if (model_lds + sizeof(MatchCtx) + 2048 > kLdsPerCu) return fail(PMX_ERR_INVALID, "model tables do not fit LDS");
+        const uint32_t max_cap = ((uint32_t)kLdsPerCu - model_lds - 64u) & ~15u;
+        static const uint32_t kCaps[kNumBins] = {6144, 8192, 12288, 16384, 24576, 32768, 49152, 65536, 98304, 0xffffffffu};
+        uint32_t caps[kNumBins];
+        for (int b = 0; b < kNumBins; ++b) caps[b] = std::min(kCaps[b], max_cap);
+        HIPCHECK(hipMemcpyAsync(sl.caps_dev, caps, sizeof(caps), hipMemcpyHostToDevice, q));
+        bins_init_kernel<<<dim3(1), dim3(64), 0, q>>>(sl.bins, sl.caps_dev, kNumBins + 1, sl.bstats);
+        fold_weights_kernel<<<dim3((Nm * Nm + 255) / 256), dim3(256), 0, q>>>(model->dm, W, sl.wtab);
+        bin_kernel<G><<<dim3((n + 255) / 256), dim3(256), 0, q>>>(lib->dl, model->dm.tclus, lig0, n, sl.bins, sl.lists, sl.lists, nullptr, nullptr);
+        MatchParams mp;
+        mp.M = model->dm;
+        mp.wtab = sl.wtab;
+        mp.nzw = 0;
+        for (int m = 0; m < Nm; ++m)
+            if (W.w[model->node_type[m]] != 0.f) mp.nzw |= 1ull << m;
+        mp.lib = lib->dl;
+        mp.first = lig0;
+        mp.bins = sl.bins;
+        mp.arena = nullptr;
+        mp.arena_bytes = 0;
+        mp.hlist = nullptr;
+        mp.roots = nullptr;
+        mp.roots_cap = 0;
+        mp.budget = 0;
+        mp.pool_bytes = 0;
+        mp.scores = nullptr;
+        mp.stats = sl.bstats;
+        mp.flags = (uint32_t)env_long("PMX_TREE_FLAGS", 0);
+        mp.seed = nullptr;
+        mp.seed_mode = 0;
+        mp.taboff = sl.taboff;
+        mp.out_arena = sl.arena;
+        const int num_cu = ws_num_cu;
+        for (int b = kNumBins - 1; b >= 0; --b) {
+            if (b > 0 && caps[b] == caps[b - 1]) continue;
+            const uint32_t waves = std::max<uint32_t>(1, std::min<uint32_t>(16, ((uint32_t)kLdsPerCu - model_lds) / caps[b]));
+            mp.list = sl.lists + (size_t)b * n;
+            mp.bin = (uint32_t)b;
+            mp.wave_bytes = caps[b];
+            const size_t lds = model_lds + (size_t)waves * caps[b];
+            tables_kernel_v3<G><<<dim3(num_cu), dim3(64 * waves), lds, q>>>(mp);
+        }
+        HIPCHECK(hipGetLastError());
+        // tables beyond the largest class: the generic kernel on those ligands only
+        {
+            const size_t model_lds2 = (size_t)Nm * (Nm + 1) * sizeof(float4) + 64 * 8 + 128 * 8;
+            const int v2_waves = (int)std::min<size_t>(8, (kLdsPerCu - 1024 - model_lds2) / tables_v2_wave_bytes<G>());
+            const size_t lds2 = model_lds2 + (size_t)v2_waves * tables_v2_wave_bytes<G>();
+            tables_kernel_v2<G><<<dim3((n + v2_waves - 1) / v2_waves), dim3(64 * v2_waves), lds2, q>>>(model->dm, lib->dl, W, lig0, n, status, sl.taboff, sl.arena,
+                                                                           sl.lists + (size_t)kNumBins * n, &sl.bins->count[kNumBins]);
+            bounds_kernel<G><<<dim3((n + 3) / 4), dim3(256), 0, q>>>(n, status, sl.taboff, sl.arena, (int)(env_long("PMX_TREE_FLAGS", 0) & 4),
+                                                                     sl.lists + (size_t)kNumBins * n, &sl.bins->count[kNumBins]);
+        }
+        HIPCHECK(hipGetLastError());
+    } else if (sl.table_total > 0) {
         // <= 8 ligands (waves) per block share one staged model table; the 160 KB of LDS always hold at least one
         const size_t model_lds = (size_t)Nm * (Nm + 1) * sizeof(float4) + 64 * 8 + 128 * 8; // edge table + one neutral column
         if (model_lds + tables_v2_wave_bytes<G>() + 1024 > kLdsPerCu) return fail(PMX_ERR_INVALID, "model tables do not fit LDS");
         const int v2_waves = (int)std::min<size_t>(8, (kLdsPerCu - 1024 - model_lds) / tables_v2_wave_bytes<G>());
         const size_t lds2 = model_lds + (size_t)v2_waves * tables_v2_wave_bytes<G>();
         tables_kernel_v2<G><<<dim3((n + v2_waves - 1) / v2_waves), dim3(64 * v2_waves), lds2, q>>>(
-            model->dm, lib->dl, W, lig0, n, status, sl.taboff, sl.arena);
+            model->dm, lib->dl, W, lig0, n, status, sl.taboff, sl.arena, nullptr, nullptr);
         bounds_kernel<G><<<dim3((n + 3) / 4), dim3(256), 0, q>>>(n, status, sl.taboff, sl.arena,
-                                                                 (int)(env_long("PMX_TREE_FLAGS", 0) & 4));
+                                                                 (int)(env_long("PMX_TREE_FLAGS", 0) & 4), nullptr, nullptr);
         HIPCHECK(hipGetLastError());
     }
     if (g_profiling) HIPCHECK(hipEventRecord(sl.ev[2], q));
@@ -433,7 +502,11 @@ static int tree_phase(const pmx_model *model, const pmx_library *lib, int32_t *s
     if (g_profiling) HIPCHECK(hipEventRecord(sl.ev[3], stream));
     const int depth = std::max<int>(1, (int)sl.max_levels);
     const int Kc = std::max(1, model->dm.K);
-    const size_t lds = tree_wave_bytes<G>(depth, Kc) + (size_t)std::max<long>(0, env_long("PMX_LDS_PAD", 0));
+#ifndef PMX_TOT_WINDOW
+#define PMX_TOT_WINDOW 0
+#endif
+    const size_t lds = tree_wave_bytes<G>(depth, Kc) + (size_t)std::min<int>(PMX_TOT_WINDOW, depth + 1) * 64 * 8 +
+                       (size_t)std::max<long>(0, env_long("PMX_LDS_PAD", 0));
     if (lds > kLdsPerCu) return fail(PMX_ERR_INVALID, "tree state of %zu bytes does not fit LDS", lds);
     TreeParams tp;
     tp.arena = sl.arena;
@@ -577,11 +650,11 @@ static int score_chunks(const pmx_model *const *models, int n_models, const pmx_
     auto chunk_first = [&](uint64_t it) { return first + (it % n_chunks) * cap; };
     auto chunk_status = [&](uint64_t it) { return (status_dev && it < n_chunks) ? status_dev + it * cap : ws.slot[it & 1].status; };
     auto chunk_scores = [&](uint64_t it) { return scores_dev + (it / n_chunks) * model_stride + (it % n_chunks) * cap; };
-    int rc = table_phase<G>(model_of(0), lib, W, chunk_first(0), chunk_n(0), chunk_status(0), ws.slot[0], side);
+    int rc = table_phase<G>(model_of(0), lib, W, chunk_first(0), chunk_n(0), chunk_status(0), ws.slot[0], side, ws.num_cu);
     for (uint64_t it = 0; it < n_items && rc == PMX_OK; ++it) {
         if (it + 1 < n_items)
             rc = table_phase<G>(model_of(it + 1), lib, W, chunk_first(it + 1), chunk_n(it + 1), chunk_status(it + 1),
-                                ws.slot[(it + 1) & 1], side);
+                                ws.slot[(it + 1) & 1], side, ws.num_cu);
         if (rc == PMX_OK) rc = tree_phase<G>(model_of(it), lib, chunk_status(it), chunk_scores(it), ws.slot[it & 1], ws, stream);
     }
     if (rc != PMX_OK) { // leave no work in flight that still references the slots
@@ -755,7 +828,7 @@ extern "C" int pmx_score_multi(const pmx_model *const *models, int n_models, con
         if (models[i]->device != lib->device) return fail(PMX_ERR_INVALID, "model and library live on different devices");
     }
     if (first > lib->info.n_ligands || count > lib->info.n_ligands - first) return fail(PMX_ERR_INVALID, "ligand range out of bounds");
-    if (env_long("PMX_ENGINE", 2) == 2) {
+    if (env_long("PMX_ENGINE", 1) == 2) {
         g_stats = pmx_score_stats{};
         if (count == 0 || n_models == 0) return PMX_OK;
         HIPCHECK(hipSetDevice(lib->device));

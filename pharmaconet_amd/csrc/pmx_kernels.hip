@@ -280,9 +280,11 @@ __host__ __device__ constexpr uint32_t tables_v2_wave_bytes() {
 
 template <int G>
 __global__ __launch_bounds__(512, 6) void tables_kernel_v2(DevModel M, DevLibrary lib, Weights W, uint64_t first, uint32_t count,
-                                                        const int32_t *status, const uint64_t *taboff, uint8_t *arena) {
+                                                        const int32_t *status, const uint64_t *taboff, uint8_t *arena,
+                                                        const uint32_t *list, const uint32_t *list_count) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int GPW = 64 / G; // slots per wave
+    if (list && (uint64_t)blockIdx.x * (blockDim.x / 64) >= *list_count) return; // nothing listed for this block
     const int Nm = M.Nm;
     float4 *tab = reinterpret_cast<float4 *>(smem);
     const int Ns = Nm + 1; // row stride: one neutral column after the model's nodes (see node_pair_lists)
@@ -309,7 +311,11 @@ __global__ __launch_bounds__(512, 6) void tables_kernel_v2(DevModel M, DevLibrar
 
     const int lane = threadIdx.x & 63;
     const int s = lane / G, c = lane % G;
-    const uint64_t gid = (uint64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6); // ligand of this wave
+    uint64_t gid = (uint64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6); // ligand of this wave
+    if (list) { // only the listed ligands (one pass: the list is short - tables too large for tables_kernel_v3)
+        if (gid >= *list_count) return;
+        gid = list[gid];
+    }
     if (gid >= count) return;
     if (status[gid] != PMX_LIGAND_OK) return;
     const uint64_t off = taboff[gid];
@@ -498,11 +504,16 @@ __global__ __launch_bounds__(512, 6) void tables_kernel_v2(DevModel M, DevLibrar
 // f.. add to a node's total. One wavefront per ligand: lane c of group g takes candidates b = g, g + 64/G, ...
 template <int G>
 __global__ __launch_bounds__(256) void bounds_kernel(uint32_t count, const int32_t *status, const uint64_t *taboff, uint8_t *arena,
-                                                      int no_bounds /* debug: write +inf, so that nothing is ever dropped */) {
+                                                      int no_bounds /* debug: write +inf, so that nothing is ever dropped */,
+                                                      const uint32_t *list, const uint32_t *list_count) {
     constexpr int GPW = 64 / G;
     const int lane = threadIdx.x & 63;
     const int g = lane / G, c = lane % G;
-    const uint32_t li = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    uint32_t li = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    if (list) {
+        if (li >= *list_count) return;
+        li = list[li];
+    }
     if (li >= count) return;
     if (status[li] != PMX_LIGAND_OK) return;
     const uint64_t o0 = taboff[li], o1 = taboff[li + 1];
@@ -763,7 +774,17 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
     unsigned char *base = lstk + LCAP * task_bytes<G>() + (size_t)g * tree_group_bytes<G>(D, K);
     // float64 totals by match count live in the wave's private (scratch) memory, not in LDS: they are read
     // and written next to global table loads anyway, and LDS per wave decides how many waves a CU holds
-    double tot[PMX_MAX_LEVELS + 1];
+#ifndef PMX_TOT_WINDOW
+#define PMX_TOT_WINDOW 0 // totals of the first PMX_TOT_WINDOW match counts live in LDS (0: all in private memory)
+#endif
+    constexpr int TW = PMX_TOT_WINDOW;
+    double tot_hi[TW >= PMX_MAX_LEVELS + 1 ? 1 : PMX_MAX_LEVELS + 1 - TW];
+    double *totw = reinterpret_cast<double *>(smem + tree_wave_bytes<G>(D, K)) + lane; // [TW][64]
+    auto tget = [&](int nmq) -> double { return (TW > 0 && nmq < TW) ? totw[nmq * 64] : tot_hi[TW >= PMX_MAX_LEVELS + 1 ? 0 : nmq - TW]; };
+    auto tset = [&](int nmq, double v) {
+        if (TW > 0 && nmq < TW) totw[nmq * 64] = v;
+        else tot_hi[TW >= PMX_MAX_LEVELS + 1 ? 0 : nmq - TW] = v;
+    };
     uint64_t *todo = reinterpret_cast<uint64_t *>(base);                // [D + 1]
     vm_t *cm = reinterpret_cast<vm_t *>(base + todo_bytes);             // [D + 1][K]
     vm_t *msk = reinterpret_cast<vm_t *>(base + todo_bytes + cm_bytes); // [D + 1]
@@ -837,7 +858,7 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
             const int kj = hk[j];
             mat[q] = make_int2((int)hrow[j] - kj * (int)hksum[j + 1], kj | (a << 8) | (j << 16));
         }
-        tot[nm0] = reinterpret_cast<const double *>(th + 1)[c];
+        tset(nm0, reinterpret_cast<const double *>(th + 1)[c]);
         msk[nm0] = (vm_t)th->mask;
         frm[f] = make_uchar4(0, 0, F_MATCHED, (unsigned char)nm0);
         ebf = -1;
@@ -845,7 +866,7 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
         jf = th->jf;
         // a subtree with >= 5 matches at its root that can no longer raise any maximum (the maxima may have grown
         // since it was handed over) is not walked at all
-        busy = nm0 < 5 || may_improve(f - 1, (vm_t)th->mask, tot[nm0]);
+        busy = nm0 < 5 || may_improve(f - 1, (vm_t)th->mask, tget(nm0));
     };
     // describe candidate b of frame fr (conformer mask m) as a task record
     auto describe = [&](TaskHeader *th, int fr, int nmr, int b, vm_t m, double t, bool joined) {
@@ -867,7 +888,7 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
     // total of candidate b of frame fr: parent + self + accumulated pair (tree.py:38-41); any frame, slow path
     auto child_total = [&](int fr, int nmr, int b) -> double {
         const int kr = hk[fr], ksr = hksum[fr];
-        return tot[nmr] + (double)St[(size_t)(ksr + b) * G + c] + pair_sum<G>(Pt, mat, nmr, ksr, kr, b, c);
+        return tget(nmr) + (double)St[(size_t)(ksr + b) * G + c] + pair_sum<G>(Pt, mat, nmr, ksr, kr, b, c);
     };
     // a frame may give children away once it has >= 4 matches (their subtrees hold >= 5, see above)
     auto donatable = [&](int fr) -> bool {
@@ -922,7 +943,7 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
             // The children are leaves: finish the whole frame here. Each existing candidate feeds the
             // per-conformer maximum (graph_match.py:105-108) and returns 1; the skip leaf (tree.py:98-101,
             // :42-43) carries this node's totals and returns 0; then return to the parent (tree.py:102).
-            const double tp = tot[nmr];
+            const double tp = tget(nmr);
             const int ksr = hksum[fr];
             uint64_t left = E;
             while (left) {
@@ -963,7 +984,7 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
             C = parse_record(p.lib.data + p.lib.offsets[p.first + li]).C;
             f0 = f = 0; // root frame
             sfr = 0;
-            tot[0] = 0.0;
+            tset(0, 0.0);
             msk[0] = (vm_t)((C >= 64) ? ~0ull : ((1ull << C) - 1ull));
             frm[0] = make_uchar4(0, 0, 0, 0);
             busy = true;
@@ -1113,7 +1134,7 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
                     const int nm = F.w;
                     const bool matched = F.z & F_MATCHED;
                     if (f == nl) { // a subtree root that is itself a leaf (tree.py:103-104)
-                        const double t = tot[nm];
+                        const double t = tget(nm);
                         if (((msk[nm] >> c) & 1) && t > best) best = t;
                         const unsigned char ret = matched ? 1 : 0;
                         --f;
@@ -1140,7 +1161,7 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
                         // parent + self + accumulated pair (tree.py:38-41)
                         const uint32_t bc = ((uint32_t)b << PSH) + 4u * (uint32_t)c;
                         const float self = *reinterpret_cast<const float *>(Sb + (((uint32_t)ksf << PSH) + bc));
-                        const double t = tot[nm] + (double)self + pair_sum_eb<G>(Pb, eb, nm, bc);
+                        const double t = tget(nm) + (double)self + pair_sum_eb<G>(Pb, eb, nm, bc);
                         if (nm >= 4) { // the child holds >= 5 matches: its subtree is a pure enumeration of leaves
                             if (!may_improve(f, m, t)) { // no leaf below can exceed the maxima found so far
                                 F.y = F.y > 1 ? F.y : 1; // the dropped child returns at least 1
@@ -1163,7 +1184,7 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
                                 if (c == 0) qtail[1] = 1; // queue full: walk it here
                             }
                         }
-                        tot[nm + 1] = t;
+                        tset(nm + 1, t);
                         msk[nm + 1] = m;
                         // entry(this match, level f', b') = rowbase[f] + k_f * (ksum[f'] - ksum[f + 1]) + b * k_f' + b'
                         mat[nm] = make_int2((int)hrow[f] - kf * (int)hksum[f + 1], kf | (b << 8) | (f << 16));

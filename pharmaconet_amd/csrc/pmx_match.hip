@@ -117,6 +117,8 @@ struct MatchParams {
     uint32_t roots_cap;  // roots per block
     uint32_t budget;     // match_kernel: tree steps after which a ligand is passed on to coop_kernel
     uint32_t pool_bytes; // coop_kernel: LDS behind the tables for the helper waves' walk state
+    const uint64_t *taboff; // tables_kernel_v3: arena offsets of the chunk's table blocks (scan_kernel)
+    uint8_t *out_arena;
     double *seed;        // experiment (PMX_SEED_BEST): per-conformer maxima of a previous pass [count][G]; mode 1 = record, 2 = seed
     int seed_mode;
     float *scores;
@@ -197,13 +199,13 @@ __global__ void bin_kernel(DevLibrary lib, const uint64_t *tclus, uint64_t first
     const Record r = parse_record(lib.data + lib.offsets[first + i]);
     if (!record_supported(r)) {
         if (status) status[i] = PMX_LIGAND_UNSUPPORTED;
-        scores[i] = __builtin_nanf("");
+        if (scores) scores[i] = __builtin_nanf("");
         return;
     }
     if (status) status[i] = PMX_LIGAND_OK;
     const Levels L = scan_levels(r, tclus, [](int, int, int, uint64_t, uint32_t) {});
     if (L.nl == 0) {
-        scores[i] = 0.f;
+        if (scores) scores[i] = 0.f;
         return;
     }
     const uint32_t need = match_bytes<G>(L.T, L.ksumtot, (uint32_t)L.nl);
@@ -378,6 +380,38 @@ struct Matcher {
         }
         lds_sync();
         return true;
+    }
+
+    // The finished tables as one block of the chunk's arena, in the layout the tree kernels read (pmx_device.h, TabHeader).
+    __device__ void write_out(uint8_t *blk) {
+        TabHeader *H = reinterpret_cast<TabHeader *>(blk);
+        if (lane == 0) {
+            H->nl = (uint32_t)nl;
+            H->T = T;
+            H->ksumtot = ksumtot;
+            H->pad = 0;
+        }
+        if (lane < nl) {
+            H->k[lane] = X.lk[lane];
+            H->rowbase[lane] = X.rowbase[lane];
+        }
+        if (lane <= nl) H->ksum[lane] = X.ksum[lane];
+        const uint32_t v_bytes = (uint32_t)round16(uint64_t(T) * sizeof(vmask_t<G>));
+        const uint32_t s_bytes = (uint32_t)round16(uint64_t(ksumtot) * G * 4), p_bytes = (uint32_t)round16(uint64_t(T) * G * 4);
+        vmask_t<G> *Vo = reinterpret_cast<vmask_t<G> *>(blk + sizeof(TabHeader));
+        for (uint32_t e = lane; e < T; e += 64) { // conformer-validity mask of each pair entry (tree.py:81)
+            unsigned long long m = 0;
+            for (int q = 0; q < C; ++q) m |= (unsigned long long)(Pt[e * G + q] > 0.f) << q;
+            Vo[e] = (vmask_t<G>)m;
+        }
+        uint4 *So = reinterpret_cast<uint4 *>(blk + sizeof(TabHeader) + v_bytes);
+        const uint4 *Si = reinterpret_cast<const uint4 *>(St);
+        for (uint32_t i = lane; i < s_bytes / 16; i += 64) So[i] = Si[i];
+        uint4 *Po = reinterpret_cast<uint4 *>(blk + sizeof(TabHeader) + v_bytes + s_bytes);
+        const uint4 *Pi = reinterpret_cast<const uint4 *>(Pt);
+        for (uint32_t i = lane; i < p_bytes / 16; i += 64) Po[i] = Pi[i];
+        double *Ro = reinterpret_cast<double *>(blk + sizeof(TabHeader) + v_bytes + s_bytes + p_bytes);
+        for (int i = lane; i < (nl + 1) * G; i += 64) Ro[i] = Rt[i];
     }
 
     // coop_kernel: a wave that did not build the tables takes their geometry from the wave that did
@@ -1102,6 +1136,40 @@ __global__ __launch_bounds__(1024) void match_kernel(const MatchParams p) {
         atomicAdd(&p.stats[45], mt.cyc_walk);
         atomicAdd(&p.stats[46 + 2 * p.bin], mt.cyc_tab);
         atomicAdd(&p.stats[47 + 2 * p.bin], mt.cyc_walk);
+    }
+}
+
+// The table phase of the chunk pipeline (pmx_api.hip): every wavefront pulls ligands of its LDS size class, builds their
+// tables and search bounds in LDS and writes them to the chunk's arena for the tree kernels.
+template <int G>
+__global__ __launch_bounds__(1024) void tables_kernel_v3(const MatchParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int Nm = p.M.Nm;
+    float4 *tab = reinterpret_cast<float4 *>(smem);
+    uint64_t *cnodes = reinterpret_cast<uint64_t *>(smem + round16(uint64_t(Nm) * Nm * 16));
+    uint64_t *tnodes = cnodes + 64;
+    float2 *cpair = reinterpret_cast<float2 *>(tnodes + 128);
+    const int K = p.M.K;
+    for (int i = threadIdx.x; i < Nm * Nm; i += blockDim.x) tab[i] = p.wtab[i];
+    for (int i = threadIdx.x; i < 64; i += blockDim.x) cnodes[i] = p.M.cnodes[i];
+    for (int i = threadIdx.x; i < 128; i += blockDim.x) tnodes[i] = p.M.tnodes[i];
+    for (int i = threadIdx.x; i < K * K; i += blockDim.x) cpair[i] = p.M.cpair[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned char *ctx = smem + model_lds_bytes(Nm, K) + (size_t)wave * p.wave_bytes;
+    unsigned char *tables = ctx + sizeof(MatchCtx);
+    const uint32_t count = (uint32_t)uni((int)p.bins->count[p.bin]);
+    Matcher<G, true> mt(p, tab, cnodes, tnodes, cpair, ctx);
+    for (;;) {
+        uint32_t pos = 0;
+        if (lane == 0) pos = atomicAdd(&p.bins->cursor[p.bin], 1u);
+        pos = (uint32_t)uni((int)pos);
+        if (pos >= count) break;
+        const uint32_t li = (uint32_t)uni((int)p.list[pos]);
+        if (!mt.setup(li, tables)) continue;
+        mt.build_tables();
+        mt.build_bounds();
+        mt.write_out(p.out_arena + p.taboff[li]);
     }
 }
 

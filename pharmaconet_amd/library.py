@@ -47,6 +47,8 @@ __all__ = [
     "cluster_ligand",
     "pack_clustered_ligand",
     "pack_ligand",
+    "pack_ligand_or_marker",
+    "UNSUPPORTED_RECORD",
     "as_packed_library",
 ]
 
@@ -288,6 +290,25 @@ def pack_clustered_ligand(cl: ClusteredLigand) -> bytes:
 
 def pack_ligand(lig: LigandFeatures) -> bytes:
     return pack_clustered_ligand(cluster_ligand(lig))
+
+
+class LigandTooLarge(ValueError):
+    """The ligand exceeds a structural limit of the GPU engine (include/pmx.h)."""
+
+
+# A header-only record (0 nodes, 0 conformers): the engine reports PMX_LIGAND_UNSUPPORTED and a NaN score for it.
+UNSUPPORTED_RECORD = _HEADER.pack(0, 0, 0, 0) + b"\0" * (RECORD_ALIGN - _HEADER.size)
+
+
+def pack_ligand_or_marker(lig: LigandFeatures) -> tuple[bytes, str | None]:
+    """`pack_ligand`, except that a ligand outside the engine's structural limits becomes `UNSUPPORTED_RECORD`
+    (returned with the reason) instead of raising: one oversized molecule must not abort a whole screen."""
+    try:
+        return pack_ligand(lig), None
+    except ValueError as e:
+        if "supported" not in str(e):
+            raise
+        return UNSUPPORTED_RECORD, str(e)
 
 
 @dataclass

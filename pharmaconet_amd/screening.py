@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import argparse
 import multiprocessing
+import sys
 from pathlib import Path
 
 import numpy as np
@@ -38,11 +39,11 @@ class Screening_ArgParser(argparse.ArgumentParser):
         par.add_argument("--cation", type=float, default=8.0, help="weight for cation")
 
 
-def _pack_file(path: str) -> bytes:
-    from .library import pack_ligand
+def _pack_file(path: str) -> tuple[bytes, str | None]:
+    from .library import pack_ligand_or_marker
     from .ligand import Ligand
 
-    return pack_ligand(Ligand.load_from_file(path).features)
+    return pack_ligand_or_marker(Ligand.load_from_file(path).features)
 
 
 def load_library(library: Path, cpus: int) -> tuple[list[str], PackedLibrary]:
@@ -59,18 +60,27 @@ def load_library(library: Path, cpus: int) -> tuple[list[str], PackedLibrary]:
     file_list = list(library.rglob("*.sdf")) + list(library.rglob("*.mol2"))  # screening.py:63-64
     print(f"find {len(file_list)} molecules")
     with multiprocessing.Pool(cpus) as pool:
-        records = pool.map(_pack_file, [str(f) for f in file_list])
-    return [str(f) for f in file_list], PackedLibrary.from_records(records)
+        packed = pool.map(_pack_file, [str(f) for f in file_list])
+    for f, (_, why) in zip(file_list, packed):
+        if why is not None:  # scored by the reference, not by this engine: reported, never silently dropped
+            print(f"warning: {f}: {why}; written with score nan", file=sys.stderr)
+    return [str(f) for f in file_list], PackedLibrary.from_records([rec for rec, _ in packed])
 
 
-def write_csv(out: Path, names: list[str], scores: np.ndarray) -> None:
+def write_csv(out: Path, names: list[str], scores: np.ndarray, status: np.ndarray | None = None) -> None:
     """`result.sort(key=score, reverse=True)` (stable) then `path,score` lines (screening.py:70-75).
-    Scores print with Python's float repr of the float32 value the GPU returned."""
-    order = np.lexsort((np.arange(len(scores)), -scores.astype(np.float64)))
+    Scores print with Python's float repr of the float32 value the GPU returned. Ligands the engine could not score
+    (`status != 0`: outside the structural limits of include/pmx.h) come last with score `nan`."""
+    key = scores.astype(np.float64)
+    bad = np.isnan(key) if status is None else (np.asarray(status) != 0)
+    key = np.where(bad, -np.inf, key)
+    order = np.lexsort((np.arange(len(scores)), -key))
     with open(out, "w") as w:
         w.write("path,score\n")
         for i in order:
-            w.write(f"{names[i]},{float(scores[i])}\n")
+            w.write(f"{names[i]},{'nan' if bad[i] else float(scores[i])}\n")
+    if bad.any():
+        print(f"warning: {int(bad.sum())} ligand(s) outside the engine's structural limits were not scored", file=sys.stderr)
 
 
 def main(argv=None) -> None:
@@ -87,7 +97,7 @@ def main(argv=None) -> None:
     )
     names, lib = load_library(Path(args.library_dir), args.cpus)
     result = model.screen(lib, weights=weight)
-    write_csv(Path(args.out), names, result.scores.cpu().numpy())
+    write_csv(Path(args.out), names, result.scores.cpu().numpy(), result.status.cpu().numpy())
 
 
 if __name__ == "__main__":
