@@ -31,7 +31,13 @@ REPO = Path(__file__).resolve().parent
 sys.path.insert(0, str(REPO))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s HBM3E spec
-VALU_LANE_OPS = 256 * 64 * 2.4e9  # plain (unpacked) VALU lane-operations per second
+# Plain (unpacked) fp32 VALU lane-operations per second: 256 CU x 4 SIMD-32 x 2.4 GHz (MI355X_MICROARCH.md: a wave64
+# instruction issues over 2 cycles; 157.3 TFLOP/s fp32 vector = 2 flops x this). tools/calib/valu_calib.hip measures
+# 6.84e13 with independent v_fma_f32 chains (87 %), v_pk_fma_f32 at half that instruction rate (no gain), and
+# v_exp_f32 at 3.6 plain slots: profiles/r2_valu_calibration.json. A Gaussian term (sub, mul, mul, exp, fma, cmp, addc)
+# is therefore priced at 6 + 3.6 ~ 10 slots.
+VALU_LANE_OPS = 256 * 4 * 32 * 2.4e9
+SLOTS_PER_TERM = 10.0
 
 
 def log(*a):
@@ -112,6 +118,7 @@ def main():
     ap.add_argument("--conformers", type=int, default=8)
     ap.add_argument("--topologies", type=int, default=4096, help="distinct synthetic molecules per GPU")
     ap.add_argument("--topk", type=int, default=1000)
+    ap.add_argument("--pockets", type=int, default=1, help="score this many distinct pockets (1..16) against the shared library (BASELINE configs[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -142,23 +149,29 @@ def main():
     entry.build()
     from pharmaconet_amd import PharmacophoreModel
     from pharmaconet_amd import engine
-    from pharmaconet_amd.distributed import allgather_topk, merge_topk
+    from pharmaconet_amd.distributed import TopkExchange, allgather_topk, merge_topk
 
     model = PharmacophoreModel.load(REPO / "tests" / "golden" / "model_6oim_like.pm")
+    pockets = [model]
+    if args.pockets > 1:
+        pockets = [PharmacophoreModel.load(REPO / "tests" / "golden" / "pockets16" / f"model_{k:02d}.pm") for k in range(min(args.pockets, 16))]
+    exchange = TopkExchange(device) if (world > 1 and backend == "nccl") else None
     lib, offsets, data = build_library(model, args.ligands, args.conformers, args.topologies, rank, device)
     n_lig = len(lib)
     n_conf_total = lib.total_conformers
     index_base = rank * n_lig
 
     def step():
-        res = engine.screen(model, lib, topk=args.topk, index_base=index_base)
-        if world > 1:
-            if backend == "nccl":
-                top = allgather_topk(res.topk_scores, res.topk_indices, args.topk)
+        for pocket in pockets:  # pocket-outer / ligand-inner: the library stays resident, every pocket makes one pass
+            res = engine.screen(pocket, lib, topk=args.topk, index_base=index_base)
+            if world > 1:
+                if exchange is not None:  # RCCL all-gather + merge on the device through libpmx's C ABI
+                    top_s, top_i = exchange.allgather(res.topk_scores, res.topk_indices, args.topk)
+                    top = (top_s.cpu().numpy(), top_i.cpu().numpy())
+                else:
+                    top = allgather_topk(res.topk_scores.cpu(), res.topk_indices.cpu(), args.topk)
             else:
-                top = allgather_topk(res.topk_scores.cpu(), res.topk_indices.cpu(), args.topk)
-        else:
-            top = merge_topk(res.topk_scores.cpu().numpy(), res.topk_indices.cpu().numpy(), args.topk)
+                top = merge_topk(res.topk_scores.cpu().numpy(), res.topk_indices.cpu().numpy(), args.topk)
         return res, top
 
     def barrier():
@@ -190,6 +203,31 @@ def main():
         log(f"[rank {rank}] step stats: {st}")
     barrier()
     elapsed = time.perf_counter() - t0
+    # One extra, untimed pass with the chunk pipelines serialised (one pipeline, table and tree phases on one stream): the
+    # duration of every kernel when it has the GPU to itself, quoted beside the co-running figures of the timed steps.
+    serial = None
+    if rank == 0 and world == 1:
+        saved = {k: os.environ.get(k) for k in ("PMX_PIPELINES", "PMX_OVERLAP")}
+        os.environ["PMX_PIPELINES"], os.environ["PMX_OVERLAP"] = "1", "0"
+        try:
+            engine.screen(pockets[0], lib, topk=args.topk, index_base=index_base)
+            torch.cuda.synchronize()
+            st1 = engine.last_score_stats()
+            nch = max(st1["n_chunks"], 1)
+            serial = {
+                "ligands_per_launch": n_lig / nch,
+                "sizes+scan": st1["ms_sizes"] / nch,
+                "tables_kernel_v2 + bounds_kernel": st1["ms_tables"] / nch,
+                "tree_kernel<G,false>": st1["ms_tree"] / nch,
+                "tree_kernel<G,true> (all rounds of a chunk)": st1["ms_tasks"] / nch,
+                "pass_ms": st1["ms_total"],
+            }
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
     engine.set_profiling(False)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
@@ -199,7 +237,7 @@ def main():
 
     if rank == 0:
         ms_per_step = elapsed * 1e3 / max(args.steps, 1)
-        value = world * n_conf_total * args.steps / elapsed
+        value = world * n_conf_total * len(pockets) * args.steps / elapsed
         # algorithmic bytes: records + 8 B offset in, 4 B score + 4 B status out, per ligand
         alg_bytes_per_ligand = lib.num_bytes / n_lig + 8 + 4 + 4
         ligands_per_launch = n_lig * args.steps / max(launches, 1)
@@ -215,7 +253,7 @@ def main():
         # collected separately with rocprofv3 --pmc and corrected as MI355X_MICROARCH.md prescribes)
         traffic = None
         try:
-            pmc = json.loads((REPO / "profiles" / "r1_hbm_traffic.json").read_text())
+            pmc = json.loads((REPO / "profiles" / "r2_hbm_traffic.json").read_text())
             key = {"tables_kernel_v2": "pmx::tables_kernel_v2<8>", "tree_kernel<G,false>": "pmx::tree_kernel<8, false>",
                    "tree_kernel<G,true>": "pmx::tree_kernel<8, true>"}[dominant.split(" ")[0]]
             if args.conformers == 8:
@@ -223,7 +261,7 @@ def main():
         except Exception:
             traffic = None
         out = {
-            "metric": "ligand-conformers scored/sec (1 pocket)",
+            "metric": f"ligand-conformers scored/sec ({len(pockets)} pocket{'s' if len(pockets) > 1 else ''})",
             "value": value,
             "unit": "ligand-conformers/s",
             "n_gpus": world,
@@ -236,8 +274,12 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"6OIM-like model (37 nodes, 11 clusters) vs {n_lig} synthetic ligands per GPU "
-                            f"(<=32 pharmacophore points, {args.conformers} conformers each), top-{args.topk}",
+                "workload": (f"6OIM-like model (37 nodes, 11 clusters)" if len(pockets) == 1 else f"{len(pockets)} fixture pockets (pockets16)")
+                            + f" vs {n_lig} synthetic ligands per GPU = {min(args.topologies, n_lig)} molecule topologies x "
+                            f"{-(-n_lig // min(args.topologies, n_lig))} copies with every node displaced (sigma 0.35 A) and every conformer "
+                            f"coordinate jittered (sigma 0.30 A); mean {lib.num_bytes / n_lig / (12.0 * args.conformers):.1f} pharmacophore nodes "
+                            f"(<= 32), {args.conformers} conformers each, 10 % drawn on the model's nodes; top-{args.topk}",
+                "pockets": len(pockets),
                 "ligands_per_gpu": n_lig,
                 "conformers_per_ligand": args.conformers,
                 "parallelism": f"ligand-sharded x{world}" if world > 1 else "single GPU",
@@ -250,37 +292,44 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "traffic_note": "HBM bytes per launch from profiles/r1_hbm_traffic.json (separate rocprofv3 --pmc passes); null if unavailable",
+                "traffic_note": "HBM bytes per launch of that kernel from profiles/r2_hbm_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, read side doubled per MI355X_MICROARCH.md); null if unavailable",
                 "algorithmic_bytes_per_ligand": alg_bytes_per_ligand,
                 "ligands_per_launch": ligands_per_launch,
                 "kernel_ms_per_launch": {"sizes+scan": ms_sizes / max(launches, 1), **per_chunk},
+                "kernel_ms_per_launch_serialised": serial,
                 "tree_steps_per_ligand": n_steps / max(n_lig * args.steps, 1),
                 "busy_conformer_groups_per_wave": n_steps / max(n_iters, 1),
                 "subtree_tasks_per_ligand": n_tasks / max(n_lig * args.steps, 1),
                 "intermediate_table_bytes_per_ligand": table_bytes / max(n_lig * args.steps, 1),
-                "note": "durations are HIP-event times on the stream each kernel runs on, taken inside the timed steps; "
-                        "the table phase of chunk k+1 overlaps the tree phase of chunk k (PMX_OVERLAP=0 serialises them), "
-                        "so the per-chunk figures add up to more than ms_per_step / chunks. The path is not HBM-bound: "
-                        "see DESIGN.md section 4 for the VALU / latency accounting.",
+                "note": "kernel_ms_per_launch: HIP-event times on the stream each kernel runs on, inside the timed steps, where three "
+                        "chunk pipelines co-run (so they add up to more than ms_per_step / chunks); kernel_ms_per_launch_serialised: one "
+                        "extra untimed pass with PMX_PIPELINES=1 PMX_OVERLAP=0, every kernel alone on the GPU. The path is not "
+                        "HBM-bound: see roofline_valu and DESIGN.md section 4.",
             },
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], work = cpu_baseline(model, offsets, data, args.conformers)
-            # The bound that matters for the table kernel: Gaussian terms per second against the VALU issue rate,
-            # pricing a term at the 10 plain VALU slots it needs (address, 2 x multiply, subtract, exp ~ 5/3 slot,
-            # fma, compare, count; MI355X_MICROARCH.md: 256 CU x 4 SIMD x 16 lanes x 2.4 GHz = 3.93e13 lane-ops/s).
-            terms_per_s = work["gaussian_terms_per_ligand_conformer"] * value
+            # The bound that matters for the table kernel: Gaussian terms per second (terms as the reference evaluates
+            # them, counted by the oracle on the same ligands) against the VALU issue rate at SLOTS_PER_TERM slots per term.
+            terms_per_conf = work["gaussian_terms_per_ligand_conformer"]
+            terms_per_s = terms_per_conf * value
+            peak_terms = VALU_LANE_OPS / SLOTS_PER_TERM
+            alone = None
+            if serial and serial["tables_kernel_v2 + bounds_kernel"] > 0:
+                alone = terms_per_conf * args.conformers * serial["ligands_per_launch"] / (serial["tables_kernel_v2 + bounds_kernel"] * 1e-3)
             out["roofline_valu"] = {
                 "bound": "valu",
                 "kernel": "tables_kernel_v2",
                 "achieved": terms_per_s / 1e12,
-                "peak": VALU_LANE_OPS / 10 / 1e12,
+                "peak": peak_terms / 1e12,
                 "unit": "T Gaussian terms/s",
-                "frac": terms_per_s / (VALU_LANE_OPS / 10),
-                "frac_of_table_phase_alone": terms_per_s / (VALU_LANE_OPS / 10) * (ms_per_step / max(ms_tables / max(args.steps, 1), 1e-9)),
+                "frac": terms_per_s / peak_terms,
+                "table_kernel_alone": {"achieved": alone / 1e12, "frac": alone / peak_terms} if alone else None,
+                "valu_lane_ops_per_s": VALU_LANE_OPS,
+                "slots_per_term": SLOTS_PER_TERM,
                 **work,
-                "note": "whole-pass rate; frac_of_table_phase_alone rescales by pass time / table-phase time "
-                        "(the table phase overlaps the tree phase of the previous chunk)",
+                "note": "frac = whole-pass rate (every kernel's time counted) / peak; table_kernel_alone = terms of one launch / its "
+                        "serialised duration. Peak and slots per term: profiles/r2_valu_calibration.json (tools/calib/valu_calib.hip).",
             }
         else:
             out["cpu_baseline"] = None

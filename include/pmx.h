@@ -126,6 +126,54 @@ int pmx_score_multi(const pmx_model *const *models, int n_models, const pmx_libr
 int pmx_topk(const float *scores_dev, const uint64_t *index_dev, uint64_t n, uint64_t base_index, int k,
              float *out_scores_dev, uint64_t *out_index_dev, int device, void *stream);
 
+/*
+ * Multi-GPU exchange (one process per GPU). Replaces the gather-and-sort of screening.py:66-70 (`pool.map` over all
+ * files, then one Python sort): every rank scores a contiguous shard, takes its k best with pmx_topk (global indices:
+ * base_index = first ligand of the shard) and calls pmx_topk_allgather, which all-gathers the (score, index) lists
+ * over RCCL (xGMI inside a node) and merges them identically on every rank - descending score, ties by ascending
+ * global index. The communicator is built from an id made on rank 0 (pmx_comm_unique_id) and handed to the other
+ * ranks by the host program (file, socket, torch.distributed store ...).
+ */
+#define PMX_COMM_ID_BYTES 128
+typedef struct pmx_comm pmx_comm;
+int pmx_comm_unique_id(char id_out[PMX_COMM_ID_BYTES]);
+int pmx_comm_create(const char id[PMX_COMM_ID_BYTES], int rank, int nranks, int device, pmx_comm **out);
+int pmx_comm_destroy(pmx_comm *comm);
+int pmx_topk_allgather(pmx_comm *comm, const float *scores_k_dev, const uint64_t *index_k_dev, int k, float *out_scores_dev,
+                       uint64_t *out_index_dev, void *stream);
+
+/*
+ * The library packer in native code (pmx_pack.cpp): what LigandGraph.__init__ (src/pmnet/scoring/ligand.py:110-259) and the
+ * priority sort of graph_match.py:43-60 make of a molecule's perceived pharmacophore features, as records of the packed
+ * library format. Input = what Ligand.__init__ hands to LigandGraph (ligand.py:16-61,120-132), flat over a batch of
+ * molecules: per atom its atomic number and heavy-atom neighbours (CSR, in the order OBAtomAtomIter yields them); per
+ * feature (`pharmacophore_list` order, ligand_utils.py:80-88) its type id, the atom indices and the centre indices, with
+ * flags bit 0 / bit 1 telling whether atom_indices / center_indices was a tuple rather than an int (an int and a
+ * 1-tuple are different node keys, ligand.py:137); positions float32 [n_atoms][n_conformers][3] per molecule.
+ * offsets_out[n_mols + 1] and data_out receive the library; *data_bytes the bytes written (or needed, when data_cap is
+ * too small - call once with data_cap = 0 to size the buffer). status_out (may be NULL): 1 for a molecule outside the
+ * structural limits above, which becomes a header-only record that pmx_score reports as PMX_LIGAND_UNSUPPORTED.
+ */
+typedef struct {
+    uint64_t n_mols;
+    const uint64_t *atom_off;        /* [n_mols + 1] first atom of each molecule */
+    const uint8_t *atomic_num;       /* [total atoms] */
+    const uint64_t *nbr_off;         /* [total atoms + 1] */
+    const int32_t *nbr;              /* neighbour atom indices, local to the molecule */
+    const uint64_t *feat_off;        /* [n_mols + 1] first feature of each molecule */
+    const uint8_t *feat_type;        /* [total features] type id 0..6 */
+    const uint8_t *feat_flags;       /* [total features] bit 0: atom_indices is a tuple, bit 1: center_indices is a tuple */
+    const uint64_t *feat_atom_off;   /* [total features + 1] */
+    const int32_t *feat_atoms;
+    const uint64_t *feat_center_off; /* [total features + 1] */
+    const int32_t *feat_centers;
+    const int32_t *n_conf;           /* [n_mols] */
+    const uint64_t *pos_off;         /* [n_mols + 1] float offset of each molecule's positions */
+    const float *positions;
+} pmx_feature_batch;
+int pmx_pack_features(const pmx_feature_batch *batch, int threads, uint64_t *offsets_out, uint8_t *data_out, uint64_t data_cap,
+                      uint64_t *data_bytes, int32_t *status_out);
+
 /* Timing / diagnostics of the last pmx_score on this thread: kernel-time split measured with HIP events. */
 typedef struct {
     double ms_sizes, ms_tables, ms_tree, ms_tasks, ms_total; /* sizes+scan | tables_kernel | tree_kernel per ligand | task rounds */

@@ -86,13 +86,16 @@ def _load():
             ctypes.c_void_p,
             ctypes.c_int,
         ]
+        _lib.oracle_score_variant.restype = ctypes.c_int
+        _lib.oracle_score_variant.argtypes = list(_lib.oracle_score.argtypes) + [ctypes.c_int]
     return _lib
 
 
 def oracle_score(flat_model, library, weights7, first: int = 0, count: int | None = None, num_threads: int = 1,
-                 with_stats: bool = False):
+                 with_stats: bool = False, variant: str = "numpy"):
     """Score `count` ligands of a `PackedLibrary` against a `FlatModel`; returns float64 scores
-    (and the per-ligand statistics record array when `with_stats`)."""
+    (and the per-ligand statistics record array when `with_stats`). `variant`: "numpy" (the reference's
+    match_utils.py, what the golden vectors pin) or "numba" (restatement of match_utils_numba.py, unpinned)."""
     lib = _load()
     if count is None:
         count = len(library) - first
@@ -117,7 +120,7 @@ def oracle_score(flat_model, library, weights7, first: int = 0, count: int | Non
     assert w.shape == (7,)
     scores = np.zeros(count, dtype=np.float64)
     stats = np.zeros(count, dtype=RESULT_DTYPE) if with_stats else None
-    rc = lib.oracle_score(
+    rc = lib.oracle_score_variant(
         ctypes.byref(model),
         offsets.ctypes.data,
         data.ctypes.data,
@@ -127,6 +130,7 @@ def oracle_score(flat_model, library, weights7, first: int = 0, count: int | Non
         scores.ctypes.data,
         stats.ctypes.data if stats is not None else None,
         int(num_threads),
+        {"numpy": 0, "numba": 1}[variant],
     )
     if rc != 0:
         raise RuntimeError(f"oracle_score failed ({rc})")

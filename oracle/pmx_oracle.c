@@ -11,7 +11,12 @@
  * The reference holds no tests or golden vectors of its own for this path.
  *
  * Every step cites the reference file:line it follows (paths relative to /root/reference/src/pmnet).
- * Arithmetic follows the NumPy variant: float32 tables, float64 tree totals.
+ * Arithmetic follows the NumPy variant (scoring/match_utils.py): float32 tables, float64 tree totals. That is the variant the
+ * golden vectors were minted with (Numba is absent in the build container). `variant = 1` restates the Numba kernels of
+ * scoring/match_utils_numba.py:54-86,126-151 instead (what a user with Numba installed runs, pyproject.toml:28): float64
+ * accumulation of the likelihood, `sigma_sq < 4.0` for the 2-sigma test, weight sums W1 * W2. It is NOT pinned against
+ * reference output (Numba cannot be run here; `fastmath=True` may further reassociate): it bounds the spread between
+ * the reference's own two code paths, see tests/test_oracle_golden.py::test_numba_variant_spread.
  */
 #include <math.h>
 #include <stdint.h>
@@ -77,6 +82,7 @@ typedef struct {
     int64_t n_tree, n_leaf, n_terms;
     /* DFS path */
     int sel[MAX_LEVELS];
+    int variant; /* 0: NumPy kernels, 1: Numba kernels */
 } ctx_t;
 
 static float edge_distance(const ligand_t *L, int u, int v, int c) {
@@ -118,6 +124,32 @@ static void node_pair_term(ctx_t *X, const node_match *a, const node_match *b, f
     const int C = X->L.C, Nm = M->n_nodes;
     int num_match = a->nm * b->nm;
     X->n_terms += num_match;
+    if (X->variant == 1) { /* match_utils_numba.py:54-86 (pair) / :126-151 (self) */
+        double W1 = 0.0, W2 = 0.0; /* sum(weights): the int 0 start value makes Numba accumulate in float64 */
+        for (int i = 0; i < a->nm; ++i) W1 += (double)a->w[i];
+        for (int j = 0; j < b->nm; ++j) W2 += (double)b->w[j];
+        const double normalize_coeff = 1.0 / (W1 * W2), score_coeff = (W1 * W2) / (double)num_match; /* :64-65 */
+        const int pass_threshold = (num_match + 1) / 2;                                               /* :59 */
+        for (int c = 0; c < C; ++c) {
+            const float d = edge_distance(&X->L, a->u, b->u, c);
+            int num_pass = 0;
+            double likelihood = 0.0;
+            for (int i = 0; i < a->nm; ++i) {
+                double row = 0.0; /* _likelihood */
+                for (int j = 0; j < b->nm; ++j) {
+                    const float mu = M->edge_mean[a->m[i] * Nm + b->m[j]], sd = M->edge_std[a->m[i] * Nm + b->m[j]];
+                    const float z = (d - mu) / sd;
+                    const float sigma_sq = z * z;                                  /* :75 float32 operands */
+                    row += (double)(b->w[j] / sd) * exp(-0.5 * (double)sigma_sq);  /* :76 */
+                    if ((double)sigma_sq < 4.0) ++num_pass;                        /* :77-78 */
+                }
+                likelihood += (double)a->w[i] * row; /* :79 */
+            }
+            score[c] = (float)((double)score[c] + likelihood * normalize_coeff * score_coeff); /* :81 */
+            if (fails && num_pass < pass_threshold) fails[c] += 1;                             /* :82-83 */
+        }
+        return;
+    }
     /* weights = outer(w1, w2).reshape(-1); weights_sum = sum(weights)  (builtin sum, float32 steps) */
     float weights_sum = 0.f;
     for (int i = 0; i < a->nm; ++i)
@@ -295,10 +327,11 @@ static int dfs(ctx_t *X, int level, int matched, int num_matches, const uint8_t 
     return max_num + matched; /* tree.py:102 */
 }
 
-static void score_ligand(const oracle_model *M, const uint8_t *rec, const float w[7], oracle_result *R) {
+static void score_ligand(const oracle_model *M, const uint8_t *rec, const float w[7], oracle_result *R, int variant) {
     ctx_t *X = (ctx_t *)calloc(1, sizeof(ctx_t));
     memset(R, 0, sizeof(*R));
     X->M = M;
+    X->variant = variant;
     ligand_t *L = &X->L;
     L->n = rec[0] | (rec[1] << 8);
     L->C = rec[2] | (rec[3] << 8);
@@ -350,14 +383,21 @@ static void score_ligand(const oracle_model *M, const uint8_t *rec, const float 
 }
 
 /* Scores ligands [first, first+count) of a packed library. `results` may be NULL. Returns 0. */
+int oracle_score_variant(const oracle_model *M, const uint64_t *offsets, const uint8_t *data, uint64_t first, uint64_t count,
+                         const float weights[7], double *scores, oracle_result *results, int num_threads, int variant);
 int oracle_score(const oracle_model *M, const uint64_t *offsets, const uint8_t *data, uint64_t first, uint64_t count,
                  const float weights[7], double *scores, oracle_result *results, int num_threads) {
+    return oracle_score_variant(M, offsets, data, first, count, weights, scores, results, num_threads, 0);
+}
+
+int oracle_score_variant(const oracle_model *M, const uint64_t *offsets, const uint8_t *data, uint64_t first, uint64_t count,
+                         const float weights[7], double *scores, oracle_result *results, int num_threads, int variant) {
     if (num_threads < 1) num_threads = 1;
     int64_t n = (int64_t)count;
 #pragma omp parallel for schedule(dynamic, 16) num_threads(num_threads)
     for (int64_t i = 0; i < n; ++i) {
         oracle_result r;
-        score_ligand(M, data + offsets[first + (uint64_t)i], weights, &r);
+        score_ligand(M, data + offsets[first + (uint64_t)i], weights, &r, variant);
         scores[i] = r.score;
         if (results) results[i] = r;
     }

@@ -10,6 +10,7 @@ PKG = Path(__file__).resolve().parent
 LIB_PATH = PKG / "libpmx.so"
 
 NUM_TYPES = 7
+COMM_ID_BYTES = 128
 
 
 class PmxError(RuntimeError):
@@ -48,6 +49,26 @@ class LibraryInfo(ctypes.Structure):
         ("max_conformers", ctypes.c_int32),
         ("max_clusters", ctypes.c_int32),
         ("n_unsupported", ctypes.c_int32),
+    ]
+
+
+class FeatureBatch(ctypes.Structure):
+    _fields_ = [
+        ("n_mols", ctypes.c_uint64),
+        ("atom_off", ctypes.c_void_p),
+        ("atomic_num", ctypes.c_void_p),
+        ("nbr_off", ctypes.c_void_p),
+        ("nbr", ctypes.c_void_p),
+        ("feat_off", ctypes.c_void_p),
+        ("feat_type", ctypes.c_void_p),
+        ("feat_flags", ctypes.c_void_p),
+        ("feat_atom_off", ctypes.c_void_p),
+        ("feat_atoms", ctypes.c_void_p),
+        ("feat_center_off", ctypes.c_void_p),
+        ("feat_centers", ctypes.c_void_p),
+        ("n_conf", ctypes.c_void_p),
+        ("pos_off", ctypes.c_void_p),
+        ("positions", ctypes.c_void_p),
     ]
 
 
@@ -95,6 +116,17 @@ SIGNATURES = {
         [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, ctypes.c_void_p,
          ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p],
     ),
+    "pmx_comm_unique_id": (ctypes.c_int, [ctypes.c_char_p]),
+    "pmx_comm_create": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
+    "pmx_comm_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "pmx_topk_allgather": (
+        ctypes.c_int,
+        [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p],
+    ),
+    "pmx_pack_features": (
+        ctypes.c_int,
+        [ctypes.POINTER(FeatureBatch), ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64), ctypes.c_void_p],
+    ),
     "pmx_score_stats_get": (ctypes.c_int, [ctypes.POINTER(ScoreStats)]),
     "pmx_set_profiling": (ctypes.c_int, [ctypes.c_int]),
 }
@@ -102,13 +134,15 @@ SIGNATURES = {
 _lib = None
 
 
-def load() -> ctypes.CDLL:
+def load(need_torch: bool = True) -> ctypes.CDLL:
     """Load libpmx.so from the package directory (built by `python -m pharmaconet_amd.build`)."""
     global _lib
     if _lib is None:
         # torch bundles its own libamdhip64 (same SONAME as /opt/rocm's); import it first so that the
         # process has ONE HIP runtime - the one that owns torch's device buffers and streams.
-        import torch  # noqa: F401
+        # (Host-only entry points - the packer - are used by worker processes that never touch a GPU.)
+        if need_torch:
+            import torch  # noqa: F401
 
         if not LIB_PATH.exists():
             raise PmxError(

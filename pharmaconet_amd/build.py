@@ -15,7 +15,7 @@ PKG = Path(__file__).resolve().parent
 REPO = PKG.parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libpmx.so"
-SOURCES = ("pmx_api.hip", "pmx_topk.hip")
+SOURCES = ("pmx_api.hip", "pmx_topk.hip", "pmx_pack.cpp")
 DEPS = ("pmx_kernels.hip", "pmx_match.hip", "pmx_device.h")
 FLAGS = (
     "--offload-arch=gfx950",
@@ -72,7 +72,7 @@ def _build(verbose: bool) -> Path:
         subprocess.run(cmd, check=True)
         objs.append(str(obj))
     tmp = LIB.with_suffix(".so.tmp")
-    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", str(tmp)]
+    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", str(tmp), "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

@@ -208,9 +208,6 @@ extern "C" int pmx_library_upload(const pmx_library_view *v, int device, pmx_lib
         HIPCHECK(hipMemcpy(&nbytes, v->offsets + n, 8, hipMemcpyDeviceToHost));
     } else {
         nbytes = v->offsets[n];
-        for (uint64_t i = 0; i < n; ++i)
-            if (v->offsets[i] % 16 || v->offsets[i + 1] < v->offsets[i] + 8)
-                return fail(PMX_ERR_INVALID, "record %llu: bad offset", (unsigned long long)i);
     }
     pmx_library *lib = new pmx_library();
     lib->device = device;
@@ -221,14 +218,14 @@ extern "C" int pmx_library_upload(const pmx_library_view *v, int device, pmx_lib
     if (e == hipSuccess) e = hipMemcpy(lib->offsets, v->offsets, (n + 1) * 8, kind);
     if (e == hipSuccess && nbytes) e = hipMemcpy(lib->data, v->data, nbytes, kind);
     unsigned long long *stats_dev = nullptr;
-    unsigned long long stats[5] = {0, 0, 0, 0, 0};
+    unsigned long long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (e == hipSuccess) e = hipMalloc((void **)&stats_dev, sizeof(stats));
     if (e == hipSuccess) e = hipMemset(stats_dev, 0, sizeof(stats));
     lib->dl.n = n;
     lib->dl.offsets = lib->offsets;
     lib->dl.data = lib->data;
     if (e == hipSuccess && n) {
-        library_stats_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256)>>>(lib->dl, stats_dev);
+        library_stats_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256)>>>(lib->dl, lib->data, nbytes, stats_dev);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpy(stats, stats_dev, sizeof(stats), hipMemcpyDeviceToHost);
@@ -238,6 +235,12 @@ extern "C" int pmx_library_upload(const pmx_library_view *v, int device, pmx_lib
         if (lib->data) (void)hipFree(lib->data);
         delete lib;
         return fail(e == hipErrorOutOfMemory ? PMX_ERR_OOM : PMX_ERR_HIP, "library upload failed: %s", hipGetErrorString(e));
+    }
+    if (stats[5]) { // offsets are validated on the device, for host and device views alike
+        (void)hipFree(lib->offsets);
+        (void)hipFree(lib->data);
+        delete lib;
+        return fail(PMX_ERR_INVALID, "%llu record offsets are not 16-byte aligned, run backwards or point past the data", stats[5]);
     }
     lib->info.n_ligands = n;
     lib->info.n_bytes = nbytes;
@@ -384,6 +387,8 @@ static bool trace_on() {
         }                                 \
     } while (0)
 
+static constexpr int kRetrySmaller = -100; // internal: the chunk's tables exceed the arena limit
+
 // Table phase of one chunk on stream `q`: sizes -> scan -> (one small device-to-host read) -> pair-score
 // tables -> search bounds.
 template <int G>
@@ -407,6 +412,10 @@ static int table_phase(const pmx_model *model, const pmx_library *lib, const Wei
     sl.max_levels = sl.meta_host[0];
     std::memcpy(&sl.table_total, sl.meta_host + 2, 8);
     TRACE("max_levels=%u table bytes=%llu", sl.max_levels, (unsigned long long)sl.table_total);
+    // tree_kernel addresses a ligand's tables with 32 bits of 16-byte units: a chunk's tables must stay below 64 GB
+    // (and below PMX_ARENA_MAX_MB); a chunk that would need more is cut smaller by the caller (kRetrySmaller)
+    const uint64_t arena_limit = std::min<uint64_t>((1ull << 36) - (1ull << 22), (uint64_t)std::max<long>(64, env_long("PMX_ARENA_MAX_MB", 40960)) << 20);
+    if (sl.table_total + sl.table_total / 4 + (1u << 20) > arena_limit) return kRetrySmaller;
     if (sl.table_total > sl.arena_cap) {
         if (sl.arena) (void)hipFree(sl.arena);
         sl.arena = nullptr;
@@ -624,9 +633,7 @@ static int score_chunks(const pmx_model *const *models, int n_models, const pmx_
                         uint64_t count, uint64_t model_stride, float *scores_dev, int32_t *status_dev, hipStream_t stream,
                         Workspace &ws) {
     // equal chunks: the range is cut into the fewest chunks of at most chunk_size() ligands, all of the same size
-    const uint32_t cap_max = std::min<uint32_t>(chunk_size(), ws.chunk_cap);
-    const uint64_t want_chunks = (count + cap_max - 1) / cap_max;
-    const uint32_t cap = (uint32_t)((count + want_chunks - 1) / std::max<uint64_t>(want_chunks, 1));
+    uint32_t cap_max = std::min<uint32_t>(chunk_size(), ws.chunk_cap);
     const uint32_t attr_bit = 1u << __builtin_ctz((unsigned)G);
     if (!(ws.lds_attr_set & attr_bit)) { // once per device (the workspace is per device) and group width
         HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&tables_kernel_v2<G>),
@@ -644,6 +651,9 @@ static int score_chunks(const pmx_model *const *models, int n_models, const pmx_
         HIPCHECK(hipEventRecord(ws.entry, stream));
         HIPCHECK(hipStreamWaitEvent(side, ws.entry, 0));
     }
+    for (;;) {
+    const uint64_t want_chunks = (count + cap_max - 1) / cap_max;
+    const uint32_t cap = (uint32_t)((count + want_chunks - 1) / std::max<uint64_t>(want_chunks, 1));
     const uint64_t n_chunks = (count + cap - 1) / cap, n_items = n_chunks * (uint64_t)n_models;
     auto model_of = [&](uint64_t it) { return models[it / n_chunks]; };
     auto chunk_n = [&](uint64_t it) { return (uint32_t)std::min<uint64_t>(cap, count - (it % n_chunks) * cap); };
@@ -661,7 +671,13 @@ static int score_chunks(const pmx_model *const *models, int n_models, const pmx_
         (void)hipStreamSynchronize(side);
         (void)hipStreamSynchronize(stream);
     }
-    return rc;
+    if (rc != kRetrySmaller) return rc;
+    // a chunk's tables did not fit the arena: start this range again with chunks of half the size (scoring is idempotent)
+    if (cap_max <= 1024) return fail(PMX_ERR_OOM, "the score tables of 1024 ligands exceed the arena limit (PMX_ARENA_MAX_MB)");
+    cap_max = std::max<uint32_t>(1024, cap / 2);
+    for (Slot &sl : ws.slot) sl.walked = false;
+    TRACE("chunk tables exceed the arena limit: retrying with chunks of at most %u ligands", cap_max);
+    }
 }
 
 // ------------------------------------------------------------------------------- fused matcher (pmx_match.hip)
@@ -916,6 +932,15 @@ extern "C" int pmx_score_multi(const pmx_model *const *models, int n_models, con
         });
     rc = run(parts[0].lo, parts[0].n, stream, *ws0);
     for (auto &t : threads) t.join();
+    bool failed = rc != PMX_OK;
+    for (int i = 1; i < P; ++i) failed = failed || parts[i].rc != PMX_OK;
+    if (failed) { // nothing may still be writing scores_dev when the caller sees the error
+        for (int i = 0; i < P; ++i) {
+            (void)hipStreamSynchronize(parts[i].ws->own);
+            (void)hipStreamSynchronize(parts[i].ws->side);
+        }
+        (void)hipStreamSynchronize(stream);
+    }
     if (rc != PMX_OK) return rc;
     for (int i = 1; i < P; ++i)
         if (parts[i].rc != PMX_OK) return fail(parts[i].rc, "%s", parts[i].err.c_str());

@@ -311,6 +311,9 @@ __global__ __launch_bounds__(512, 6) void tables_kernel_v2(DevModel M, DevLibrar
 
     const int lane = threadIdx.x & 63;
     const int s = lane / G, c = lane % G;
+    // model nodes whose type has a non-zero weight: a node-pair term whose weights sum to 0 is 0 * (1 / 0) = NaN in the
+    // reference (match_utils.py:50-52,69)
+    const unsigned long long nzw = __ballot(lane < Nm && W.w[M.node_type[lane < Nm ? lane : 0]] != 0.f);
     uint64_t gid = (uint64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6); // ligand of this wave
     if (list) { // only the listed ligands (one pass: the list is short - tables too large for tables_kernel_v3)
         if (gid >= *list_count) return;
@@ -392,7 +395,8 @@ __global__ __launch_bounds__(512, 6) void tables_kernel_v2(DevModel M, DevLibrar
                     int np = 0;
                     const int mn = cluster_node_pair(M, tab, cnodes, tnodes, a, a, tm[si + u], tm[si + v], d, acc, np);
                     if (!mn) continue;
-                    atomicAdd(&acc_score[e * G + c], acc / (float)mn);
+                    const bool zw = !(cnodes[a] & tnodes[tm[si + u]] & nzw) || !(cnodes[a] & tnodes[tm[si + v]] & nzw);
+                    atomicAdd(&acc_score[e * G + c], zw ? __builtin_nanf("") : acc / (float)mn);
                 }
             }
             wave_lds_sync();
@@ -450,7 +454,8 @@ __global__ __launch_bounds__(512, 6) void tables_kernel_v2(DevModel M, DevLibrar
                     int np = 0;
                     const int mn = cluster_node_pair(M, tab, cnodes, tnodes, a, b, tm[si + u], tm[sj + v], d, acc, np);
                     if (!mn) continue;
-                    atomicAdd(&acc_score[e * G + c], acc / (float)mn);
+                    const bool zw = !(cnodes[a] & tnodes[tm[si + u]] & nzw) || !(cnodes[b] & tnodes[tm[sj + v]] & nzw);
+                    atomicAdd(&acc_score[e * G + c], zw ? __builtin_nanf("") : acc / (float)mn);
                     if (2 * np < mn) atomicAdd(&acc_fail[e * G + c], 1u); // num_pass < num_match * 0.5 (match_utils.py:61)
                 }
                 wave_lds_sync();
@@ -1001,7 +1006,7 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
         const int n_busy = __popcll(busy_bal), n_idle = GPW - n_busy;
         nsteps += (unsigned)n_busy;
         if (++total_iters > max_iters) { // cannot happen for a finite tree; report instead of spinning
-            if (c == 0) {
+            if (c == 0 && g < 8) { // the host decodes 8 groups; meta has room for no more
                 uint32_t *d = p.dbg + 16 + g * 8;
                 d[0] = li; d[1] = busy; d[2] = (uint32_t)f; d[3] = (uint32_t)f0; d[4] = (uint32_t)sp; d[5] = (uint32_t)sfr;
                 d[6] = busy && f >= 0 ? *reinterpret_cast<uint32_t *>(&frm[f]) : 0u; d[7] = busy && f >= 0 ? (uint32_t)todo[f] : 0u;
@@ -1355,10 +1360,39 @@ __global__ void clear_kernel(uint32_t *meta, uint32_t meta_words, unsigned long 
 __global__ void set_word_kernel(uint32_t *word, uint32_t value) { *word = value; }
 
 // -------------------------------------------------------------------------------- library stats
-__global__ void library_stats_kernel(DevLibrary lib, unsigned long long *out /* [0] conformers [1] maxn [2] maxC [3] maxcl [4] unsupported */) {
+// Also validates every record (a truncated or corrupt library must not make the scoring kernels read out of bounds): the
+// header-implied size has to fit the record's byte range, cluster ends have to be monotonic and <= n_nodes, type masks
+// <= 127. A record that fails is neutralised in the device copy (header zeroed -> PMX_LIGAND_UNSUPPORTED, score NaN) and
+// counted; offsets that are not multiples of 16 or run backwards make the upload fail (out[5]).
+__global__ void library_stats_kernel(DevLibrary lib, uint8_t *data_rw, uint64_t nbytes,
+                                     unsigned long long *out /* [0] conformers [1] maxn [2] maxC [3] maxcl [4] unsupported [5] bad offsets [6] corrupt */) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= lib.n) return;
-    Record r = parse_record(lib.data + lib.offsets[i]);
+    const uint64_t o0 = lib.offsets[i], o1 = lib.offsets[i + 1];
+    if ((o0 & 15) || o1 < o0 + 8 || o1 > nbytes) {
+        atomicAdd(&out[5], 1ull);
+        return;
+    }
+    Record r = parse_record(lib.data + o0);
+    {
+        const uint64_t need = ((8ull + (uint64_t)r.n + (uint64_t)r.ncl + 3ull) & ~3ull) + 12ull * (uint64_t)r.n * (uint64_t)r.C;
+        bool ok = need <= o1 - o0;
+        if (ok && record_supported(r)) {
+            int prev = 0;
+            for (int q = 0; q < r.ncl && ok; ++q) {
+                const int e = r.cluster_end[q];
+                ok = e >= prev && e <= r.n;
+                prev = e;
+            }
+            for (int u = 0; u < r.n && ok; ++u) ok = r.typemask[u] < 128;
+        }
+        if (!ok) { // neutralise: 0 nodes, 0 conformers, 0 clusters
+            *reinterpret_cast<uint64_t *>(data_rw + o0) = 0ull;
+            atomicAdd(&out[6], 1ull);
+            atomicAdd(&out[4], 1ull);
+            return;
+        }
+    }
     atomicAdd(&out[0], (unsigned long long)r.C);
     atomicMax(&out[1], (unsigned long long)r.n);
     atomicMax(&out[2], (unsigned long long)r.C);

@@ -1,0 +1,330 @@
+// pmx_pack.cpp - the library packer in native code: LigandGraph's node merging, grouping and clustering
+// (src/pmnet/scoring/ligand.py:110-259) and the priority sort of graph_match.py:43-60, from perceived pharmacophore
+// features to records of the packed library format (pharmaconet_amd/library.py). Host code only; it is the step right
+// in front of the scoring kernels and has to keep up with them.
+//
+// This restates pharmaconet_amd.library.cluster_ligand / pack_clustered_ligand step by step - including what follows from
+// Python container semantics in the reference (dict insertion order and LIFO popitem, `atom_indices` keys where an int
+// and a 1-tuple differ) - so that records are byte-identical to the ones extracted from the reference's own LigandGraph
+// (tests/test_library.py on 708 fixture molecules).
+#include <algorithm>
+#include <atomic>
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <thread>
+#include <utility>
+#include <vector>
+
+#include "pmx.h"
+
+int pmx_topk_fail(int code, const char *msg); // error hook in pmx_api.hip
+
+namespace {
+
+enum : unsigned { T_HYDROPHOBIC = 1u << 0, T_AROMATIC = 1u << 1, T_CATION = 1u << 2, T_ANION = 1u << 3, T_DONOR = 1u << 4, T_ACCEPTOR = 1u << 5, T_HALOGEN = 1u << 6 };
+constexpr unsigned T_HBOND = T_DONOR | T_ACCEPTOR, T_ION = T_CATION | T_ANION;
+
+// cluster types in the order of CLUSTER_PRIORITY (constants.py): (group, subtype) of priority_fn (graph_match.py:43-60)
+enum ClusterType { C_AROMATIC, C_CATION, C_ANION, C_HBOND, C_HALOGEN, C_HYDROPHOBIC };
+constexpr int kPriorityGroup[6] = {0, 0, 0, 1, 1, 1}, kPrioritySub[6] = {0, 1, 2, 0, 1, 2};
+
+struct Node {
+    unsigned types = 0;
+    std::vector<int> atoms;   // sorted, unique (frozenset)
+    bool center_is_tuple = false;
+    std::vector<int> centers; // as given
+    std::vector<int> group;   // insertion-ordered set of node indices (may hold the node itself)
+    int min_dependence = -1;  // min(node.dependence), -1 = empty
+};
+
+inline bool subset(const std::vector<int> &a, const std::vector<int> &b) { return std::includes(b.begin(), b.end(), a.begin(), a.end()); }
+inline void add_dep(Node &n, int idx) { n.min_dependence = n.min_dependence < 0 ? idx : std::min(n.min_dependence, idx); }
+inline void group_add(Node &n, int idx) {
+    if (std::find(n.group.begin(), n.group.end(), idx) == n.group.end()) n.group.push_back(idx);
+}
+
+struct Mol {
+    int n_atoms, n_conf, n_feat;
+    const uint8_t *z;
+    const uint64_t *nbr_off; // [n_atoms + 1], absolute offsets into nbr
+    const int32_t *nbr;
+    const uint8_t *ftype, *fflags;
+    const uint64_t *fatom_off, *fcenter_off; // [n_feat + 1], absolute
+    const int32_t *fatoms, *fcenters;
+    const float *pos; // [n_atoms][n_conf][3]
+};
+
+// One molecule -> one record at `out` (capacity `cap`); returns the record size, 0 if it does not fit the structural
+// limits of include/pmx.h (the caller emits the header-only "unsupported" record), or -1 if cap is too small.
+int64_t pack_one(const Mol &m, uint8_t *out, uint64_t cap) {
+    std::vector<Node> nodes;
+    std::vector<int> node_dict[PMX_NUM_TYPES]; // nodes of each type in order of appearance (duplicates possible)
+    std::map<std::pair<int, std::vector<int>>, int> by_key; // (is_tuple, atom indices as given) -> node
+    // __add_nodes (ligand.py:134-156)
+    for (int f = 0; f < m.n_feat; ++f) {
+        const int t = m.ftype[f];
+        const bool key_tuple = m.fflags[f] & 1;
+        std::vector<int> key(m.fatoms + m.fatom_off[f], m.fatoms + m.fatom_off[f + 1]);
+        auto it = by_key.find(std::make_pair((int)key_tuple, key));
+        if (it != by_key.end()) {
+            nodes[it->second].types |= 1u << t;
+            node_dict[t].push_back(it->second);
+            continue;
+        }
+        Node nw;
+        nw.types = 1u << t;
+        nw.atoms = key;
+        std::sort(nw.atoms.begin(), nw.atoms.end());
+        nw.atoms.erase(std::unique(nw.atoms.begin(), nw.atoms.end()), nw.atoms.end());
+        nw.center_is_tuple = (m.fflags[f] >> 1) & 1;
+        nw.centers.assign(m.fcenters + m.fcenter_off[f], m.fcenters + m.fcenter_off[f + 1]);
+        const int ni = (int)nodes.size();
+        for (int oi = 0; oi < ni; ++oi) { // old.add_neighbors(new) (ligand.py:303-329); old's types as they are NOW
+            Node &old = nodes[oi];
+            if ((old.types & T_HYDROPHOBIC) && (nw.types & T_AROMATIC)) {
+                if (subset(old.atoms, nw.atoms)) add_dep(old, ni);
+            } else if ((old.types & T_AROMATIC) && (nw.types & T_HYDROPHOBIC)) {
+                if (subset(nw.atoms, old.atoms)) add_dep(nw, oi);
+            } else if ((old.types & T_HBOND) && (nw.types & T_ION)) {
+                if (subset(old.atoms, nw.atoms)) add_dep(old, ni);
+            } else if ((old.types & T_ION) && (nw.types & T_HBOND)) {
+                if (subset(nw.atoms, old.atoms)) add_dep(nw, oi);
+            }
+        }
+        nodes.push_back(std::move(nw));
+        node_dict[t].push_back(ni);
+        by_key.emplace(std::make_pair((int)key_tuple, std::move(key)), ni);
+    }
+    const int n = (int)nodes.size();
+    auto heavy_nbrs = [&](int atom) { return std::make_pair(m.nbr + m.nbr_off[atom], m.nbr + m.nbr_off[atom + 1]); };
+
+    // __group_nodes, functional groups (ligand.py:158-192): atoms bonded to the same single heavy neighbour
+    {
+        std::map<int, std::vector<int>> hbond_groups, hydrop_groups;
+        for (int i = 0; i < n; ++i) {
+            Node &nd = nodes[i];
+            std::map<int, std::vector<int>> *groups;
+            if (nd.types & T_HBOND) groups = &hbond_groups;
+            else if (nd.types & T_HYDROPHOBIC) groups = &hydrop_groups;
+            else continue;
+            const int atom = nd.atoms[0];
+            auto nb = heavy_nbrs(atom);
+            int count = 0, only = -1;
+            for (const int32_t *q = nb.first; q != nb.second; ++q)
+                if (m.z[*q] != 1) {
+                    ++count;
+                    only = *q;
+                }
+            if (count == 1) {
+                std::vector<int> &members = (*groups)[only];
+                for (int other : members) {
+                    group_add(nd, other);
+                    group_add(nodes[other], i);
+                }
+                members.push_back(i);
+            }
+        }
+    }
+    // __group_nodes, hydrophobic flood over carbon-carbon bonds (ligand.py:194-213). index_to_node is a dict built from
+    // node_dict["Hydrophobic"]: a repeated key keeps its first position and takes the last value; popitem() is LIFO.
+    {
+        std::vector<std::pair<int, int>> entries; // (atom, node), insertion order
+        std::vector<char> alive;
+        std::map<int, int> where;
+        for (int ni : node_dict[0]) {
+            const int atom = nodes[ni].atoms[0];
+            auto it = where.find(atom);
+            if (it == where.end()) {
+                where.emplace(atom, (int)entries.size());
+                entries.emplace_back(atom, ni);
+                alive.push_back(1);
+            } else {
+                entries[it->second].second = ni;
+            }
+        }
+        int last = (int)entries.size() - 1;
+        for (;;) {
+            while (last >= 0 && !alive[last]) --last;
+            if (last < 0) break;
+            const int start = entries[last].second;
+            alive[last] = 0;
+            where.erase(entries[last].first);
+            std::vector<int> members;
+            members.push_back(start);
+            for (int g : nodes[start].group) members.push_back(g);
+            std::vector<int> group_index;
+            for (int mi : members) group_index.push_back(nodes[mi].atoms[0]);
+            for (size_t gi = 0; gi < group_index.size(); ++gi) { // grows while iterating
+                auto nb = heavy_nbrs(group_index[gi]);
+                for (const int32_t *q = nb.first; q != nb.second; ++q) {
+                    if (m.z[*q] != 6) continue;
+                    auto it = where.find(*q);
+                    if (it == where.end()) continue;
+                    const int reached = entries[it->second].second;
+                    alive[it->second] = 0;
+                    where.erase(it);
+                    group_index.push_back(*q);
+                    for (int mi : members) {
+                        group_add(nodes[mi], reached);
+                        group_add(nodes[reached], mi);
+                    }
+                    members.push_back(reached);
+                }
+            }
+        }
+    }
+    // __setup_cluster (ligand.py:215-259)
+    std::vector<std::vector<int>> clusters;
+    std::vector<int> ctype;
+    std::vector<int> founder(n, -1); // node -> cluster it founded
+    std::vector<char> in_cluster(n, 0);
+    const int high_types[4] = {1, 2, 3, 6}; // Aromatic, Cation, Anion, Halogen
+    const int high_ctype[4] = {C_AROMATIC, C_CATION, C_ANION, C_HALOGEN};
+    for (int h = 0; h < 4; ++h)
+        for (int ni : node_dict[high_types[h]]) {
+            if (in_cluster[ni]) continue;
+            in_cluster[ni] = 1;
+            clusters.push_back({ni});
+            ctype.push_back(high_ctype[h]);
+            founder[ni] = (int)clusters.size() - 1;
+        }
+    const int low_types[3] = {0, 4, 5}; // Hydrophobic, HBond_donor, HBond_acceptor
+    for (int l = 0; l < 3; ++l)
+        for (int ni : node_dict[low_types[l]]) {
+            if (in_cluster[ni]) continue;
+            in_cluster[ni] = 1;
+            Node &nd = nodes[ni];
+            bool add_new = true;
+            if (nd.min_dependence >= 0 && founder[nd.min_dependence] >= 0) { // (the reference would raise KeyError otherwise)
+                clusters[founder[nd.min_dependence]].push_back(ni);
+                add_new = false;
+            } else if (nd.min_dependence < 0) {
+                for (int g : nd.group)
+                    if (founder[g] >= 0) {
+                        clusters[founder[g]].push_back(ni);
+                        add_new = false;
+                        break;
+                    }
+            }
+            if (add_new) {
+                clusters.push_back({ni});
+                ctype.push_back(l == 0 ? C_HYDROPHOBIC : C_HBOND);
+                founder[ni] = (int)clusters.size() - 1;
+            }
+        }
+    // pack_clustered_ligand: stable sort by priority_fn (graph_match.py:43-60), nodes renumbered cluster by cluster
+    const int ncl = (int)clusters.size();
+    std::vector<int> order(ncl);
+    for (int i = 0; i < ncl; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+        const int ka[4] = {kPriorityGroup[ctype[a]], -(int)clusters[a].size(), kPrioritySub[ctype[a]], nodes[clusters[a][0]].atoms[0]};
+        const int kb[4] = {kPriorityGroup[ctype[b]], -(int)clusters[b].size(), kPrioritySub[ctype[b]], nodes[clusters[b][0]].atoms[0]};
+        return std::lexicographical_compare(ka, ka + 4, kb, kb + 4);
+    });
+    if (n > PMX_MAX_LIGAND_NODES || ncl > PMX_MAX_LIGAND_CLUSTERS || m.n_conf < 1 || m.n_conf > PMX_MAX_CONFORMERS) return 0;
+    const int C = m.n_conf;
+    const uint64_t head = 8 + (uint64_t)n + (uint64_t)ncl;
+    const uint64_t body = ((head + 3) & ~3ull) + 12ull * n * C;
+    const uint64_t total = (body + 15) & ~15ull;
+    if (total > cap) return -1;
+    std::memset(out, 0, total);
+    uint16_t h16[4] = {(uint16_t)n, (uint16_t)C, (uint16_t)ncl, 0};
+    std::memcpy(out, h16, 8);
+    uint8_t *tm = out + 8, *ends = out + 8 + n;
+    float *xyz = reinterpret_cast<float *>(out + ((head + 3) & ~3ull));
+    int pos = 0;
+    for (int ci = 0; ci < ncl; ++ci) {
+        for (int ni : clusters[order[ci]]) {
+            const Node &nd = nodes[ni];
+            tm[pos] = (uint8_t)nd.types;
+            float *dst = xyz + (size_t)pos * 3 * C; // [3][C]
+            if (!nd.center_is_tuple) { // LigandNode.set_positions (ligand.py:293-301)
+                const float *src = m.pos + (size_t)nd.centers[0] * C * 3;
+                for (int c = 0; c < C; ++c)
+                    for (int d = 0; d < 3; ++d) dst[d * C + c] = src[c * 3 + d];
+            } else { // float32 mean over the centre atoms, atom after atom, then one division
+                const float cnt = (float)nd.centers.size();
+                for (int c = 0; c < C; ++c)
+                    for (int d = 0; d < 3; ++d) {
+                        float sum = 0.f;
+                        bool first = true;
+                        for (int a : nd.centers) {
+                            const float v = m.pos[((size_t)a * C + c) * 3 + d];
+                            sum = first ? v : sum + v;
+                            first = false;
+                        }
+                        dst[d * C + c] = sum / cnt;
+                    }
+            }
+            ++pos;
+        }
+        ends[ci] = (uint8_t)pos;
+    }
+    return (int64_t)total;
+}
+
+} // namespace
+
+extern "C" int pmx_pack_features(const pmx_feature_batch *b, int threads, uint64_t *offsets_out, uint8_t *data_out, uint64_t data_cap,
+                                 uint64_t *data_bytes, int32_t *status_out) {
+    if (!b || !offsets_out || (!data_out && data_cap) || !data_bytes) return pmx_topk_fail(PMX_ERR_INVALID, "null argument");
+    const uint64_t n = b->n_mols;
+    // every record gets the worst-case room of its molecule first (features x conformers), then the records are compacted
+    std::vector<uint64_t> room(n + 1, 0);
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint64_t nf = b->feat_off[i + 1] - b->feat_off[i];
+        const uint64_t c = (uint64_t)std::max(b->n_conf[i], 1);
+        room[i + 1] = room[i] + ((8 + 2 * nf + 3 + 12 * nf * c + 15) & ~15ull) + 16;
+    }
+    std::vector<uint8_t> scratch(room[n]);
+    std::vector<int64_t> sizes(n, 0);
+    std::atomic<uint64_t> next{0};
+    auto work = [&]() {
+        for (;;) {
+            const uint64_t i0 = next.fetch_add(256);
+            if (i0 >= n) break;
+            for (uint64_t i = i0; i < std::min(n, i0 + 256); ++i) {
+                Mol m;
+                const uint64_t a0 = b->atom_off[i];
+                m.n_atoms = (int)(b->atom_off[i + 1] - a0);
+                m.n_conf = b->n_conf[i];
+                m.n_feat = (int)(b->feat_off[i + 1] - b->feat_off[i]);
+                m.z = b->atomic_num + a0;
+                m.nbr_off = b->nbr_off + a0;
+                m.nbr = b->nbr;
+                m.ftype = b->feat_type + b->feat_off[i];
+                m.fflags = b->feat_flags + b->feat_off[i];
+                m.fatom_off = b->feat_atom_off + b->feat_off[i];
+                m.fcenter_off = b->feat_center_off + b->feat_off[i];
+                m.fatoms = b->feat_atoms;
+                m.fcenters = b->feat_centers;
+                m.pos = b->positions + b->pos_off[i];
+                int64_t sz = pack_one(m, scratch.data() + room[i], room[i + 1] - room[i]);
+                if (sz <= 0) { // outside the structural limits: header-only record, reported per ligand (PMX_LIGAND_UNSUPPORTED)
+                    std::memset(scratch.data() + room[i], 0, 16);
+                    sz = 16;
+                    if (status_out) status_out[i] = 1;
+                } else if (status_out) {
+                    status_out[i] = 0;
+                }
+                sizes[i] = sz;
+            }
+        }
+    };
+    const int nt = std::max(1, std::min(threads, 256));
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; ++t) pool.emplace_back(work);
+    work();
+    for (auto &t : pool) t.join();
+    uint64_t total = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        offsets_out[i] = total;
+        total += (uint64_t)sizes[i];
+    }
+    offsets_out[n] = total;
+    *data_bytes = total;
+    if (total > data_cap) return data_out ? pmx_topk_fail(PMX_ERR_INVALID, "data_out too small (data_bytes holds the size needed)") : PMX_OK;
+    for (uint64_t i = 0; i < n; ++i) std::memcpy(data_out + offsets_out[i], scratch.data() + room[i], (size_t)sizes[i]);
+    return PMX_OK;
+}

@@ -11,7 +11,7 @@ from __future__ import annotations
 
 import numpy as np
 
-__all__ = ["shard_range", "merge_topk", "allgather_topk", "screen_sharded"]
+__all__ = ["shard_range", "merge_topk", "allgather_topk", "screen_sharded", "TopkExchange"]
 
 
 def shard_range(n_total: int, rank: int, world: int) -> tuple[int, int]:
@@ -47,6 +47,60 @@ def allgather_topk(local_scores, local_indices, k: int, group=None) -> tuple[np.
     dist.all_gather_into_tensor(gathered_s, local_scores.contiguous(), group=group)
     dist.all_gather_into_tensor(gathered_i, local_indices.contiguous(), group=group)
     return merge_topk(gathered_s.cpu().numpy(), gathered_i.cpu().numpy(), k)
+
+
+class TopkExchange:
+    """The top-k exchange through libpmx's C ABI (`pmx_comm_*`, `pmx_topk_allgather`): RCCL all-gather of the per-rank
+    lists and the merge, both on the device. The communicator id is made on rank 0 and handed to the other ranks through
+    the `torch.distributed` store (control plane only); the data never leaves HBM until the caller reads the result."""
+
+    def __init__(self, device, group=None):
+        import ctypes
+
+        import torch
+        import torch.distributed as dist
+
+        from . import _ffi
+
+        self._lib = _ffi.load()
+        self.device = torch.device(device)
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        ident = ctypes.create_string_buffer(_ffi.COMM_ID_BYTES)
+        if self.rank == 0:
+            _ffi.check(self._lib.pmx_comm_unique_id(ident))
+        payload = [ident.raw]
+        if self.world > 1:
+            dist.broadcast_object_list(payload, src=0, group=group)
+        self._handle = ctypes.c_void_p()
+        _ffi.check(self._lib.pmx_comm_create(payload[0], self.rank, self.world, self.device.index or 0, ctypes.byref(self._handle)))
+
+    def allgather(self, local_scores, local_indices, k: int):
+        """`local_scores` float32 [k], `local_indices` int64 [k] (global indices, -1 padding) on this rank's GPU ->
+        the global top-k as device tensors, identical on every rank."""
+        import ctypes
+
+        import torch
+
+        from . import _ffi
+
+        out_s = torch.empty(k, dtype=torch.float32, device=self.device)
+        out_i = torch.empty(k, dtype=torch.int64, device=self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _ffi.check(self._lib.pmx_topk_allgather(self._handle, local_scores.contiguous().data_ptr(), local_indices.contiguous().data_ptr(), int(k),
+                                                out_s.data_ptr(), out_i.data_ptr(), ctypes.c_void_p(stream)))
+        return out_s, out_i
+
+    def close(self):
+        if getattr(self, "_handle", None):
+            self._lib.pmx_comm_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def screen_sharded(model, shard_library, k: int, shard_first: int, weights=None, group=None):

@@ -48,6 +48,8 @@ __all__ = [
     "pack_clustered_ligand",
     "pack_ligand",
     "pack_ligand_or_marker",
+    "pack_features_native",
+    "flatten_features",
     "UNSUPPORTED_RECORD",
     "as_packed_library",
 ]
@@ -290,6 +292,65 @@ def pack_clustered_ligand(cl: ClusteredLigand) -> bytes:
 
 def pack_ligand(lig: LigandFeatures) -> bytes:
     return pack_clustered_ligand(cluster_ligand(lig))
+
+
+def flatten_features(mols: Sequence[LigandFeatures]) -> dict[str, np.ndarray]:
+    """A batch of `LigandFeatures` as the flat arrays of `pmx_feature_batch` (include/pmx.h)."""
+    atom_off, feat_off, pos_off = [0], [0], [0]
+    z, nbr_off, nbr = [], [0], []
+    ftype, fflags, fa_off, fa, fc_off, fc = [], [], [0], [], [0], []
+    n_conf, pos = [], []
+    for m in mols:
+        na = m.num_atoms
+        z.extend(int(x) for x in m.atomic_nums)
+        for row in m.heavy_neighbors:
+            nbr.extend(int(j) for j in row)
+            nbr_off.append(len(nbr))
+        atom_off.append(atom_off[-1] + na)
+        for t, atoms, centers in m.features:
+            ftype.append(TYPE_ID[t])
+            a_tuple, c_tuple = not isinstance(atoms, int), not isinstance(centers, int)
+            fflags.append((1 if a_tuple else 0) | (2 if c_tuple else 0))
+            fa.extend([int(atoms)] if not a_tuple else [int(x) for x in atoms])
+            fa_off.append(len(fa))
+            fc.extend([int(centers)] if not c_tuple else [int(x) for x in centers])
+            fc_off.append(len(fc))
+        feat_off.append(len(ftype))
+        p = np.ascontiguousarray(m.atom_positions, dtype=np.float32)
+        n_conf.append(int(p.shape[1]) if p.ndim == 3 else 0)
+        pos.append(p.reshape(-1))
+        pos_off.append(pos_off[-1] + p.size)
+    return dict(
+        atom_off=np.array(atom_off, np.uint64), atomic_num=np.array(z, np.uint8), nbr_off=np.array(nbr_off, np.uint64),
+        nbr=np.array(nbr, np.int32), feat_off=np.array(feat_off, np.uint64), feat_type=np.array(ftype, np.uint8),
+        feat_flags=np.array(fflags, np.uint8), feat_atom_off=np.array(fa_off, np.uint64), feat_atoms=np.array(fa, np.int32),
+        feat_center_off=np.array(fc_off, np.uint64), feat_centers=np.array(fc, np.int32), n_conf=np.array(n_conf, np.int32),
+        pos_off=np.array(pos_off, np.uint64), positions=np.concatenate(pos) if pos else np.zeros(0, np.float32),
+    )
+
+
+def pack_features_native(mols: Sequence[LigandFeatures] | dict[str, np.ndarray], threads: int = 1) -> tuple["PackedLibrary", np.ndarray]:
+    """The packer in native code (`pmx_pack_features`, csrc/pmx_pack.cpp): byte-identical to `pack_ligand` per molecule,
+    multi-threaded over molecules. Returns the library and a per-molecule status (1: outside the structural limits,
+    packed as `UNSUPPORTED_RECORD`)."""
+    import ctypes
+
+    from . import _ffi
+
+    flat = mols if isinstance(mols, dict) else flatten_features(mols)
+    lib = _ffi.load(need_torch=False)
+    n = int(flat["atom_off"].shape[0]) - 1
+    batch = _ffi.FeatureBatch(n, *(flat[k].ctypes.data for k in (
+        "atom_off", "atomic_num", "nbr_off", "nbr", "feat_off", "feat_type", "feat_flags", "feat_atom_off", "feat_atoms",
+        "feat_center_off", "feat_centers", "n_conf", "pos_off", "positions")))
+    offsets = np.zeros(n + 1, dtype=np.uint64)
+    status = np.zeros(n, dtype=np.int32)
+    nbytes = ctypes.c_uint64(0)
+    _ffi.check(lib.pmx_pack_features(ctypes.byref(batch), int(threads), offsets.ctypes.data, None, 0, ctypes.byref(nbytes), status.ctypes.data))
+    data = np.zeros(int(nbytes.value), dtype=np.uint8)
+    _ffi.check(lib.pmx_pack_features(ctypes.byref(batch), int(threads), offsets.ctypes.data, data.ctypes.data, data.size, ctypes.byref(nbytes),
+                                     status.ctypes.data))
+    return PackedLibrary(offsets, data), status
 
 
 class LigandTooLarge(ValueError):

@@ -1,0 +1,270 @@
+"""GPU tests beyond the golden sets: both of the reference's kernel variants, zero weights, the alternative engines, the
+structural limits, corrupt libraries, the arena limit, the multi-pocket batch (BASELINE.json configs[3]) and the stress
+configuration at full size (configs[4])."""
+
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, GOLDEN_SETS, REPO, load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 2e-6
+
+
+def _model_nodes(model):
+    from pharmaconet_amd.constants import TYPE_ID
+
+    st = model.__getstate__()
+    centers = np.array([n["center"] for n in st["nodes"]], dtype=np.float64)
+    types = np.array([TYPE_ID[n["type"]] for n in st["nodes"]])
+    return centers, types
+
+
+def _gpu(model, lib, weights=None, **kw):
+    from pharmaconet_amd.engine import screen
+
+    res = screen(model, lib, weights=weights, **kw)
+    return res.scores.cpu().numpy().astype(np.float64), res.status.cpu().numpy()
+
+
+def test_within_1e5_of_both_reference_variants(oracle):
+    """north_star: scores within 1e-5 relative of the reference's CPU path - NumPy kernels (pinned) and Numba kernels
+    (restated, match_utils_numba.py:54-86). Flips (a ligand beyond 1e-6 of either) are counted and must be absent."""
+    from pharmaconet_amd.constants import weights_vector
+    from pharmaconet_amd.synthetic import synthetic_library
+
+    model, _, _, _ = load_golden("set_6oim_c8")
+    lib = synthetic_library(600, num_conformers=8, model_nodes=_model_nodes(model), active_fraction=0.3, seed=90210)
+    got, status = _gpu(model, lib)
+    assert np.all(status == 0)
+    for variant in ("numpy", "numba"):
+        ref = oracle.oracle_score(model.flat, lib, weights_vector(None), num_threads=os.cpu_count() or 8, variant=variant)
+        zero = ref == 0
+        assert np.all(got[zero] == 0.0)
+        err = rel_err(got[~zero], ref[~zero])
+        flips = int((err > 1e-6).sum())
+        print(f"GPU vs {variant} variant: max rel err {err.max():.2e}, {flips} of {err.size} ligands beyond 1e-6")
+        assert err.max() < 1e-5
+        assert flips == 0
+
+
+def test_zero_type_weight_matches_oracle(oracle):
+    """`--hydrophobic 0` (screening.py:33): node pairs whose weights sum to 0 give 0 * (1 / 0) = NaN in the reference
+    (match_utils.py:50-52,69), which invalidates the pair entry / poisons the self entry. GPU == oracle."""
+    from pharmaconet_amd.constants import weights_vector
+    from pharmaconet_amd.synthetic import synthetic_library
+
+    model, _, _, _ = load_golden("set_6oim_c8")
+    lib = synthetic_library(300, num_conformers=8, model_nodes=_model_nodes(model), active_fraction=0.4, seed=31337)
+    for weights in ({"Hydrophobic": 0.0}, {"Aromatic": 0.0, "Halogen": 0.0}):
+        ref = oracle.oracle_score(model.flat, lib, weights_vector(weights), num_threads=os.cpu_count() or 8)
+        got, status = _gpu(model, lib, weights)
+        assert np.all(status == 0) and np.all(np.isfinite(got))
+        zero = ref == 0
+        assert np.all(got[zero] == 0.0)
+        assert rel_err(got[~zero], ref[~zero]).max() < RTOL + 6e-8
+        default, _ = _gpu(model, lib)
+        assert np.abs(default - got).max() > 0.5  # the weight matters on this library
+
+
+@pytest.mark.parametrize("env", [{"PMX_ENGINE": "2"}, {"PMX_TABLES": "3"}], ids=["fused-matcher", "tables-v3"])
+@pytest.mark.parametrize("name", GOLDEN_SETS)
+def test_alternative_engines_match_reference_golden(name, env, monkeypatch):
+    """The LDS-resident fused matcher (pmx_match.hip, PMX_ENGINE=2) and its table builder inside the chunk pipeline
+    (PMX_TABLES=3) are held to the same fixtures as the production path."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    model, lib, weights, d = load_golden(name)
+    got, status = _gpu(model, lib, weights)
+    assert np.all(status == 0)
+    ref = d["score"]
+    zero = ref == 0
+    assert np.all(got[zero] == 0.0)
+    assert rel_err(got[~zero], ref[~zero]).max() < RTOL + 6e-8
+
+
+def test_structural_limits_are_explicit():
+    """include/pmx.h: at most 64 model nodes / clusters and 64 ligand nodes / clusters / conformers. A model beyond
+    them is refused with a message; a ligand beyond them is reported per ligand (status 1, score NaN) and ranks last."""
+    from pharmaconet_amd import PharmacophoreModel
+    from pharmaconet_amd.library import UNSUPPORTED_RECORD
+
+    model, lib, _, _ = load_golden("set_6oim_c5")
+    st = json.loads(json.dumps(model.__getstate__()))
+    node = dict(st["nodes"][0])
+    for i in range(len(st["nodes"]), 65):
+        extra = dict(node, index=i)
+        st["nodes"].append(extra)
+    with pytest.raises(ValueError, match="at most 64"):
+        big = PharmacophoreModel.__new__(PharmacophoreModel)
+        big.__setstate__(st)
+        _ = big.flat
+    recs = [lib.record(0), UNSUPPORTED_RECORD, lib.record(1)]
+    res = model.screen(recs, topk=3)
+    status = res.status.cpu().numpy()
+    scores = res.scores.cpu().numpy()
+    assert status.tolist() == [0, 1, 0] and np.isnan(scores[1]) and np.isfinite(scores[[0, 2]]).all()
+    assert [i for i, _ in res.ranking()][-1] == 1
+
+
+def test_corrupt_library_is_neutralised_not_followed():
+    """pmx_library_upload validates every record on the device: a record whose header does not fit its byte range, whose
+    cluster ends run backwards or whose type mask has bit 7 set is scored as unsupported (NaN) instead of being read."""
+    from pharmaconet_amd import PackedLibrary
+    from pharmaconet_amd.engine import DeviceLibrary
+
+    model, lib, _, d = load_golden("set_6oim_c5")
+    recs = [bytearray(lib.record(i)) for i in range(6)]
+    recs[1][2:4] = (60).to_bytes(2, "little")  # claims 60 conformers: xyz would run past the record
+    recs[2][8] |= 0x80                         # type mask with bit 7
+    n2, _, k2 = lib.header(3)
+    if k2 >= 2:
+        recs[3][8 + n2] = 200                  # first cluster end beyond n_nodes
+    bad = PackedLibrary.from_records([bytes(r) for r in recs])
+    dev = DeviceLibrary(bad)
+    assert dev.num_unsupported >= 2
+    scores = model.screen(dev).scores.cpu().numpy()
+    assert np.isnan(scores[1]) and np.isnan(scores[2])
+    assert abs(scores[0] - d["score"][0]) <= RTOL * abs(d["score"][0]) + 1e-30
+    assert abs(scores[5] - d["score"][5]) <= RTOL * abs(d["score"][5]) + 1e-30
+
+
+def test_arena_limit_cuts_chunks_smaller(monkeypatch):
+    """A chunk whose score tables would exceed the arena limit (64 GB addressing / PMX_ARENA_MAX_MB) is cut into smaller
+    chunks instead of overflowing 32-bit table offsets or failing: same bits."""
+    import torch
+
+    from pharmaconet_amd.engine import DeviceLibrary
+    from pharmaconet_amd.synthetic import expand_library_on_device, synthetic_library
+
+    model, _, _, _ = load_golden("set_6oim_c8")
+    base = synthetic_library(256, num_conformers=8, model_nodes=_model_nodes(model), conformer_noise=0.0, seed=777)
+    offsets, data = expand_library_on_device(base, 64, "cuda")  # 16,384 ligands, ~180 MB of tables
+    lib = DeviceLibrary.from_device_buffers(offsets, data)
+    want = model.screen(lib).scores
+    with monkeypatch.context() as mp:
+        mp.setenv("PMX_ARENA_MAX_MB", "64")
+        got = model.screen(lib).scores
+    assert torch.equal(got, want)
+
+
+def test_sixteen_pockets_one_library():
+    """BASELINE.json configs[3]: a batch of 16 distinct pockets against one shared library through pmx_score_multi;
+    every (pocket, ligand) score against the reference's own (fixture minted by tests/golden/make_golden_pockets.py)."""
+    import ctypes
+
+    import torch
+
+    from pharmaconet_amd import PackedLibrary, PharmacophoreModel, _ffi
+    from pharmaconet_amd.constants import weights_vector
+    from pharmaconet_amd.engine import DeviceLibrary, device_model
+
+    d = np.load(GOLDEN / "pockets16.npz")
+    lib = PackedLibrary.load(GOLDEN / "pockets16.pmxlib")
+    models = [PharmacophoreModel.load(GOLDEN / "pockets16" / f"model_{k:02d}.pm") for k in range(16)]
+    dev = DeviceLibrary(lib)
+    handles = (ctypes.c_void_p * 16)(*[device_model(m).handle for m in models])
+    out = torch.empty(16 * len(lib), dtype=torch.float32, device="cuda")
+    status = torch.empty(len(lib), dtype=torch.int32, device="cuda")
+    w = (ctypes.c_float * 7)(*weights_vector(None))
+    _ffi.check(_ffi.load().pmx_score_multi(handles, 16, dev.handle, w, 0, len(lib), out.data_ptr(), status.data_ptr(), None))
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().reshape(16, -1).astype(np.float64)
+    assert np.all(status.cpu().numpy() == 0)
+    ref = d["score"]
+    zero = ref == 0
+    assert np.all(got[zero] == 0.0)
+    assert rel_err(got[~zero], ref[~zero]).max() < RTOL + 6e-8
+    assert np.count_nonzero(ref) > ref.size // 2
+
+
+def test_stress_config_at_full_size(oracle, monkeypatch):
+    """BASELINE.json configs[4] at its stated size: the 64-node model, 100 352 ligands x 64 conformers. Size-independent
+    properties (finite, non-negative, chunk-invariant, reproducible) and a 512-ligand sample against the CPU oracle; then
+    the fp32 vs fp16-coordinate sweep on 4 096 ligands with median / p95 / max error and the flip count written to
+    profiles/ (PMX_WRITE_PROFILES=1) or a temporary file."""
+    import tempfile
+
+    import torch
+
+    from pharmaconet_amd import PackedLibrary
+    from pharmaconet_amd.constants import weights_vector
+    from pharmaconet_amd.engine import DeviceLibrary
+    from pharmaconet_amd.synthetic import expand_library_on_device, synthetic_library
+
+    model, _, _, _ = load_golden("set_s64_c64")
+    assert model.flat.num_nodes == 64
+    base = synthetic_library(512, num_conformers=64, model_nodes=_model_nodes(model), active_fraction=0.2, seed=6464,
+                             max_nodes=32, conformer_noise=0.0)
+    offsets, data = expand_library_on_device(base, 196, "cuda", seed=6465)
+    lib = DeviceLibrary.from_device_buffers(offsets, data)
+    assert len(lib) == 100_352 and lib.max_conformers == 64
+    full = model.screen(lib).scores
+    assert torch.isfinite(full).all() and (full >= 0).all()
+    checksum = full.double().sum().item()
+    with monkeypatch.context() as mp:
+        mp.setenv("PMX_CHUNK", "17000")
+        again = model.screen(lib).scores
+    assert torch.equal(again, full) and again.double().sum().item() == checksum
+    off = offsets.cpu().numpy()
+    dat = data.cpu().numpy()
+    rng = np.random.default_rng(64)
+    pick = np.sort(rng.choice(len(lib), size=512, replace=False))
+    sample = PackedLibrary.from_records([dat[off[i] : off[i + 1]].tobytes() for i in pick])
+    ref = oracle.oracle_score(model.flat, sample, weights_vector(None), num_threads=os.cpu_count() or 8)
+    got = full[torch.from_numpy(pick).cuda()].cpu().numpy().astype(np.float64)
+    zero = ref == 0
+    assert np.all(got[zero] == 0.0)
+    assert rel_err(got[~zero], ref[~zero]).max() < RTOL + 6e-8
+    # fp16 coordinates (centred per ligand before rounding), everything else unchanged
+    n_sweep = 4096
+    recs = []
+    for i in range(n_sweep):
+        rec = bytearray(dat[off[i] : off[i + 1]].tobytes())
+        n, c, k = int.from_bytes(rec[0:2], "little"), int.from_bytes(rec[2:4], "little"), int.from_bytes(rec[4:6], "little")
+        o = (8 + n + k + 3) & ~3
+        xyz = np.frombuffer(bytes(rec[o : o + 12 * n * c]), dtype=np.float32).reshape(n, 3, c)
+        center = xyz.mean(axis=(0, 2), keepdims=True)
+        q = ((xyz - center).astype(np.float16).astype(np.float32) + center).astype(np.float32)
+        rec[o : o + 12 * n * c] = np.ascontiguousarray(q).tobytes()
+        recs.append(bytes(rec))
+    half = model.screen(PackedLibrary.from_records(recs)).scores.cpu().numpy().astype(np.float64)
+    f32 = full[:n_sweep].cpu().numpy().astype(np.float64)
+    nz = f32 > 0
+    err = rel_err(half[nz], f32[nz])
+    report = {
+        "config": "BASELINE.json configs[4]: model_stress64 (64 nodes), 64 conformers per ligand",
+        "ligands_scored_fp32": len(lib), "ligands_in_sweep": int(nz.sum()),
+        "coordinates": "centred per ligand, rounded to fp16, converted back to fp32; all arithmetic unchanged",
+        "rel_err_median": float(np.median(err)), "rel_err_p95": float(np.percentile(err, 95)), "rel_err_max": float(err.max()),
+        "flips_beyond_1e-3": int((err > 1e-3).sum()), "flips_beyond_1e-2": int((err > 1e-2).sum()),
+        "zero_vs_nonzero_changes": int(((half > 0) != (f32 > 0)).sum()),
+    }
+    target = REPO / "profiles" / "r2_fp16_sweep.json" if os.environ.get("PMX_WRITE_PROFILES") else tempfile.mktemp(suffix=".json")
+    with open(target, "w") as fh:
+        json.dump(report, fh, indent=1)
+    print(json.dumps(report))
+    assert report["rel_err_median"] < 1e-3 and report["flips_beyond_1e-2"] <= n_sweep // 50
+
+
+def test_topk_exchange_through_the_c_abi_single_rank():
+    """pmx_comm_* / pmx_topk_allgather (RCCL) with one rank: the all-gather is a copy, the merge is the ranking rule of
+    screening.py:70. (Two-rank behaviour of the merge is covered on CPU by tests/test_distributed.py with gloo.)"""
+    import torch
+
+    from pharmaconet_amd.distributed import TopkExchange, merge_topk
+
+    model, lib, _, _ = load_golden("set_c21_c8")
+    k = 40
+    res = model.screen(lib, topk=k, index_base=5000)
+    ex = TopkExchange("cuda:0")
+    top_s, top_i = ex.allgather(res.topk_scores, res.topk_indices, k)
+    torch.cuda.synchronize()
+    want_s, want_i = merge_topk(res.topk_scores.cpu().numpy(), res.topk_indices.cpu().numpy(), k)
+    assert top_i.cpu().numpy().tolist() == want_i.tolist()
+    np.testing.assert_array_equal(top_s.cpu().numpy(), want_s)
+    ex.close()

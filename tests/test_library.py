@@ -99,3 +99,29 @@ def test_limits_are_enforced():
     cl = ClusteredLigand(np.ones(1, np.uint8), np.zeros((1, 65, 3), np.float32), [[0]], ["Hydrophobic"], [0])
     with pytest.raises(ValueError):
         pack_clustered_ligand(cl)
+
+
+@pytest.mark.parametrize("name", ["set_6oim_c8", "set_6oim_c1", "set_6oim_c64", "set_c21_c8", "set_s64_c8"])
+def test_native_packer_matches_reference_ligandgraph(name):
+    """`pmx_pack_features` (csrc/pmx_pack.cpp, the C ABI's packer) on the same molecules: the whole library byte for byte,
+    whatever the number of threads."""
+    from pharmaconet_amd.library import pack_features_native
+
+    lib = PackedLibrary.load(GOLDEN / f"{name}.pmxlib")
+    mols = list(golden_molecules(name))
+    for threads in (1, 4):
+        got, status = pack_features_native(mols, threads=threads)
+        assert np.all(status == 0)
+        np.testing.assert_array_equal(got.offsets, lib.offsets)
+        assert got.data.tobytes() == lib.data.tobytes()
+
+
+def test_native_packer_marks_oversized_molecules():
+    from pharmaconet_amd.library import UNSUPPORTED_RECORD, LigandFeatures, pack_features_native
+
+    n = 70
+    big = LigandFeatures([17] * n + [6], [[n]] * n + [list(range(n))], [("Halogen", i, i) for i in range(n)], np.zeros((n + 1, 2, 3), np.float32))
+    small = LigandFeatures([6, 17], [[1], [0]], [("Halogen", 1, 1)], np.ones((2, 4, 3), np.float32))
+    lib, status = pack_features_native([small, big, small], threads=2)
+    assert status.tolist() == [0, 1, 0]
+    assert lib.record(1) == UNSUPPORTED_RECORD and lib.record(0) == lib.record(2) == pack_ligand(small)
