@@ -395,6 +395,8 @@ template <int G>
 static int table_phase(const pmx_model *model, const pmx_library *lib, const Weights &W, uint64_t lig0, uint32_t n,
                        int32_t *status, Slot &sl, hipStream_t q, int ws_num_cu) {
     const int Nm = model->dm.Nm;
+    bool zero_weight = false; // a type with weight 0 among the model's nodes
+    for (int m = 0; m < Nm; ++m) zero_weight = zero_weight || W.w[model->node_type[m]] == 0.f;
     if (sl.walked) HIPCHECK(hipStreamWaitEvent(q, sl.walk_done, 0)); // the slot's previous chunk has been walked
     sl.n = n;
     sl.lig0 = lig0;
@@ -477,8 +479,12 @@ static int table_phase(const pmx_model *model, const pmx_library *lib, const Wei
             const size_t model_lds2 = (size_t)Nm * (Nm + 1) * sizeof(float4) + 64 * 8 + 128 * 8;
             const int v2_waves = (int)std::min<size_t>(8, (kLdsPerCu - 1024 - model_lds2) / tables_v2_wave_bytes<G>());
             const size_t lds2 = model_lds2 + (size_t)v2_waves * tables_v2_wave_bytes<G>();
-            tables_kernel_v2<G><<<dim3((n + v2_waves - 1) / v2_waves), dim3(64 * v2_waves), lds2, q>>>(model->dm, lib->dl, W, lig0, n, status, sl.taboff, sl.arena,
-                                                                           sl.lists + (size_t)kNumBins * n, &sl.bins->count[kNumBins]);
+            if (zero_weight)
+                tables_kernel_v2<G, true><<<dim3((n + v2_waves - 1) / v2_waves), dim3(64 * v2_waves), lds2, q>>>(
+                    model->dm, lib->dl, W, lig0, n, status, sl.taboff, sl.arena, sl.lists + (size_t)kNumBins * n, &sl.bins->count[kNumBins]);
+            else
+                tables_kernel_v2<G, false><<<dim3((n + v2_waves - 1) / v2_waves), dim3(64 * v2_waves), lds2, q>>>(
+                    model->dm, lib->dl, W, lig0, n, status, sl.taboff, sl.arena, sl.lists + (size_t)kNumBins * n, &sl.bins->count[kNumBins]);
             bounds_kernel<G><<<dim3((n + 3) / 4), dim3(256), 0, q>>>(n, status, sl.taboff, sl.arena, (int)(env_long("PMX_TREE_FLAGS", 0) & 4),
                                                                      sl.lists + (size_t)kNumBins * n, &sl.bins->count[kNumBins]);
         }
@@ -489,8 +495,12 @@ static int table_phase(const pmx_model *model, const pmx_library *lib, const Wei
         if (model_lds + tables_v2_wave_bytes<G>() + 1024 > kLdsPerCu) return fail(PMX_ERR_INVALID, "model tables do not fit LDS");
         const int v2_waves = (int)std::min<size_t>(8, (kLdsPerCu - 1024 - model_lds) / tables_v2_wave_bytes<G>());
         const size_t lds2 = model_lds + (size_t)v2_waves * tables_v2_wave_bytes<G>();
-        tables_kernel_v2<G><<<dim3((n + v2_waves - 1) / v2_waves), dim3(64 * v2_waves), lds2, q>>>(
-            model->dm, lib->dl, W, lig0, n, status, sl.taboff, sl.arena, nullptr, nullptr);
+        if (zero_weight)
+            tables_kernel_v2<G, true><<<dim3((n + v2_waves - 1) / v2_waves), dim3(64 * v2_waves), lds2, q>>>(
+                model->dm, lib->dl, W, lig0, n, status, sl.taboff, sl.arena, nullptr, nullptr);
+        else
+            tables_kernel_v2<G, false><<<dim3((n + v2_waves - 1) / v2_waves), dim3(64 * v2_waves), lds2, q>>>(
+                model->dm, lib->dl, W, lig0, n, status, sl.taboff, sl.arena, nullptr, nullptr);
         bounds_kernel<G><<<dim3((n + 3) / 4), dim3(256), 0, q>>>(n, status, sl.taboff, sl.arena,
                                                                  (int)(env_long("PMX_TREE_FLAGS", 0) & 4), nullptr, nullptr);
         HIPCHECK(hipGetLastError());
@@ -636,7 +646,9 @@ static int score_chunks(const pmx_model *const *models, int n_models, const pmx_
     uint32_t cap_max = std::min<uint32_t>(chunk_size(), ws.chunk_cap);
     const uint32_t attr_bit = 1u << __builtin_ctz((unsigned)G);
     if (!(ws.lds_attr_set & attr_bit)) { // once per device (the workspace is per device) and group width
-        HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&tables_kernel_v2<G>),
+        HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&tables_kernel_v2<G, false>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));
+        HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&tables_kernel_v2<G, true>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));
         HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&tree_kernel<G, false>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));

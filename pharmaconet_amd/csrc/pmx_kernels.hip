@@ -278,7 +278,7 @@ __host__ __device__ constexpr uint32_t tables_v2_wave_bytes() {
     return sizeof(WaveLevels) + kTabEntryChunk * G * 8 + kTabEntryChunk; // levels, accumulators, near-entry list
 }
 
-template <int G>
+template <int G, bool ZW /* some type weight is 0: node pairs whose weights sum to 0 score NaN (match_utils.py:50-52) */>
 __global__ __launch_bounds__(512, 6) void tables_kernel_v2(DevModel M, DevLibrary lib, Weights W, uint64_t first, uint32_t count,
                                                         const int32_t *status, const uint64_t *taboff, uint8_t *arena,
                                                         const uint32_t *list, const uint32_t *list_count) {
@@ -314,6 +314,7 @@ __global__ __launch_bounds__(512, 6) void tables_kernel_v2(DevModel M, DevLibrar
     // model nodes whose type has a non-zero weight: a node-pair term whose weights sum to 0 is 0 * (1 / 0) = NaN in the
     // reference (match_utils.py:50-52,69)
     const unsigned long long nzw = __ballot(lane < Nm && W.w[M.node_type[lane < Nm ? lane : 0]] != 0.f);
+    constexpr bool some_zero = ZW;
     uint64_t gid = (uint64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6); // ligand of this wave
     if (list) { // only the listed ligands (one pass: the list is short - tables too large for tables_kernel_v3)
         if (gid >= *list_count) return;
@@ -395,7 +396,7 @@ __global__ __launch_bounds__(512, 6) void tables_kernel_v2(DevModel M, DevLibrar
                     int np = 0;
                     const int mn = cluster_node_pair(M, tab, cnodes, tnodes, a, a, tm[si + u], tm[si + v], d, acc, np);
                     if (!mn) continue;
-                    const bool zw = !(cnodes[a] & tnodes[tm[si + u]] & nzw) || !(cnodes[a] & tnodes[tm[si + v]] & nzw);
+                    const bool zw = some_zero && (!(cnodes[a] & tnodes[tm[si + u]] & nzw) || !(cnodes[a] & tnodes[tm[si + v]] & nzw));
                     atomicAdd(&acc_score[e * G + c], zw ? __builtin_nanf("") : acc / (float)mn);
                 }
             }
@@ -454,7 +455,7 @@ __global__ __launch_bounds__(512, 6) void tables_kernel_v2(DevModel M, DevLibrar
                     int np = 0;
                     const int mn = cluster_node_pair(M, tab, cnodes, tnodes, a, b, tm[si + u], tm[sj + v], d, acc, np);
                     if (!mn) continue;
-                    const bool zw = !(cnodes[a] & tnodes[tm[si + u]] & nzw) || !(cnodes[b] & tnodes[tm[sj + v]] & nzw);
+                    const bool zw = some_zero && (!(cnodes[a] & tnodes[tm[si + u]] & nzw) || !(cnodes[b] & tnodes[tm[sj + v]] & nzw));
                     atomicAdd(&acc_score[e * G + c], zw ? __builtin_nanf("") : acc / (float)mn);
                     if (2 * np < mn) atomicAdd(&acc_fail[e * G + c], 1u); // num_pass < num_match * 0.5 (match_utils.py:61)
                 }

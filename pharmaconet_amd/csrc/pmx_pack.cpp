@@ -12,6 +12,7 @@
 #include <cstdint>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <thread>
 #include <utility>
 #include <vector>
@@ -57,29 +58,47 @@ struct Mol {
 
 // One molecule -> one record at `out` (capacity `cap`); returns the record size, 0 if it does not fit the structural
 // limits of include/pmx.h (the caller emits the header-only "unsupported" record), or -1 if cap is too small.
+// Per-thread scratch reused from molecule to molecule: after the first few molecules packing allocates nothing (the
+// packer runs on every host core at once; a general-purpose allocator would serialise them).
+struct Scratch {
+    std::vector<Node> pool; // node objects with their vectors' capacity kept
+    std::vector<int> node_dict[PMX_NUM_TYPES];
+    std::vector<std::pair<int, std::vector<int>>> keys; // (is_tuple, atom indices as given) of node i
+};
+
 int64_t pack_one(const Mol &m, uint8_t *out, uint64_t cap) {
-    std::vector<Node> nodes;
-    std::vector<int> node_dict[PMX_NUM_TYPES]; // nodes of each type in order of appearance (duplicates possible)
-    std::map<std::pair<int, std::vector<int>>, int> by_key; // (is_tuple, atom indices as given) -> node
+    static thread_local Scratch S;
+    if ((int)S.pool.size() < m.n_feat) S.pool.resize(m.n_feat);
+    if ((int)S.keys.size() < m.n_feat) S.keys.resize(m.n_feat);
+    std::vector<Node> &nodes = S.pool; // nodes [0, n)
+    int n = 0;
+    std::vector<int> *node_dict = S.node_dict; // nodes of each type in order of appearance (duplicates possible)
+    for (int t = 0; t < PMX_NUM_TYPES; ++t) node_dict[t].clear();
     // __add_nodes (ligand.py:134-156)
     for (int f = 0; f < m.n_feat; ++f) {
         const int t = m.ftype[f];
         const bool key_tuple = m.fflags[f] & 1;
-        std::vector<int> key(m.fatoms + m.fatom_off[f], m.fatoms + m.fatom_off[f + 1]);
-        auto it = by_key.find(std::make_pair((int)key_tuple, key));
-        if (it != by_key.end()) {
-            nodes[it->second].types |= 1u << t;
-            node_dict[t].push_back(it->second);
+        const int32_t *kb = m.fatoms + m.fatom_off[f], *ke = m.fatoms + m.fatom_off[f + 1];
+        int found = -1;
+        for (int i = 0; i < n && found < 0; ++i) // by_key lookup: same tuple-ness, same indices in the same order
+            if (S.keys[i].first == (int)key_tuple && S.keys[i].second.size() == (size_t)(ke - kb) && std::equal(kb, ke, S.keys[i].second.begin())) found = i;
+        if (found >= 0) {
+            nodes[found].types |= 1u << t;
+            node_dict[t].push_back(found);
             continue;
         }
-        Node nw;
+        const int ni = n;
+        Node &nw = nodes[ni];
         nw.types = 1u << t;
-        nw.atoms = key;
+        nw.atoms.assign(kb, ke);
         std::sort(nw.atoms.begin(), nw.atoms.end());
         nw.atoms.erase(std::unique(nw.atoms.begin(), nw.atoms.end()), nw.atoms.end());
         nw.center_is_tuple = (m.fflags[f] >> 1) & 1;
         nw.centers.assign(m.fcenters + m.fcenter_off[f], m.fcenters + m.fcenter_off[f + 1]);
-        const int ni = (int)nodes.size();
+        nw.group.clear();
+        nw.min_dependence = -1;
+        S.keys[ni].first = (int)key_tuple;
+        S.keys[ni].second.assign(kb, ke);
         for (int oi = 0; oi < ni; ++oi) { // old.add_neighbors(new) (ligand.py:303-329); old's types as they are NOW
             Node &old = nodes[oi];
             if ((old.types & T_HYDROPHOBIC) && (nw.types & T_AROMATIC)) {
@@ -92,11 +111,9 @@ int64_t pack_one(const Mol &m, uint8_t *out, uint64_t cap) {
                 if (subset(nw.atoms, old.atoms)) add_dep(nw, oi);
             }
         }
-        nodes.push_back(std::move(nw));
+        ++n;
         node_dict[t].push_back(ni);
-        by_key.emplace(std::make_pair((int)key_tuple, std::move(key)), ni);
     }
-    const int n = (int)nodes.size();
     auto heavy_nbrs = [&](int atom) { return std::make_pair(m.nbr + m.nbr_off[atom], m.nbr + m.nbr_off[atom + 1]); };
 
     // __group_nodes, functional groups (ligand.py:158-192): atoms bonded to the same single heavy neighbour
@@ -277,7 +294,8 @@ extern "C" int pmx_pack_features(const pmx_feature_batch *b, int threads, uint64
         const uint64_t c = (uint64_t)std::max(b->n_conf[i], 1);
         room[i + 1] = room[i] + ((8 + 2 * nf + 3 + 12 * nf * c + 15) & ~15ull) + 16;
     }
-    std::vector<uint8_t> scratch(room[n]);
+    std::unique_ptr<uint8_t[]> scratch_mem(new uint8_t[room[n] + 16]); // not zero-filled: pack_one clears what it writes
+    uint8_t *scratch = scratch_mem.get();
     std::vector<int64_t> sizes(n, 0);
     std::atomic<uint64_t> next{0};
     auto work = [&]() {
@@ -300,9 +318,9 @@ extern "C" int pmx_pack_features(const pmx_feature_batch *b, int threads, uint64
                 m.fatoms = b->feat_atoms;
                 m.fcenters = b->feat_centers;
                 m.pos = b->positions + b->pos_off[i];
-                int64_t sz = pack_one(m, scratch.data() + room[i], room[i + 1] - room[i]);
+                int64_t sz = pack_one(m, scratch + room[i], room[i + 1] - room[i]);
                 if (sz <= 0) { // outside the structural limits: header-only record, reported per ligand (PMX_LIGAND_UNSUPPORTED)
-                    std::memset(scratch.data() + room[i], 0, 16);
+                    std::memset(scratch + room[i], 0, 16);
                     sz = 16;
                     if (status_out) status_out[i] = 1;
                 } else if (status_out) {
@@ -325,6 +343,17 @@ extern "C" int pmx_pack_features(const pmx_feature_batch *b, int threads, uint64
     offsets_out[n] = total;
     *data_bytes = total;
     if (total > data_cap) return data_out ? pmx_topk_fail(PMX_ERR_INVALID, "data_out too small (data_bytes holds the size needed)") : PMX_OK;
-    for (uint64_t i = 0; i < n; ++i) std::memcpy(data_out + offsets_out[i], scratch.data() + room[i], (size_t)sizes[i]);
+    next = 0;
+    auto compact = [&]() {
+        for (;;) {
+            const uint64_t i0 = next.fetch_add(1024);
+            if (i0 >= n) break;
+            for (uint64_t i = i0; i < std::min(n, i0 + 1024); ++i) std::memcpy(data_out + offsets_out[i], scratch + room[i], (size_t)sizes[i]);
+        }
+    };
+    pool.clear();
+    for (int t = 1; t < nt; ++t) pool.emplace_back(compact);
+    compact();
+    for (auto &t : pool) t.join();
     return PMX_OK;
 }

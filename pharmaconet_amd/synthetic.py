@@ -347,6 +347,7 @@ def synthetic_library(
     seed: int = BASE_SEED,
     max_nodes: int = 32,
     conformer_noise: float = 0.45,
+    molecules_out: list | None = None,
 ) -> PackedLibrary:
     """Ligands `first .. first + count` of the synthetic library `seed` (molecule-level generator).
 
@@ -368,6 +369,8 @@ def synthetic_library(
                 break
             n_fragments = max(1, (n_fragments or 8) - 2)
         records.append(rec)
+        if molecules_out is not None:
+            molecules_out.append(lig)
     return PackedLibrary.from_records(records)
 
 

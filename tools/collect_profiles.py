@@ -14,8 +14,11 @@ import shutil
 import sys
 from pathlib import Path
 
+import os
+
 REPO = Path(__file__).resolve().parents[1]
 PROF = REPO / "profiles"
+TAG = os.environ.get("PMX_PROFILE_TAG", "r2")  # file name prefix: the round the profiles belong to
 
 
 def short(name):
@@ -26,13 +29,13 @@ def main():
     bench, kstats, fetch_dir, write_dir, sq_dir = (Path(a) for a in sys.argv[1:6])
     n_lig = int(sys.argv[6]) if len(sys.argv) > 6 else 200704
     PROF.mkdir(exist_ok=True)
-    shutil.copy(bench, PROF / "r1_bench_1M.json")
+    shutil.copy(bench, PROF / f"{TAG}_bench_1M.json")
     # kernel stats: keep pmx kernels and the five largest others
     rows = list(csv.reader(open(kstats)))
     keep = [rows[0]] + [r for r in rows[1:] if "pmx::" in r[0] or "cub" in r[0].lower()]
-    csv.writer(open(PROF / "r1_kernel_stats.csv", "w", newline="")).writerows(keep)
+    csv.writer(open(PROF / f"{TAG}_kernel_stats.csv", "w", newline="")).writerows(keep)
     res = {}
-    for d, ctr, out in ((fetch_dir, "FETCH_SIZE", "r1_pmc_fetch_size.csv"), (write_dir, "WRITE_SIZE", "r1_pmc_write_size.csv")):
+    for d, ctr, out in ((fetch_dir, "FETCH_SIZE", f"{TAG}_pmc_fetch_size.csv"), (write_dir, "WRITE_SIZE", f"{TAG}_pmc_write_size.csv")):
         f = next(d.glob("*counter_collection.csv"))
         rows = list(csv.reader(open(f)))
         ki = rows[0].index("Kernel_Name")
@@ -61,15 +64,15 @@ def main():
             "fetch_kib_raw": f, "write_kib": w, "hbm_bytes_per_ligand": (2 * f + w) * 1024 / n_lig,
             "launches": res["FETCH_SIZE"][1][k],
         }
-    json.dump(out, open(PROF / "r1_hbm_traffic.json", "w"), indent=1)
+    json.dump(out, open(PROF / f"{TAG}_hbm_traffic.json", "w"), indent=1)
     sq = collections.defaultdict(lambda: collections.defaultdict(float))
     for row in csv.DictReader(open(next(sq_dir.glob("*counter_collection.csv")))):
         k = row["Kernel_Name"]
-        if "pmx::" in k and ("tree_kernel" in k or "tables_kernel" in k or "bounds_kernel" in k):
+        if "pmx::" in k and ("tree_kernel" in k or "tables_kernel" in k or "bounds_kernel" in k or "match_kernel" in k or "coop_kernel" in k):
             sq[short(k).replace("pmx::", "")][row["Counter_Name"]] += float(row["Counter_Value"])
     json.dump({"source": "rocprofv3 --pmc SQ_* (one pass) of bench.py --ligands 200000 --steps 1 --warmup 0; SQ_WAVE_CYCLES, "
                          "SQ_WAIT_* and SQ_ACTIVE_* count quad-cycles", "counters": sq},
-              open(PROF / "r1_pmc_sq_summary.json", "w"), indent=1)
+              open(PROF / f"{TAG}_pmc_sq_summary.json", "w"), indent=1)
     for k, v in out["kernels"].items():
         print(f"{k:40s} fetch {v['fetch_kib_raw'] / 1e6:8.3f} GiB  write {v['write_kib'] / 1e6:8.3f} GiB  {v['hbm_bytes_per_ligand']:10.0f} B/ligand")
     for k, v in sq.items():
