@@ -159,6 +159,7 @@ def main():
     ap.add_argument("--topk", type=int, default=1000)
     ap.add_argument("--pockets", type=int, default=1, help="score this many distinct pockets (1..16) against the shared library (BASELINE configs[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-serial-leg", action="store_true", help="skip the extra untimed pass that measures every kernel alone (profiling runs)")
     args = ap.parse_args()
 
     import torch
@@ -245,7 +246,7 @@ def main():
     # One extra, untimed pass with the chunk pipelines serialised (one pipeline, table and tree phases on one stream): the
     # duration of every kernel when it has the GPU to itself, quoted beside the co-running figures of the timed steps.
     serial = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_serial_leg and os.environ.get("PMX_ENGINE", "1") == "1":
         saved = {k: os.environ.get(k) for k in ("PMX_PIPELINES", "PMX_OVERLAP")}
         os.environ["PMX_PIPELINES"], os.environ["PMX_OVERLAP"] = "1", "0"
         try:
@@ -372,7 +373,7 @@ def main():
             }
         else:
             out["cpu_baseline"] = None
-        if world == 1:
+        if world == 1 and not args.no_serial_leg:
             try:
                 out["end_to_end"] = end_to_end(molecules, lib, data, ms_per_step, n_conf_total * len(pockets))
             except Exception as e:  # never lose the bench line over the side measurement

@@ -174,6 +174,9 @@ typedef struct {
 int pmx_pack_features(const pmx_feature_batch *batch, int threads, uint64_t *offsets_out, uint8_t *data_out, uint64_t data_cap,
                       uint64_t *data_bytes, int32_t *status_out);
 
+/* Frees the scoring workspaces libpmx keeps between calls on `device` (synchronises the device first). */
+int pmx_release_workspaces(int device);
+
 /* Timing / diagnostics of the last pmx_score on this thread: kernel-time split measured with HIP events. */
 typedef struct {
     double ms_sizes, ms_tables, ms_tree, ms_tasks, ms_total; /* sizes+scan | tables_kernel | tree_kernel per ligand | task rounds */

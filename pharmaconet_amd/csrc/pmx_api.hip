@@ -1009,5 +1009,50 @@ static int fused_stats(pmx_score_stats *out) {
     return PMX_OK;
 }
 
+// Frees the cached scoring workspaces of `device` (table arenas, task queues, class lists, fused-engine buffers): they are
+// grown on demand and kept between calls, which is what a screening loop wants and what a long-lived host program that
+// is done screening does not.
+int pmx_topk_release(int device);
+extern "C" int pmx_release_workspaces(int device) {
+    HIPCHECK(hipSetDevice(device));
+    HIPCHECK(hipDeviceSynchronize());
+    std::lock_guard<std::mutex> lock(g_mu);
+    for (auto it = g_ws.begin(); it != g_ws.end();) {
+        if (it->first.first != device) {
+            ++it;
+            continue;
+        }
+        Workspace &w = it->second;
+        for (Slot &sl : w.slot) {
+            for (void *q : {(void *)sl.units, (void *)sl.status, (void *)sl.taboff, (void *)sl.arena, (void *)sl.meta, (void *)sl.bins, (void *)sl.caps_dev,
+                            (void *)sl.lists, (void *)sl.wtab, (void *)sl.bstats, (void *)sl.bestbuf, (void *)sl.deferred})
+                if (q) (void)hipFree(q);
+            if (sl.meta_host) (void)hipHostFree(sl.meta_host);
+            for (auto &ev : sl.ev)
+                if (ev) (void)hipEventDestroy(ev);
+            if (sl.tables_done) (void)hipEventDestroy(sl.tables_done);
+            if (sl.walk_done) (void)hipEventDestroy(sl.walk_done);
+        }
+        if (w.queue) (void)hipFree(w.queue);
+        if (w.side) (void)hipStreamDestroy(w.side);
+        if (w.own) (void)hipStreamDestroy(w.own);
+        if (w.entry) (void)hipEventDestroy(w.entry);
+        if (w.done) (void)hipEventDestroy(w.done);
+        it = g_ws.erase(it);
+    }
+    for (auto it = g_fused.begin(); it != g_fused.end();) {
+        if (it->first.first != device) {
+            ++it;
+            continue;
+        }
+        FusedWs &w = it->second;
+        for (void *q : {(void *)w.bins, (void *)w.caps_dev, (void *)w.lists, (void *)w.wtab, (void *)w.stats, (void *)w.arena, (void *)w.roots})
+            if (q) (void)hipFree(q);
+        if (g_last_fused == &w) g_last_fused = nullptr;
+        it = g_fused.erase(it);
+    }
+    return pmx_topk_release(device);
+}
+
 // error hook for pmx_topk.hip (keeps the thread-local message in one translation unit)
 int pmx_topk_fail(int code, const char *msg) { return fail(code, "%s", msg); }

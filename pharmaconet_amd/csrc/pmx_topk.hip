@@ -105,6 +105,19 @@ extern "C" int pmx_topk(const float *scores_dev, const uint64_t *index_dev, uint
     return PMX_OK;
 }
 
+int pmx_topk_release(int device) {
+    std::lock_guard<std::mutex> lock(g_topk_mu);
+    for (auto it = g_topk_ws.begin(); it != g_topk_ws.end();) {
+        if (it->first.first == device) {
+            if (it->second.buf) (void)hipFree(it->second.buf);
+            it = g_topk_ws.erase(it);
+        } else {
+            ++it;
+        }
+    }
+    return PMX_OK;
+}
+
 // ------------------------------------------------------------------------------------------ RCCL exchange
 // The one data-path collective of a sharded screen (screening.py:66-70 done by ranks instead of a process pool): every
 // rank's k best (score, global index) pairs are all-gathered over RCCL (xGMI inside a node) and merged identically on

@@ -247,5 +247,10 @@ def last_score_stats() -> dict:
     return {name: getattr(st, name) for name, _ in st._fields_}
 
 
+def release_workspaces(device=None) -> None:
+    """Free the device buffers libpmx caches between scoring calls (`pmx_release_workspaces`)."""
+    _ffi.check(_ffi.load().pmx_release_workspaces(_device_index(device)))
+
+
 def set_profiling(enabled: bool) -> None:
     _ffi.check(_ffi.load().pmx_set_profiling(1 if enabled else 0))

@@ -268,3 +268,16 @@ def test_topk_exchange_through_the_c_abi_single_rank():
     assert top_i.cpu().numpy().tolist() == want_i.tolist()
     np.testing.assert_array_equal(top_s.cpu().numpy(), want_s)
     ex.close()
+
+
+def test_release_workspaces_and_score_again():
+    """pmx_release_workspaces frees what libpmx caches between calls; scoring afterwards rebuilds it and gives the same bits."""
+    import torch
+
+    from pharmaconet_amd import engine
+
+    model, lib, weights, d = load_golden("set_6oim_c5")
+    a = model.screen(lib, weights=weights, topk=5)
+    engine.release_workspaces()
+    b = model.screen(lib, weights=weights, topk=5)
+    assert torch.equal(a.scores, b.scores) and torch.equal(a.topk_indices, b.topk_indices)
