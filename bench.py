@@ -294,7 +294,7 @@ def main():
         traffic = None
         try:
             pmc = json.loads((REPO / "profiles" / "r2_hbm_traffic.json").read_text())
-            key = {"tables_kernel_v2": "pmx::tables_kernel_v2<8>", "tree_kernel<G,false>": "pmx::tree_kernel<8, false>",
+            key = {"tables_kernel_v2": "pmx::tables_kernel_v2<8, false>", "tree_kernel<G,false>": "pmx::tree_kernel<8, false>",
                    "tree_kernel<G,true>": "pmx::tree_kernel<8, true>"}[dominant.split(" ")[0]]
             if args.conformers == 8:
                 traffic = pmc["kernels"][key]["hbm_bytes_per_ligand"] * ligands_per_launch

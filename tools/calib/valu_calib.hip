@@ -99,7 +99,7 @@ __device__ __forceinline__ void term(float d, float mean, float s, float T, floa
 
 // edge parameters in registers: 8 terms per pass, parameters perturbed per pass so nothing folds
 __global__ void k_term_reg(float *out, const float4 *tab, int n_terms) {
-    const float d = 3.0f + 0.01f * (float)threadIdx.x;
+    float d = 3.0f + 0.01f * (float)threadIdx.x;
     float4 e[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) e[i] = tab[i];
@@ -108,6 +108,7 @@ __global__ void k_term_reg(float *out, const float4 *tab, int n_terms) {
     for (int it = 0; it < n_terms / 8; ++it) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) term(d, e[i].x, e[i].y, e[i].z, e[i].w, acc, np);
+        d += 1e-4f; // one extra plain op per 8 terms: keeps the terms from being hoisted out of the loop
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = acc + (float)np;
 }
