@@ -278,7 +278,7 @@ struct Slot {
     uint64_t *taboff = nullptr;
     uint8_t *arena = nullptr;
     size_t arena_cap = 0;
-    uint32_t *meta = nullptr;      // device: [0] max levels, [1] fetch counter, [2..3] table bytes (u64), [4] task queue tail, [5] queue overflow
+    uint32_t *meta = nullptr;      // device: [0] max levels, [1] fetch counter, [2..3] table bytes (u64), [4] task queue tail, [5] queue overflow, [6..7] tree steps, [8] / [9] ligand cursors of the table kernel
     uint32_t *meta_host = nullptr; // pinned mirror
     BinInfo *bins = nullptr;               // table phase: LDS size classes of the chunk's ligands
     uint32_t *caps_dev = nullptr;
@@ -427,7 +427,8 @@ static int table_phase(const pmx_model *model, const pmx_library *lib, const Wei
         sl.arena_cap = want;
     }
     if (g_profiling) HIPCHECK(hipEventRecord(sl.ev[1], q));
-    if (sl.table_total > 0 && env_long("PMX_TABLES", 2) == 3) {
+    const long tables_version = env_long("PMX_TABLES", 2);
+    if (sl.table_total > 0 && (tables_version == 3 || tables_version == 4)) {
         // tables_kernel_v3: ligands binned by the LDS their tables need, one persistent launch per size class
         const int K = model->dm.K;
         const uint32_t model_lds = model_lds_bytes(Nm, K);
@@ -466,25 +467,47 @@ static int table_phase(const pmx_model *model, const pmx_library *lib, const Wei
         const int num_cu = ws_num_cu;
         for (int b = kNumBins - 1; b >= 0; --b) {
             if (b > 0 && caps[b] == caps[b - 1]) continue;
-            const uint32_t waves = std::max<uint32_t>(1, std::min<uint32_t>(16, ((uint32_t)kLdsPerCu - model_lds) / caps[b]));
             mp.list = sl.lists + (size_t)b * n;
             mp.bin = (uint32_t)b;
             mp.wave_bytes = caps[b];
-            const size_t lds = model_lds + (size_t)waves * caps[b];
-            tables_kernel_v3<G><<<dim3(num_cu), dim3(64 * waves), lds, q>>>(mp);
+            if (tables_version == 3) {
+                const uint32_t waves = std::max<uint32_t>(1, std::min<uint32_t>(16, ((uint32_t)kLdsPerCu - model_lds) / caps[b]));
+                const size_t lds = model_lds + (size_t)waves * caps[b];
+                tables_kernel_v3<G><<<dim3(num_cu), dim3(64 * waves), lds, q>>>(mp);
+            } else {
+                // a team of waves per ligand: the smallest team that still fills the CU (<= 32 waves) given the LDS per block
+                const uint32_t small = 64 * 8 + 128 * 8 + (uint32_t)round16((uint64_t)K * K * 8) + 16;
+                const uint32_t helper = 2 * kPairBuf + 32 * kListSlots;
+                uint32_t team = 2, best_waves = 0, blocks = 1;
+                for (uint32_t t : {2u, 4u, 8u, 16u}) {
+                    const uint32_t lds_t = small + caps[b] + (t - 1) * helper;
+                    if (lds_t > kLdsPerCu) break;
+                    const uint32_t fit = std::min<uint32_t>((uint32_t)kLdsPerCu / lds_t, 32u / t);
+                    const uint32_t wv = fit * t;
+                    if (wv > best_waves) {
+                        best_waves = wv;
+                        team = t;
+                        blocks = fit;
+                    }
+                    if (wv >= (uint32_t)std::max<long>(8, env_long("PMX_TEAM_WAVES", 24))) break;
+                }
+                const size_t lds = small + caps[b] + (size_t)(team - 1) * helper;
+                tables_kernel_v4<G><<<dim3(num_cu * blocks), dim3(64 * team), lds, q>>>(mp);
+            }
         }
         HIPCHECK(hipGetLastError());
         // tables beyond the largest class: the generic kernel on those ligands only
         {
             const size_t model_lds2 = (size_t)Nm * (Nm + 1) * sizeof(float4) + 64 * 8 + 128 * 8;
-            const int v2_waves = (int)std::min<size_t>(8, (kLdsPerCu - 1024 - model_lds2) / tables_v2_wave_bytes<G>());
-            const size_t lds2 = model_lds2 + (size_t)v2_waves * tables_v2_wave_bytes<G>();
+            const int v2_waves = (int)std::min<size_t>(8, (kLdsPerCu - 1024 - model_lds2) / tables_v2_wave_bytes<G>(model->dm.K));
+            const size_t lds2 = model_lds2 + (size_t)v2_waves * tables_v2_wave_bytes<G>(model->dm.K);
+            const unsigned v2_blocks = (unsigned)std::min<uint64_t>((n + v2_waves - 1) / v2_waves, (uint64_t)num_cu * 4);
             if (zero_weight)
-                tables_kernel_v2<G, true><<<dim3((n + v2_waves - 1) / v2_waves), dim3(64 * v2_waves), lds2, q>>>(
-                    model->dm, lib->dl, W, lig0, n, status, sl.taboff, sl.arena, sl.lists + (size_t)kNumBins * n, &sl.bins->count[kNumBins]);
+                tables_kernel_v2<G, true><<<dim3(v2_blocks), dim3(64 * v2_waves), lds2, q>>>(
+                    model->dm, lib->dl, W, lig0, n, status, sl.taboff, sl.arena, sl.lists + (size_t)kNumBins * n, &sl.bins->count[kNumBins], sl.meta + 9);
             else
-                tables_kernel_v2<G, false><<<dim3((n + v2_waves - 1) / v2_waves), dim3(64 * v2_waves), lds2, q>>>(
-                    model->dm, lib->dl, W, lig0, n, status, sl.taboff, sl.arena, sl.lists + (size_t)kNumBins * n, &sl.bins->count[kNumBins]);
+                tables_kernel_v2<G, false><<<dim3(v2_blocks), dim3(64 * v2_waves), lds2, q>>>(
+                    model->dm, lib->dl, W, lig0, n, status, sl.taboff, sl.arena, sl.lists + (size_t)kNumBins * n, &sl.bins->count[kNumBins], sl.meta + 9);
             bounds_kernel<G><<<dim3((n + 3) / 4), dim3(256), 0, q>>>(n, status, sl.taboff, sl.arena, (int)(env_long("PMX_TREE_FLAGS", 0) & 4),
                                                                      sl.lists + (size_t)kNumBins * n, &sl.bins->count[kNumBins]);
         }
@@ -492,15 +515,19 @@ static int table_phase(const pmx_model *model, const pmx_library *lib, const Wei
     } else if (sl.table_total > 0) {
         // <= 8 ligands (waves) per block share one staged model table; the 160 KB of LDS always hold at least one
         const size_t model_lds = (size_t)Nm * (Nm + 1) * sizeof(float4) + 64 * 8 + 128 * 8; // edge table + one neutral column
-        if (model_lds + tables_v2_wave_bytes<G>() + 1024 > kLdsPerCu) return fail(PMX_ERR_INVALID, "model tables do not fit LDS");
-        const int v2_waves = (int)std::min<size_t>(8, (kLdsPerCu - 1024 - model_lds) / tables_v2_wave_bytes<G>());
-        const size_t lds2 = model_lds + (size_t)v2_waves * tables_v2_wave_bytes<G>();
+        if (model_lds + tables_v2_wave_bytes<G>(model->dm.K) + 1024 > kLdsPerCu) return fail(PMX_ERR_INVALID, "model tables do not fit LDS");
+        const int v2_waves = (int)std::min<size_t>((size_t)env_long("PMX_V2_WAVES", 8), (kLdsPerCu - 1024 - model_lds) / tables_v2_wave_bytes<G>(model->dm.K));
+        size_t lds2 = model_lds + (size_t)v2_waves * tables_v2_wave_bytes<G>(model->dm.K);
+        lds2 = std::max<size_t>(lds2, (size_t)env_long("PMX_V2_LDS_MIN", 0));
+        // persistent blocks: as many as the CUs hold at once (PMX_V2_BLOCKS per CU), fed from the cursor in meta[8]
+        const unsigned v2_blocks = (unsigned)std::min<uint64_t>((n + v2_waves - 1) / v2_waves,
+                                                                (uint64_t)ws_num_cu * (uint64_t)std::max<long>(1, env_long("PMX_V2_BLOCKS", 4)));
         if (zero_weight)
-            tables_kernel_v2<G, true><<<dim3((n + v2_waves - 1) / v2_waves), dim3(64 * v2_waves), lds2, q>>>(
-                model->dm, lib->dl, W, lig0, n, status, sl.taboff, sl.arena, nullptr, nullptr);
+            tables_kernel_v2<G, true><<<dim3(v2_blocks), dim3(64 * v2_waves), lds2, q>>>(
+                model->dm, lib->dl, W, lig0, n, status, sl.taboff, sl.arena, nullptr, nullptr, sl.meta + 8);
         else
-            tables_kernel_v2<G, false><<<dim3((n + v2_waves - 1) / v2_waves), dim3(64 * v2_waves), lds2, q>>>(
-                model->dm, lib->dl, W, lig0, n, status, sl.taboff, sl.arena, nullptr, nullptr);
+            tables_kernel_v2<G, false><<<dim3(v2_blocks), dim3(64 * v2_waves), lds2, q>>>(
+                model->dm, lib->dl, W, lig0, n, status, sl.taboff, sl.arena, nullptr, nullptr, sl.meta + 8);
         bounds_kernel<G><<<dim3((n + 3) / 4), dim3(256), 0, q>>>(n, status, sl.taboff, sl.arena,
                                                                  (int)(env_long("PMX_TREE_FLAGS", 0) & 4), nullptr, nullptr);
         HIPCHECK(hipGetLastError());
@@ -652,6 +679,8 @@ static int score_chunks(const pmx_model *const *models, int n_models, const pmx_
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));
         HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&tree_kernel<G, false>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));
+        HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&tables_kernel_v3<G>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));
+        HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&tables_kernel_v4<G>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));
         HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&tree_kernel<G, true>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));
         ws.lds_attr_set |= attr_bit;

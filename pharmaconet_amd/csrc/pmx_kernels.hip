@@ -268,31 +268,41 @@ struct WaveLevels { // per wave, in LDS
     uint8_t start[PMX_MAX_LEVELS];
     uint8_t end[PMX_MAX_LEVELS];
     uint8_t k[PMX_MAX_LEVELS];
-    uint8_t pad[4];
-    uint8_t candlist[PMX_MAX_LEVELS][PMX_MAX_MODEL_CLUSTERS]; // slot -> model cluster id
 };
 static_assert(sizeof(WaveLevels) % 16 == 0, "WaveLevels alignment");
 
+// candidate slot -> model cluster id, [PMX_MAX_LEVELS][stride]: a level has at most K candidates, so the stride follows the
+// model (the wave's LDS footprint decides how many waves a CU holds: 3.5 KB instead of 6.9 KB at K = 11)
+__host__ __device__ constexpr uint32_t tables_v2_cand_stride(int K) { return (uint32_t)((K + 3) & ~3); }
+
 template <int G>
-__host__ __device__ constexpr uint32_t tables_v2_wave_bytes() {
-    return sizeof(WaveLevels) + kTabEntryChunk * G * 8 + kTabEntryChunk; // levels, accumulators, near-entry list
+__host__ __device__ constexpr uint32_t tables_v2_wave_bytes(int K) {
+    // levels, candidate lists, accumulators, near-entry list
+    return sizeof(WaveLevels) + PMX_MAX_LEVELS * tables_v2_cand_stride(K) + kTabEntryChunk * G * 8 + kTabEntryChunk;
 }
 
+#ifndef PMX_V2_MINWAVES
+#define PMX_V2_MINWAVES 6
+#endif
+
 template <int G, bool ZW /* some type weight is 0: node pairs whose weights sum to 0 score NaN (match_utils.py:50-52) */>
-__global__ __launch_bounds__(512, 6) void tables_kernel_v2(DevModel M, DevLibrary lib, Weights W, uint64_t first, uint32_t count,
+__global__ __launch_bounds__(512, PMX_V2_MINWAVES) void tables_kernel_v2(DevModel M, DevLibrary lib, Weights W, uint64_t first, uint32_t count,
                                                         const int32_t *status, const uint64_t *taboff, uint8_t *arena,
-                                                        const uint32_t *list, const uint32_t *list_count) {
+                                                        const uint32_t *list, const uint32_t *list_count, uint32_t *cursor) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int GPW = 64 / G; // slots per wave
-    if (list && (uint64_t)blockIdx.x * (blockDim.x / 64) >= *list_count) return; // nothing listed for this block
+    const uint32_t todo = list ? *list_count : count; // ligands of this launch (all, or the listed ones)
+    if ((uint64_t)blockIdx.x * (blockDim.x / 64) >= todo) return; // more blocks than work
     const int Nm = M.Nm;
     float4 *tab = reinterpret_cast<float4 *>(smem);
     const int Ns = Nm + 1; // row stride: one neutral column after the model's nodes (see node_pair_lists)
     uint64_t *cnodes = reinterpret_cast<uint64_t *>(smem + (size_t)Nm * Ns * sizeof(float4));
     uint64_t *tnodes = cnodes + 64;
-    unsigned char *wave_base = reinterpret_cast<unsigned char *>(tnodes + 128) + (size_t)(threadIdx.x >> 6) * tables_v2_wave_bytes<G>();
+    unsigned char *wave_base = reinterpret_cast<unsigned char *>(tnodes + 128) + (size_t)(threadIdx.x >> 6) * tables_v2_wave_bytes<G>(M.K);
     WaveLevels &WL = *reinterpret_cast<WaveLevels *>(wave_base);
-    float *acc_score = reinterpret_cast<float *>(wave_base + sizeof(WaveLevels)); // [kTabEntryChunk][G]
+    const int cs = (int)tables_v2_cand_stride(M.K);
+    uint8_t *candlist = wave_base + sizeof(WaveLevels); // [PMX_MAX_LEVELS][cs]
+    float *acc_score = reinterpret_cast<float *>(candlist + PMX_MAX_LEVELS * cs); // [kTabEntryChunk][G]
     unsigned *acc_fail = reinterpret_cast<unsigned *>(acc_score + kTabEntryChunk * G);
     uint8_t *near_list = reinterpret_cast<uint8_t *>(acc_fail + kTabEntryChunk * G); // [kTabEntryChunk]
 
@@ -315,15 +325,19 @@ __global__ __launch_bounds__(512, 6) void tables_kernel_v2(DevModel M, DevLibrar
     // reference (match_utils.py:50-52,69)
     const unsigned long long nzw = __ballot(lane < Nm && W.w[M.node_type[lane < Nm ? lane : 0]] != 0.f);
     constexpr bool some_zero = ZW;
-    uint64_t gid = (uint64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6); // ligand of this wave
-    if (list) { // only the listed ligands (one pass: the list is short - tables too large for tables_kernel_v3)
-        if (gid >= *list_count) return;
-        gid = list[gid];
-    }
-    if (gid >= count) return;
-    if (status[gid] != PMX_LIGAND_OK) return;
+    // The blocks are persistent: a wave that has finished a ligand fetches the next one from `cursor`, so the
+    // block's staged model table serves as many ligands as it takes and no wave idles behind a slower neighbour
+    // (ligand work spans more than 10x; with one ligand per wave a block lived as long as its slowest wave).
+    for (;;) {
+    uint32_t next = 0;
+    if (lane == 0) next = atomicAdd(cursor, 1u);
+    next = (uint32_t)__builtin_amdgcn_readfirstlane((int)next);
+    if (next >= todo) break;
+    const uint64_t gid = list ? list[next] : next; // ligand of this wave
+    if (gid >= count) continue;
+    if (status[gid] != PMX_LIGAND_OK) continue;
     const uint64_t off = taboff[gid];
-    if (taboff[gid + 1] == off) return;
+    if (taboff[gid + 1] == off) continue;
 
     const Record r = parse_record(lib.data + lib.offsets[first + gid]);
     const int C = r.C;
@@ -339,7 +353,7 @@ __global__ __launch_bounds__(512, 6) void tables_kernel_v2(DevModel M, DevLibrar
     const int nl = L.nl;
     for (int lev = 0; lev < nl; ++lev) { // candidate slot -> cluster id
         uint64_t cand = WL.cand[lev];
-        for (int q = 0; cand; cand &= cand - 1, ++q) WL.candlist[lev][q] = (uint8_t)(__ffsll((unsigned long long)cand) - 1);
+        for (int q = 0; cand; cand &= cand - 1, ++q) candlist[lev * cs + (q)] = (uint8_t)(__ffsll((unsigned long long)cand) - 1);
     }
     for (int i = lane; i < kTabEntryChunk * G; i += 64) {
         acc_score[i] = 0.f;
@@ -389,7 +403,7 @@ __global__ __launch_bounds__(512, 6) void tables_kernel_v2(DevModel M, DevLibrar
                     const int e = (int)(((float)t + 0.5f) * inv_per), rr = t - e * per;
                     const int u = (int)(((float)rr + 0.5f) * inv_ni), v = rr - u * ni;
                     if (u >= v) continue;
-                    const int a = WL.candlist[i][e0 + e];
+                    const int a = candlist[i * cs + (e0 + e)];
                     const Pos pu = load_pos(xyz, C, si + u, cc), pv = load_pos(xyz, C, si + v, cc);
                     const float d = norm3(pu.x - pv.x, pu.y - pv.y, pu.z - pv.z);
                     float acc = 0.f;
@@ -428,7 +442,7 @@ __global__ __launch_bounds__(512, 6) void tables_kernel_v2(DevModel M, DevLibrar
                     bool near = false;
                     if (e < ecur) {
                         const int ea = (int)(((float)(e0 + e) + 0.5f) * inv_kj), eb = (e0 + e) - ea * kj;
-                        const float2 mp = M.cpair[WL.candlist[i][ea] * M.K + WL.candlist[j][eb]];
+                        const float2 mp = M.cpair[candlist[i * cs + (ea)] * M.K + candlist[j * cs + (eb)]];
                         near = lane_live && !((fabsf(ldist - mp.x) - lsize) > mp.y);
                     }
                     const unsigned long long bal = __ballot(near);
@@ -448,7 +462,7 @@ __global__ __launch_bounds__(512, 6) void tables_kernel_v2(DevModel M, DevLibrar
                     const int u = (int)(((float)rr + 0.5f) * inv_nj), v = rr - u * nj;
                     const int e = near_list[en];
                     const int ea = (int)(((float)(e0 + e) + 0.5f) * inv_kj), eb = (e0 + e) - ea * kj;
-                    const int a = WL.candlist[i][ea], b = WL.candlist[j][eb];
+                    const int a = candlist[i * cs + (ea)], b = candlist[j * cs + (eb)];
                     const Pos pu = load_pos(xyz, C, si + u, cc), pv = load_pos(xyz, C, sj + v, cc);
                     const float d = norm3(pu.x - pv.x, pu.y - pv.y, pu.z - pv.z);
                     float acc = 0.f;
@@ -468,7 +482,7 @@ __global__ __launch_bounds__(512, 6) void tables_kernel_v2(DevModel M, DevLibrar
                     bool valid = false;
                     if (on) {
                         const int ea = (int)(((float)(e0 + e) + 0.5f) * inv_kj), eb = (e0 + e) - ea * kj;
-                        const int a = WL.candlist[i][ea], b = WL.candlist[j][eb];
+                        const int a = candlist[i * cs + (ea)], b = candlist[j * cs + (eb)];
                         const float2 mp = M.cpair[a * M.K + b];
                         const bool near = lane_live && !((fabsf(ldist - mp.x) - lsize) > mp.y);
                         const bool near_any = (__ballot(near) & slot_mask) != 0;
@@ -496,6 +510,7 @@ __global__ __launch_bounds__(512, 6) void tables_kernel_v2(DevModel M, DevLibrar
             pair_base += (uint32_t)E;
         }
     }
+    } // next ligand
 }
 
 // ---------------------------------------------------------------------------------- bounds_kernel

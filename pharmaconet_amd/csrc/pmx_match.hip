@@ -141,6 +141,19 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int off) {
     return __hiloint2double(hi, lo);
 }
 
+// Where the folded edge table is read from: an LDS copy (broadcast reads) or, SMEM = true, HBM through the scalar cache
+// (every address is wave-uniform, so a term's parameters arrive in SGPRs and the block needs no LDS for the model).
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef const f4v __attribute__((address_space(4))) *const_f4v_ptr;
+template <bool SMEM>
+__device__ __forceinline__ float4 edge_at(const float4 *tab, int byte_offset) {
+    if (SMEM) {
+        const f4v e = reinterpret_cast<const_f4v_ptr>(reinterpret_cast<unsigned long long>(tab))[byte_offset >> 4];
+        return make_float4(e.x, e.y, e.z, e.w);
+    }
+    return *reinterpret_cast<const float4 *>(reinterpret_cast<const unsigned char *>(tab) + byte_offset);
+}
+
 // One Gaussian term (match_utils.py:55-68): e = {mean, s, T, w / std}
 template <bool PASS>
 __device__ __forceinline__ void gterm(const float d, const float4 e, float &acc, unsigned &np) {
@@ -150,42 +163,11 @@ __device__ __forceinline__ void gterm(const float d, const float4 e, float &acc,
     if (PASS) np += (t <= e.z) ? 1u : 0u;
 }
 
-// The terms of one row m against the model nodes of column set B (ascending n), all wave-uniform; B non-empty.
-template <bool PASS>
-__device__ __forceinline__ void row_terms(const float4 *row, uint64_t B, const float d, float &acc, unsigned &np) {
-    for (;;) {
-        const int n0 = __ffsll((unsigned long long)B) - 1;
-        B &= B - 1;
-        if (!B) {
-            gterm<PASS>(d, row[n0], acc, np);
-            return;
-        }
-        const int n1 = __ffsll((unsigned long long)B) - 1;
-        B &= B - 1;
-        if (!B) {
-            const float4 e0 = row[n0], e1 = row[n1];
-            gterm<PASS>(d, e0, acc, np);
-            gterm<PASS>(d, e1, acc, np);
-            return;
-        }
-        const int n2 = __ffsll((unsigned long long)B) - 1;
-        B &= B - 1;
-        if (!B) {
-            const float4 e0 = row[n0], e1 = row[n1], e2 = row[n2];
-            gterm<PASS>(d, e0, acc, np);
-            gterm<PASS>(d, e1, acc, np);
-            gterm<PASS>(d, e2, acc, np);
-            return;
-        }
-        const int n3 = __ffsll((unsigned long long)B) - 1;
-        B &= B - 1;
-        const float4 e0 = row[n0], e1 = row[n1], e2 = row[n2], e3 = row[n3];
-        gterm<PASS>(d, e0, acc, np);
-        gterm<PASS>(d, e1, acc, np);
-        gterm<PASS>(d, e2, acc, np);
-        gterm<PASS>(d, e3, acc, np);
-        if (!B) return;
-    }
+// The terms of one row (byte offset `row` into the edge table) against the model nodes of column set B (ascending n), all
+// wave-uniform; B non-empty. Fallback for column sets of more than 12 nodes.
+template <bool PASS, bool SMEM>
+__device__ __forceinline__ void row_terms(const float4 *tab, int row, uint64_t B, const float d, float &acc, unsigned &np) {
+    for (; B; B &= B - 1) gterm<PASS>(d, edge_at<SMEM>(tab, row + 16 * (__ffsll((unsigned long long)B) - 1)), acc, np);
 }
 
 // ------------------------------------------------------------------------------------------------ bin_kernel
@@ -250,7 +232,7 @@ __global__ void fold_weights_kernel(DevModel M, Weights W, float4 *wtab) {
 }
 
 // --------------------------------------------------------------------------------------------- the matcher
-template <int G, bool LDS_TABLES>
+template <int G, bool LDS_TABLES, bool SMEM = false>
 struct Matcher {
     static constexpr int NP = 64 / G; // node pairs (table phase) / candidates (tree phase) per pass of the wave
     const MatchParams &p;
@@ -414,6 +396,39 @@ struct Matcher {
         for (int i = lane; i < (nl + 1) * G; i += 64) Ro[i] = Rt[i];
     }
 
+    // The same by a team of waves: wave `tw` of `tn` copies every tn-th chunk of V and P; wave 0 also the header, S and R.
+    __device__ void write_out_team(uint8_t *blk, int tw, int tn) {
+        const uint32_t v_bytes = (uint32_t)round16(uint64_t(T) * sizeof(vmask_t<G>));
+        const uint32_t s_bytes = (uint32_t)round16(uint64_t(ksumtot) * G * 4), p_bytes = (uint32_t)round16(uint64_t(T) * G * 4);
+        vmask_t<G> *Vo = reinterpret_cast<vmask_t<G> *>(blk + sizeof(TabHeader));
+        for (uint32_t e = tw * 64 + lane; e < T; e += 64 * tn) {
+            unsigned long long m = 0;
+            for (int q = 0; q < C; ++q) m |= (unsigned long long)(Pt[e * G + q] > 0.f) << q;
+            Vo[e] = (vmask_t<G>)m;
+        }
+        uint4 *Po = reinterpret_cast<uint4 *>(blk + sizeof(TabHeader) + v_bytes + s_bytes);
+        const uint4 *Pi = reinterpret_cast<const uint4 *>(Pt);
+        for (uint32_t i = tw * 64 + lane; i < p_bytes / 16; i += 64 * tn) Po[i] = Pi[i];
+        if (tw != 0) return;
+        TabHeader *H = reinterpret_cast<TabHeader *>(blk);
+        if (lane == 0) {
+            H->nl = (uint32_t)nl;
+            H->T = T;
+            H->ksumtot = ksumtot;
+            H->pad = 0;
+        }
+        if (lane < nl) {
+            H->k[lane] = X.lk[lane];
+            H->rowbase[lane] = X.rowbase[lane];
+        }
+        if (lane <= nl) H->ksum[lane] = X.ksum[lane];
+        uint4 *So = reinterpret_cast<uint4 *>(blk + sizeof(TabHeader) + v_bytes);
+        const uint4 *Si = reinterpret_cast<const uint4 *>(St);
+        for (uint32_t i = lane; i < s_bytes / 16; i += 64) So[i] = Si[i];
+        double *Ro = reinterpret_cast<double *>(blk + sizeof(TabHeader) + v_bytes + s_bytes + p_bytes);
+        for (int i = lane; i < (nl + 1) * G; i += 64) Ro[i] = Rt[i];
+    }
+
     // coop_kernel: a wave that did not build the tables takes their geometry from the wave that did
     __device__ void attach(uint32_t li, unsigned char *tables, double *own_tt) {
         r = parse_record(p.lib.data + p.lib.offsets[p.first + li]);
@@ -431,6 +446,7 @@ struct Matcher {
         Pt = reinterpret_cast<float *>(tables);
         St = reinterpret_cast<float *>(tables + p_bytes);
         Ft = reinterpret_cast<uint32_t *>(tables + p_bytes + s_bytes);
+        Gt = reinterpret_cast<float4 *>(tables + p_bytes + s_bytes + (uint32_t)round16(uint64_t(T) * G * 2));
         Rt = reinterpret_cast<double *>(tables + p_bytes + s_bytes);
         Tt = own_tt;
         La = Tt + (size_t)(nl + 1) * G;
@@ -451,16 +467,15 @@ struct Matcher {
         int off[NB];
 #pragma unroll
         for (int t = 0; t < NB; ++t) off[t] = (int)(((t + 1) & 1) ? (w[(t + 1) >> 1] >> 16) : (w[(t + 1) >> 1] & 0xffffu));
-        const unsigned char *tb = reinterpret_cast<const unsigned char *>(tab);
         const int rowbytes = Nm * 16;
         for (uint64_t mm = A; mm; mm &= mm - 1) {
-            const unsigned char *row = tb + (__ffsll((unsigned long long)mm) - 1) * rowbytes;
+            const int row = (__ffsll((unsigned long long)mm) - 1) * rowbytes;
 #pragma unroll
             for (int t0 = 0; t0 < NB; t0 += 4) {
                 float4 e[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    if (t0 + q < NB) e[q] = *reinterpret_cast<const float4 *>(row + off[t0 + q]);
+                    if (t0 + q < NB) e[q] = edge_at<SMEM>(tab, row + off[t0 + q]);
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     if (t0 + q < NB) gterm<PASS>(d, e[q], acc, np);
@@ -488,7 +503,7 @@ struct Matcher {
         case 11: rows_fixed<11, PASS>(A, u0, u1, d, acc, np); break;
         case 12: rows_fixed<12, PASS>(A, u0, u1, d, acc, np); break;
         default: // more than 12 compatible nodes in one model cluster: walk the masks
-            for (uint64_t mm = A; mm; mm &= mm - 1) row_terms<PASS>(tab + (__ffsll((unsigned long long)mm) - 1) * Nm, B, d, acc, np);
+            for (uint64_t mm = A; mm; mm &= mm - 1) row_terms<PASS, SMEM>(tab, (__ffsll((unsigned long long)mm) - 1) * Nm * 16, B, d, acc, np);
         }
     }
 
@@ -667,6 +682,7 @@ struct Matcher {
             const float4 gi = Gt[(size_t)i * G + c];
             const uint64_t cand_i = uni64(X.cand[i]);
             for (int j = i + 1; j < nl; ++j) {
+                if (bn > 1 && (i * PMX_MAX_LEVELS + j) % bn != bw) continue; // another wave of the team finishes this level pair
                 const int sj = uni((int)X.lstart[j]), ej = uni((int)X.lend[j]), kj = uni((int)X.lk[j]);
                 const float4 gj = Gt[(size_t)j * G + c];
                 const float ldist = norm3(gi.x - gj.x, gi.y - gj.y, gi.z - gj.z); // graph_match.py:240
@@ -1078,7 +1094,7 @@ __global__ __launch_bounds__(1024) void match_kernel(const MatchParams p) {
     for (int i = threadIdx.x; i < 128; i += blockDim.x) tnodes[i] = p.M.tnodes[i];
     for (int i = threadIdx.x; i < K * K; i += blockDim.x) cpair[i] = p.M.cpair[i];
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     unsigned char *ctx = smem + model_lds_bytes(Nm, K) + (size_t)wave * p.wave_bytes;
     unsigned char *tables = ctx + sizeof(MatchCtx);
     const uint32_t count = (uint32_t)uni((int)p.bins->count[p.bin]);
@@ -1155,7 +1171,7 @@ __global__ __launch_bounds__(1024) void tables_kernel_v3(const MatchParams p) {
     for (int i = threadIdx.x; i < 128; i += blockDim.x) tnodes[i] = p.M.tnodes[i];
     for (int i = threadIdx.x; i < K * K; i += blockDim.x) cpair[i] = p.M.cpair[i];
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     unsigned char *ctx = smem + model_lds_bytes(Nm, K) + (size_t)wave * p.wave_bytes;
     unsigned char *tables = ctx + sizeof(MatchCtx);
     const uint32_t count = (uint32_t)uni((int)p.bins->count[p.bin]);
@@ -1170,6 +1186,68 @@ __global__ __launch_bounds__(1024) void tables_kernel_v3(const MatchParams p) {
         mt.build_tables();
         mt.build_bounds();
         mt.write_out(p.out_arena + p.taboff[li]);
+    }
+}
+
+// tables_kernel_v4: the same table builder with the occupancy of a kernel that owns no model copy. A block is a TEAM of
+// waves on one ligand at a time: the edge table is read through the scalar cache (SMEM = true), LDS holds only the small
+// cluster tables and the ligand's accumulators; every wave builds the entries (x, y) of its residue class and finishes
+// the level pairs of its residue class (disjoint entries: the bits do not depend on the team size), wave 0 computes the
+// bounds, all waves write the block of the chunk's arena. Many small blocks per CU: the serial steps of one team are
+// covered by the others.
+template <int G>
+__global__ __launch_bounds__(1024) void tables_kernel_v4(const MatchParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int K = p.M.K, Nm = p.M.Nm;
+    uint64_t *cnodes = reinterpret_cast<uint64_t *>(smem);
+    uint64_t *tnodes = cnodes + 64;
+    float2 *cpair = reinterpret_cast<float2 *>(tnodes + 128);
+    for (int i = threadIdx.x; i < 64; i += blockDim.x) cnodes[i] = p.M.cnodes[i];
+    for (int i = threadIdx.x; i < 128; i += blockDim.x) tnodes[i] = p.M.tnodes[i];
+    for (int i = threadIdx.x; i < K * K; i += blockDim.x) cpair[i] = p.M.cpair[i];
+    const uint32_t small_bytes = 64 * 8 + 128 * 8 + (uint32_t)round16(uint64_t(K) * K * 8);
+    uint32_t *item = reinterpret_cast<uint32_t *>(smem + small_bytes); // [0] list position, [1] has_tree
+    unsigned char *ctx = smem + small_bytes + 16;
+    unsigned char *tables = ctx + sizeof(MatchCtx);
+    const int lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // wave-uniform for the compiler too: what a wave does
+                                                                             // under `if (wave == 0)` stays in scalar registers
+    unsigned char *helper = ctx + p.wave_bytes + (size_t)(wave > 0 ? wave - 1 : 0) * (2 * kPairBuf + 32 * kListSlots);
+    const uint32_t count = p.bins->count[p.bin];
+    Matcher<G, true, true> mt(p, p.wtab, cnodes, tnodes, cpair, ctx);
+    mt.bn = nwaves;
+    mt.bw = wave;
+    if (wave != 0) {
+        mt.pairbuf = reinterpret_cast<uint16_t *>(helper);
+        mt.lists = reinterpret_cast<uint4 *>(helper + 2 * kPairBuf);
+    }
+    (void)Nm;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) item[0] = atomicAdd(&p.bins->cursor[p.bin], 1u);
+        __syncthreads();
+        const uint32_t pos = item[0];
+        if (pos >= count) break;
+        const uint32_t li = p.list[pos];
+        if (wave == 0) {
+            const bool has_tree = mt.setup(li, tables);
+            if (lane == 0) {
+                mt.X.meta[0] = (uint32_t)mt.nl;
+                mt.X.meta[1] = mt.T;
+                mt.X.meta[2] = mt.ksumtot;
+                item[1] = has_tree ? 1u : 0u;
+            }
+        }
+        __syncthreads();
+        if (!item[1]) continue;
+        if (wave != 0) mt.attach(li, tables, nullptr);
+        mt.build_tables();
+        __syncthreads();
+        mt.finish_tables();
+        __syncthreads();
+        if (wave == 0) mt.build_bounds();
+        __syncthreads();
+        mt.write_out_team(p.out_arena + p.taboff[li], wave, nwaves);
     }
 }
 
@@ -1190,7 +1268,9 @@ __global__ __launch_bounds__(1024) void coop_kernel(const MatchParams p) {
     for (int i = threadIdx.x; i < 64; i += blockDim.x) cnodes[i] = p.M.cnodes[i];
     for (int i = threadIdx.x; i < 128; i += blockDim.x) tnodes[i] = p.M.tnodes[i];
     for (int i = threadIdx.x; i < K * K; i += blockDim.x) cpair[i] = p.M.cpair[i];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // wave-uniform for the compiler too: what a wave does
+                                                                             // under `if (wave == 0)` stays in scalar registers
     CoopShared &S = *reinterpret_cast<CoopShared *>(smem + model_lds_bytes(Nm, K));
     unsigned char *ctx = reinterpret_cast<unsigned char *>(&S + 1);
     const uint32_t table_bytes = LDS_TABLES ? p.wave_bytes - (uint32_t)sizeof(MatchCtx) : 0u;
@@ -1248,8 +1328,9 @@ __global__ __launch_bounds__(1024) void coop_kernel(const MatchParams p) {
         __syncthreads();
         const unsigned long long c2 = __builtin_amdgcn_s_memtime();
         unsigned long long c3 = c2;
+        mt.finish_tables(); // level pairs are divided among the waves like the entries were
+        __syncthreads();
         if (wave == 0) {
-            mt.finish_tables();
             mt.build_bounds();
             c3 = __builtin_amdgcn_s_memtime();
             mt.coop_top(S, roots, p.roots_cap);

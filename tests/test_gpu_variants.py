@@ -71,7 +71,8 @@ def test_zero_type_weight_matches_oracle(oracle):
         assert np.abs(default - got).max() > 0.5  # the weight matters on this library
 
 
-@pytest.mark.parametrize("env", [{"PMX_ENGINE": "2"}, {"PMX_TABLES": "3"}], ids=["fused-matcher", "tables-v3"])
+@pytest.mark.parametrize("env", [{"PMX_ENGINE": "2"}, {"PMX_TABLES": "3"}, {"PMX_TABLES": "4"}],
+                         ids=["fused-matcher", "tables-v3", "tables-v4"])
 @pytest.mark.parametrize("name", GOLDEN_SETS)
 def test_alternative_engines_match_reference_golden(name, env, monkeypatch):
     """The LDS-resident fused matcher (pmx_match.hip, PMX_ENGINE=2) and its table builder inside the chunk pipeline
