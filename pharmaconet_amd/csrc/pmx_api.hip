@@ -278,7 +278,7 @@ struct Slot {
     uint64_t *taboff = nullptr;
     uint8_t *arena = nullptr;
     size_t arena_cap = 0;
-    uint32_t *meta = nullptr;      // device: [0] max levels, [1] fetch counter, [2..3] table bytes (u64), [4] task queue tail, [5] queue overflow, [6..7] tree steps, [8] / [9] ligand cursors of the table kernel
+    uint32_t *meta = nullptr;      // device: [0] max levels, [1] fetch counter, [2..3] table bytes (u64), [4] task queue tail, [5] queue overflow, [6..13] tree statistics (TreeParams::nsteps), [14] / [15] ligand cursors of the table kernel
     uint32_t *meta_host = nullptr; // pinned mirror
     BinInfo *bins = nullptr;               // table phase: LDS size classes of the chunk's ligands
     uint32_t *caps_dev = nullptr;
@@ -504,10 +504,10 @@ static int table_phase(const pmx_model *model, const pmx_library *lib, const Wei
             const unsigned v2_blocks = (unsigned)std::min<uint64_t>((n + v2_waves - 1) / v2_waves, (uint64_t)num_cu * 4);
             if (zero_weight)
                 tables_kernel_v2<G, true><<<dim3(v2_blocks), dim3(64 * v2_waves), lds2, q>>>(
-                    model->dm, lib->dl, W, lig0, n, status, sl.taboff, sl.arena, sl.lists + (size_t)kNumBins * n, &sl.bins->count[kNumBins], sl.meta + 9);
+                    model->dm, lib->dl, W, lig0, n, status, sl.taboff, sl.arena, sl.lists + (size_t)kNumBins * n, &sl.bins->count[kNumBins], sl.meta + 15);
             else
                 tables_kernel_v2<G, false><<<dim3(v2_blocks), dim3(64 * v2_waves), lds2, q>>>(
-                    model->dm, lib->dl, W, lig0, n, status, sl.taboff, sl.arena, sl.lists + (size_t)kNumBins * n, &sl.bins->count[kNumBins], sl.meta + 9);
+                    model->dm, lib->dl, W, lig0, n, status, sl.taboff, sl.arena, sl.lists + (size_t)kNumBins * n, &sl.bins->count[kNumBins], sl.meta + 15);
             bounds_kernel<G><<<dim3((n + 3) / 4), dim3(256), 0, q>>>(n, status, sl.taboff, sl.arena, (int)(env_long("PMX_TREE_FLAGS", 0) & 4),
                                                                      sl.lists + (size_t)kNumBins * n, &sl.bins->count[kNumBins]);
         }
@@ -519,15 +519,15 @@ static int table_phase(const pmx_model *model, const pmx_library *lib, const Wei
         const int v2_waves = (int)std::min<size_t>((size_t)env_long("PMX_V2_WAVES", 8), (kLdsPerCu - 1024 - model_lds) / tables_v2_wave_bytes<G>(model->dm.K));
         size_t lds2 = model_lds + (size_t)v2_waves * tables_v2_wave_bytes<G>(model->dm.K);
         lds2 = std::max<size_t>(lds2, (size_t)env_long("PMX_V2_LDS_MIN", 0));
-        // persistent blocks: as many as the CUs hold at once (PMX_V2_BLOCKS per CU), fed from the cursor in meta[8]
+        // persistent blocks: as many as the CUs hold at once (PMX_V2_BLOCKS per CU), fed from the cursor in meta[14]
         const unsigned v2_blocks = (unsigned)std::min<uint64_t>((n + v2_waves - 1) / v2_waves,
                                                                 (uint64_t)ws_num_cu * (uint64_t)std::max<long>(1, env_long("PMX_V2_BLOCKS", 4)));
         if (zero_weight)
             tables_kernel_v2<G, true><<<dim3(v2_blocks), dim3(64 * v2_waves), lds2, q>>>(
-                model->dm, lib->dl, W, lig0, n, status, sl.taboff, sl.arena, nullptr, nullptr, sl.meta + 8);
+                model->dm, lib->dl, W, lig0, n, status, sl.taboff, sl.arena, nullptr, nullptr, sl.meta + 14);
         else
             tables_kernel_v2<G, false><<<dim3(v2_blocks), dim3(64 * v2_waves), lds2, q>>>(
-                model->dm, lib->dl, W, lig0, n, status, sl.taboff, sl.arena, nullptr, nullptr, sl.meta + 8);
+                model->dm, lib->dl, W, lig0, n, status, sl.taboff, sl.arena, nullptr, nullptr, sl.meta + 14);
         bounds_kernel<G><<<dim3((n + 3) / 4), dim3(256), 0, q>>>(n, status, sl.taboff, sl.arena,
                                                                  (int)(env_long("PMX_TREE_FLAGS", 0) & 4), nullptr, nullptr);
         HIPCHECK(hipGetLastError());
@@ -595,7 +595,8 @@ static int tree_phase(const pmx_model *model, const pmx_library *lib, int32_t *s
             g_stats.n_steps_first += ns1;
         }
         const uint32_t hi = std::min<uint32_t>(mh[4], tp.qcap);
-        TRACE("round: lo=%u hi=%u", lo, hi);
+        TRACE("round: lo=%u hi=%u steps=%llu iters=%llu", lo, hi, (unsigned long long)mh[6] | ((unsigned long long)mh[7] << 32),
+              (unsigned long long)mh[8] | ((unsigned long long)mh[9] << 32));
         if (mh[5]) g_stats.queue_overflow = 1;
         if (mh[32] == 2) return fail(PMX_ERR_INVALID, "tree kernel watchdog fired at location %u", mh[35]);
         if (mh[32]) {

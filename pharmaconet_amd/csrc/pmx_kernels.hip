@@ -126,8 +126,9 @@ struct Pos {
 };
 
 __device__ inline Pos load_pos(const float *xyz, int C, int u, int c) {
-    const float *p = xyz + (size_t)(u * 3) * C + c;
-    return Pos{p[0], p[C], p[2 * C]};
+    // unsigned 32-bit element offsets from the record's (wave-uniform) base: one add per address, no 64-bit lane arithmetic
+    const uint32_t o = (uint32_t)__mul24(u * 3, C) + (uint32_t)c, uc = (uint32_t)C;
+    return Pos{xyz[o], xyz[o + uc], xyz[o + 2u * uc]};
 }
 
 // np.linalg.norm of a float32 3-vector: sqrt((x*x + y*y) + z*z), every step rounded (ligand.py:349-351).
@@ -241,8 +242,8 @@ __device__ inline void node_pair_lists(const float4 *tab, int Ns, const uint4 la
 
 // One (ligand node, ligand node) term against model clusters a and b; returns |A| * |B| (0: nothing compatible).
 __device__ inline int cluster_node_pair(const DevModel &M, const float4 *tab, const uint64_t *cnodes, const uint64_t *tnodes, int a, int b,
-                                        unsigned tmu, unsigned tmv, float d, float &acc, int &npass) {
-    const uint4 la = M.clist[a * 128 + (int)tmu], lb = M.clist[b * 128 + (int)tmv];
+                                        unsigned tmu, unsigned tmv, const uint4 la /* M.clist[a * 128 + tmu] */,
+                                        const uint4 lb /* M.clist[b * 128 + tmv] */, float d, float &acc, int &npass) {
     const int na = (int)(la.x & 255u), nb = (int)(lb.x & 255u);
     if (na == 0 || nb == 0) return 0;
     if (na != 255 && nb != 255) {
@@ -277,8 +278,8 @@ __host__ __device__ constexpr uint32_t tables_v2_cand_stride(int K) { return (ui
 
 template <int G>
 __host__ __device__ constexpr uint32_t tables_v2_wave_bytes(int K) {
-    // levels, candidate lists, accumulators, near-entry list
-    return sizeof(WaveLevels) + PMX_MAX_LEVELS * tables_v2_cand_stride(K) + kTabEntryChunk * G * 8 + kTabEntryChunk;
+    // levels, candidate lists, accumulators, near-entry list, the ligand's node type masks
+    return sizeof(WaveLevels) + PMX_MAX_LEVELS * tables_v2_cand_stride(K) + kTabEntryChunk * G * 8 + kTabEntryChunk * 4 + PMX_MAX_LIGAND_NODES;
 }
 
 #ifndef PMX_V2_MINWAVES
@@ -304,7 +305,8 @@ __global__ __launch_bounds__(512, PMX_V2_MINWAVES) void tables_kernel_v2(DevMode
     uint8_t *candlist = wave_base + sizeof(WaveLevels); // [PMX_MAX_LEVELS][cs]
     float *acc_score = reinterpret_cast<float *>(candlist + PMX_MAX_LEVELS * cs); // [kTabEntryChunk][G]
     unsigned *acc_fail = reinterpret_cast<unsigned *>(acc_score + kTabEntryChunk * G);
-    uint8_t *near_list = reinterpret_cast<uint8_t *>(acc_fail + kTabEntryChunk * G); // [kTabEntryChunk]
+    uint32_t *near_list = acc_fail + kTabEntryChunk * G;                   // [kTabEntryChunk] entry | a << 8 | b << 16
+    uint8_t *tm = reinterpret_cast<uint8_t *>(near_list + kTabEntryChunk); // [PMX_MAX_LIGAND_NODES]
 
     for (int i = threadIdx.x; i < Nm * Ns; i += blockDim.x) {
         const int m = i / Ns, n = i - m * Ns;
@@ -359,6 +361,7 @@ __global__ __launch_bounds__(512, PMX_V2_MINWAVES) void tables_kernel_v2(DevMode
         acc_score[i] = 0.f;
         acc_fail[i] = 0u;
     }
+    if (lane < r.n) tm[lane] = r.typemask[lane]; // looked up per item and per entry: one LDS read instead of a global load
 
     uint8_t *blk = arena + off;
     TabHeader *H = reinterpret_cast<TabHeader *>(blk);
@@ -383,8 +386,10 @@ __global__ __launch_bounds__(512, PMX_V2_MINWAVES) void tables_kernel_v2(DevMode
     }
     wave_lds_sync();
 
-    const float *xyz = r.xyz;
-    const uint8_t *tm = r.typemask;
+    // the record base is the same for the whole wave: say so, and coordinate loads take it as a scalar base + 32-bit lane offset
+    const uint64_t xyz_bits = reinterpret_cast<uint64_t>(r.xyz);
+    const float *xyz = reinterpret_cast<const float *>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(xyz_bits >> 32)) << 32) |
+                                                       (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)xyz_bits));
     uint32_t self_base = 0, pair_base = 0;
     for (int i = 0; i < nl; ++i) {
         const int si = WL.start[i], ni = WL.end[i] - si, ki = WL.k[i];
@@ -400,17 +405,20 @@ __global__ __launch_bounds__(512, PMX_V2_MINWAVES) void tables_kernel_v2(DevMode
                 const float inv_per = 1.0f / (float)per, inv_ni = 1.0f / (float)ni;
                 const int total = ecur * per;
                 for (int t = s; t < total; t += GPW) {
-                    const int e = (int)(((float)t + 0.5f) * inv_per), rr = t - e * per;
-                    const int u = (int)(((float)rr + 0.5f) * inv_ni), v = rr - u * ni;
+                    const int e = (int)(((float)t + 0.5f) * inv_per), rr = t - __mul24(e, per);
+                    const int u = (int)(((float)rr + 0.5f) * inv_ni), v = rr - __mul24(u, ni);
                     if (u >= v) continue;
                     const int a = candlist[i * cs + (e0 + e)];
                     const Pos pu = load_pos(xyz, C, si + u, cc), pv = load_pos(xyz, C, si + v, cc);
-                    const float d = norm3(pu.x - pv.x, pu.y - pv.y, pu.z - pv.z);
+                    const unsigned tmu = tm[si + u], tmv = tm[si + v];
+                    const uint4 la = M.clist[(uint32_t)(a * 128) + tmu], lb = M.clist[(uint32_t)(a * 128) + tmv];
+                    float d = norm3(pu.x - pv.x, pu.y - pv.y, pu.z - pv.z);
+                    asm volatile("" : "+v"(d)); // the distance is computed while the list loads are in flight (see the pair items)
                     float acc = 0.f;
                     int np = 0;
-                    const int mn = cluster_node_pair(M, tab, cnodes, tnodes, a, a, tm[si + u], tm[si + v], d, acc, np);
+                    const int mn = cluster_node_pair(M, tab, cnodes, tnodes, a, a, tmu, tmv, la, lb, d, acc, np);
                     if (!mn) continue;
-                    const bool zw = some_zero && (!(cnodes[a] & tnodes[tm[si + u]] & nzw) || !(cnodes[a] & tnodes[tm[si + v]] & nzw));
+                    const bool zw = some_zero && (!(cnodes[a] & tnodes[tmu] & nzw) || !(cnodes[a] & tnodes[tmv] & nzw));
                     atomicAdd(&acc_score[e * G + c], zw ? __builtin_nanf("") : acc / (float)mn);
                 }
             }
@@ -440,17 +448,20 @@ __global__ __launch_bounds__(512, PMX_V2_MINWAVES) void tables_kernel_v2(DevMode
                 for (int e1 = 0; e1 < ecur; e1 += GPW) {
                     const int e = e1 + s;
                     bool near = false;
+                    uint32_t packed = 0; // the entry with its two model clusters: what an item needs, in one LDS word
                     if (e < ecur) {
-                        const int ea = (int)(((float)(e0 + e) + 0.5f) * inv_kj), eb = (e0 + e) - ea * kj;
-                        const float2 mp = M.cpair[candlist[i * cs + (ea)] * M.K + candlist[j * cs + (eb)]];
+                        const int ea = (int)(((float)(e0 + e) + 0.5f) * inv_kj), eb = (e0 + e) - __mul24(ea, kj);
+                        const int a = candlist[i * cs + (ea)], b = candlist[j * cs + (eb)];
+                        const float2 mp = M.cpair[a * M.K + b];
                         near = lane_live && !((fabsf(ldist - mp.x) - lsize) > mp.y);
+                        packed = (uint32_t)e | ((uint32_t)a << 8) | ((uint32_t)b << 16);
                     }
                     const unsigned long long bal = __ballot(near);
                     // one bit per slot: does any conformer of that slot's entry pass
                     for (int q = 0; q < GPW; ++q) {
                         const unsigned long long m = (G == 64) ? bal : ((bal >> (q * G)) & ((1ull << G) - 1ull));
                         if (m && e1 + q < ecur) {
-                            near_list[n_near] = (uint8_t)(e1 + q);
+                            if (s == q) near_list[n_near] = packed;
                             ++n_near;
                         }
                     }
@@ -458,18 +469,25 @@ __global__ __launch_bounds__(512, PMX_V2_MINWAVES) void tables_kernel_v2(DevMode
                 wave_lds_sync();
                 const int total = n_near * per;
                 for (int t = s; t < total; t += GPW) {
-                    const int en = (int)(((float)t + 0.5f) * inv_per), rr = t - en * per;
-                    const int u = (int)(((float)rr + 0.5f) * inv_nj), v = rr - u * nj;
-                    const int e = near_list[en];
-                    const int ea = (int)(((float)(e0 + e) + 0.5f) * inv_kj), eb = (e0 + e) - ea * kj;
-                    const int a = candlist[i * cs + (ea)], b = candlist[j * cs + (eb)];
+                    // (all products are far below 2^24: full-rate 24-bit multiplies)
+                    const int en = (int)(((float)t + 0.5f) * inv_per), rr = t - __mul24(en, per);
+                    const int u = (int)(((float)rr + 0.5f) * inv_nj), v = rr - __mul24(u, nj);
+                    const uint32_t packed = near_list[en];
+                    const int e = (int)(packed & 255u), a = (int)((packed >> 8) & 255u), b = (int)(packed >> 16);
+                    // Latency order: the six coordinate loads go out first (they only need u and v), then the two node
+                    // lists (which need the LDS lookups of a, b and the type masks); the distance is finished while the
+                    // lists are in flight. Left to itself the compiler sinks the coordinate loads below the test on the
+                    // lists, which makes three dependent memory round trips per item out of two.
                     const Pos pu = load_pos(xyz, C, si + u, cc), pv = load_pos(xyz, C, sj + v, cc);
-                    const float d = norm3(pu.x - pv.x, pu.y - pv.y, pu.z - pv.z);
+                    const unsigned tmu = tm[si + u], tmv = tm[sj + v];
+                    const uint4 la = M.clist[(uint32_t)(a * 128) + tmu], lb = M.clist[(uint32_t)(b * 128) + tmv];
+                    float d = norm3(pu.x - pv.x, pu.y - pv.y, pu.z - pv.z);
+                    asm volatile("" : "+v"(d));
                     float acc = 0.f;
                     int np = 0;
-                    const int mn = cluster_node_pair(M, tab, cnodes, tnodes, a, b, tm[si + u], tm[sj + v], d, acc, np);
+                    const int mn = cluster_node_pair(M, tab, cnodes, tnodes, a, b, tmu, tmv, la, lb, d, acc, np);
                     if (!mn) continue;
-                    const bool zw = some_zero && (!(cnodes[a] & tnodes[tm[si + u]] & nzw) || !(cnodes[b] & tnodes[tm[sj + v]] & nzw));
+                    const bool zw = some_zero && (!(cnodes[a] & tnodes[tmu] & nzw) || !(cnodes[b] & tnodes[tmv] & nzw));
                     atomicAdd(&acc_score[e * G + c], zw ? __builtin_nanf("") : acc / (float)mn);
                     if (2 * np < mn) atomicAdd(&acc_fail[e * G + c], 1u); // num_pass < num_match * 0.5 (match_utils.py:61)
                 }
