@@ -188,7 +188,7 @@ def test_sharded_screen_merges_to_the_global_ranking():
 
 def test_scores_do_not_depend_on_how_the_work_is_cut(monkeypatch):
     """The same bits whatever the launch structure: several chunks through the two-slot pipelines, phases
-    serialised, one or five concurrent pipelines, subtrees exported early, no in-wave sharing - and with the bound test of the tree search switched
+    serialised, one or five concurrent pipelines, subtrees exported early, no in-wave sharing, other shapes of the table kernel's persistent launch - and with the bound test of the tree search switched
     off (every subtree walked, as the reference does): dropping subtrees never changes a score."""
     import torch
 
@@ -215,6 +215,8 @@ def test_scores_do_not_depend_on_how_the_work_is_cut(monkeypatch):
         {"PMX_BUDGET": "64"},                       # trees are split across wavefronts much earlier
         {"PMX_TREE_FLAGS": "1"},                    # no hand-over between the groups of a wave
         {"PMX_TREE_FLAGS": "4"},                    # no bound test
+        {"PMX_V2_WAVES": "3", "PMX_V2_BLOCKS": "1"},  # table kernel: few, small persistent blocks - every wave builds many ligands
+        {"PMX_V2_BLOCKS": "64"},                    # more blocks than work: most find the cursor exhausted
     ):
         with monkeypatch.context() as mp:
             for k, v in env.items():
