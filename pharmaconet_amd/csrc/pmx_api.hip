@@ -272,13 +272,15 @@ extern "C" int pmx_library_destroy(pmx_library *lib) {
 // Chunks are software-pipelined over two buffer slots: while the tree kernels of chunk k run on the caller's
 // stream, the table kernels of chunk k + 1 run on an internal side stream. The two phases bind differently
 // (tables: VALU / LDS; tree search: memory latency), so their wavefronts share the CUs well.
+constexpr size_t kMetaBytes = 1024 + (size_t)kStatShards * 32; // counters + the tree kernels' sharded statistics
+
 struct Slot {
     uint32_t *units = nullptr;
     int32_t *status = nullptr;
     uint64_t *taboff = nullptr;
     uint8_t *arena = nullptr;
     size_t arena_cap = 0;
-    uint32_t *meta = nullptr;      // device: [0] max levels, [1] fetch counter, [2..3] table bytes (u64), [4] task queue tail, [5] queue overflow, [6..13] tree statistics (TreeParams::nsteps), [14] / [15] ligand cursors of the table kernel
+    uint32_t *meta = nullptr;      // device: [0] max levels, [1] fetch counter, [2..3] table bytes (u64), [4] task queue tail, [5] queue overflow, [14] / [15] ligand cursors of the table kernel, [32..] debug and profiling words; then kStatShards x 4 u64 of tree statistics
     uint32_t *meta_host = nullptr; // pinned mirror
     BinInfo *bins = nullptr;               // table phase: LDS size classes of the chunk's ligands
     uint32_t *caps_dev = nullptr;
@@ -352,12 +354,12 @@ static int ensure_workspace(int device, int pipeline, Workspace **out) {
         HIPCHECK(hipEventCreateWithFlags(&w.entry, hipEventDisableTiming));
         HIPCHECK(hipEventCreateWithFlags(&w.done, hipEventDisableTiming));
         for (Slot &sl : w.slot) {
-            HIPCHECK(hipMalloc((void **)&sl.meta, 1024));
+            HIPCHECK(hipMalloc((void **)&sl.meta, kMetaBytes));
             HIPCHECK(hipMalloc((void **)&sl.bins, sizeof(BinInfo)));
             HIPCHECK(hipMalloc((void **)&sl.caps_dev, sizeof(uint32_t) * kNumBins));
             HIPCHECK(hipMalloc((void **)&sl.wtab, (size_t)PMX_MAX_MODEL_NODES * PMX_MAX_MODEL_NODES * sizeof(float4)));
             HIPCHECK(hipMalloc((void **)&sl.bstats, 128 * sizeof(unsigned long long)));
-            HIPCHECK(hipHostMalloc((void **)&sl.meta_host, 1024));
+            HIPCHECK(hipHostMalloc((void **)&sl.meta_host, kMetaBytes));
             for (auto &ev : sl.ev) HIPCHECK(hipEventCreate(&ev));
             HIPCHECK(hipEventCreateWithFlags(&sl.tables_done, hipEventDisableTiming));
             HIPCHECK(hipEventCreateWithFlags(&sl.walk_done, hipEventDisableTiming));
@@ -401,8 +403,8 @@ static int table_phase(const pmx_model *model, const pmx_library *lib, const Wei
     sl.n = n;
     sl.lig0 = lig0;
     {
-        const uint64_t words = std::max<uint64_t>((uint64_t)n * G, 256);
-        clear_kernel<<<dim3((unsigned)((words + 255) / 256)), dim3(256), 0, q>>>(sl.meta, 256, sl.bestbuf, (uint64_t)n * G, sl.deferred, n);
+        const uint64_t words = std::max<uint64_t>((uint64_t)n * G, kMetaBytes / 4);
+        clear_kernel<<<dim3((unsigned)((words + 255) / 256)), dim3(256), 0, q>>>(sl.meta, kMetaBytes / 4, sl.bestbuf, (uint64_t)n * G, sl.deferred, n);
     }
     if (g_profiling) HIPCHECK(hipEventRecord(sl.ev[0], q));
     sizes_kernel<G><<<dim3((n + 255) / 256), dim3(256), 0, q>>>(lib->dl, model->dm.tclus, lig0, n, sl.units, status, sl.meta);
@@ -576,7 +578,7 @@ static int tree_phase(const pmx_model *model, const pmx_library *lib, int32_t *s
     tp.share_levels = (uint32_t)std::max<long>(0, env_long("PMX_SHARE_LEVELS", 1));
     tp.min_levels = (uint32_t)std::max<long>(0, env_long("PMX_MIN_LEVELS", 4));
     tp.flags = (uint32_t)env_long("PMX_TREE_FLAGS", 0);
-    tp.nsteps = reinterpret_cast<unsigned long long *>(sl.meta + 6);
+    tp.nsteps = reinterpret_cast<unsigned long long *>(sl.meta + 256); // kStatShards x 4 words after the 1 KB of counters
     tp.dbg = sl.meta + 32;
     tp.max_iters = (unsigned long long)std::max<long>(1, env_long("PMX_MAXITERS", 1L << 31));
     TRACE("tree kernel: grid=%u lds=%zu depth=%d", n, lds, depth);
@@ -586,17 +588,23 @@ static int tree_phase(const pmx_model *model, const pmx_library *lib, int32_t *s
     // rounds over the task queue: walkers that ran over budget appended subtrees
     uint32_t lo = 0;
     for (;;) {
-        HIPCHECK(hipMemcpyAsync(sl.meta_host, sl.meta, 1024, hipMemcpyDeviceToHost, stream));
+        HIPCHECK(hipMemcpyAsync(sl.meta_host, sl.meta, kMetaBytes, hipMemcpyDeviceToHost, stream));
         HIPCHECK(hipStreamSynchronize(stream));
         const uint32_t *mh = sl.meta_host;
+        unsigned long long tstat[4] = {0, 0, 0, 0}; // the tree statistics, summed over their shards
+        for (int sh = 0; sh < kStatShards; ++sh) {
+            unsigned long long v[4];
+            std::memcpy(v, mh + 256 + 8 * sh, 32);
+            tstat[0] += v[0];
+            tstat[1] += v[1];
+            tstat[2] = std::max(tstat[2], v[2]);
+            tstat[3] = std::max(tstat[3], v[3]);
+        }
         if (lo == 0 && g_stats.n_rounds == 0) {
-            unsigned long long ns1;
-            std::memcpy(&ns1, mh + 6, 8);
-            g_stats.n_steps_first += ns1;
+            g_stats.n_steps_first += tstat[0];
         }
         const uint32_t hi = std::min<uint32_t>(mh[4], tp.qcap);
-        TRACE("round: lo=%u hi=%u steps=%llu iters=%llu", lo, hi, (unsigned long long)mh[6] | ((unsigned long long)mh[7] << 32),
-              (unsigned long long)mh[8] | ((unsigned long long)mh[9] << 32));
+        TRACE("round: lo=%u hi=%u steps=%llu iters=%llu", lo, hi, tstat[0], tstat[1]);
         if (mh[5]) g_stats.queue_overflow = 1;
         if (mh[32] == 2) return fail(PMX_ERR_INVALID, "tree kernel watchdog fired at location %u", mh[35]);
         if (mh[32]) {
@@ -609,19 +617,16 @@ static int tree_phase(const pmx_model *model, const pmx_library *lib, int32_t *s
             return fail(PMX_ERR_INVALID, "%s", buf);
         }
         if (hi <= lo) {
-            unsigned long long ns;
-            std::memcpy(&ns, mh + 6, 8);
-            g_stats.n_steps += ns;
-            std::memcpy(&ns, mh + 8, 8);
-            g_stats.n_iters += ns;
-            std::memcpy(&ns, mh + 10, 8);
-            g_stats.max_iters_ligand = std::max<uint64_t>(g_stats.max_iters_ligand, ns);
-            std::memcpy(&ns, mh + 12, 8);
-            g_stats.max_iters_task = std::max<uint64_t>(g_stats.max_iters_task, ns);
+            g_stats.n_steps += tstat[0];
+            g_stats.n_iters += tstat[1];
+            g_stats.max_iters_ligand = std::max<uint64_t>(g_stats.max_iters_ligand, tstat[2]);
+            g_stats.max_iters_task = std::max<uint64_t>(g_stats.max_iters_task, tstat[3]);
+            unsigned long long ns = 0;
+            (void)ns;
 #ifdef PMX_PROF
             {
                 fprintf(stderr, "PMXPROF");
-                for (int i = 0; i < 32; ++i) {
+                for (int i = 0; i < 48; ++i) {
                     std::memcpy(&ns, mh + 128 + 2 * i, 8);
                     fprintf(stderr, " %llu", ns);
                 }

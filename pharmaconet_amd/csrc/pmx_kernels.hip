@@ -654,6 +654,8 @@ __host__ __device__ constexpr uint32_t task_bytes() {
     return sizeof(TaskHeader) + G * 8;
 }
 
+constexpr int kStatShards = 256;
+
 struct TreeParams {
     const uint8_t *arena;
     const uint64_t *taboff;
@@ -675,7 +677,8 @@ struct TreeParams {
     uint32_t min_levels; // in export mode only subtrees with at least this many levels below their root are queued
     uint32_t flags;      // debug: 1 = no in-wave sharing, 2 = no global donation (4 = no bound test: see bounds_kernel)
     uint32_t budget;     // wave iterations after which a job donates its open subtrees to the queue
-    unsigned long long *nsteps; // total DFS steps (diagnostics)
+    unsigned long long *nsteps; // [kStatShards][4] {DFS steps, wave iterations, longest whole-ligand job, longest task}: diagnostics,
+                                // sharded by block so that a million waves do not queue on three addresses
     uint32_t *dbg;       // [0] = error flag (iteration cap hit), then 8 words per group
     unsigned long long max_iters; // safety cap on wave iterations per job (a tree walk is finite; never spin forever)
     float *scores;
@@ -693,7 +696,11 @@ __host__ __device__ inline uint32_t tree_group_bytes(int depth, int K) {
     return todo_bytes + cm_bytes + msk_bytes + frm_bytes + mat_bytes + eb_bytes;
 }
 
-constexpr uint32_t kTreeSharedHdr = 32 + 48 + 80 + 256; // k[32], ksum[24], rowbase[20] of the job's ligand; one report word per group
+// k[32], ksum[24], rowbase[20] of the job's ligand; one report word per group (LDS per wave decides how many waves a CU holds)
+template <int G>
+__host__ __device__ constexpr uint32_t tree_shared_hdr() {
+    return 32 + 48 + 80 + (uint32_t)round16(4u * (64 / G));
+}
 
 template <int G>
 __host__ __device__ constexpr uint32_t tree_local_stack_entries() {
@@ -703,7 +710,7 @@ __host__ __device__ constexpr uint32_t tree_local_stack_entries() {
 // LDS bytes of one wave of tree_kernel.
 template <int G>
 __host__ __device__ inline uint32_t tree_wave_bytes(int depth, int K) {
-    return kTreeSharedHdr + tree_local_stack_entries<G>() * task_bytes<G>() +
+    return tree_shared_hdr<G>() + tree_local_stack_entries<G>() * task_bytes<G>() +
            (64 / G) * tree_group_bytes<G>(depth, K);
 }
 
@@ -805,7 +812,7 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
     uint16_t *hksum = reinterpret_cast<uint16_t *>(shared + 32);        // [24]
     uint32_t *hrow = reinterpret_cast<uint32_t *>(shared + 32 + 48);    // [20]
     uint32_t *rep = reinterpret_cast<uint32_t *>(shared + 32 + 48 + 80); // [GPW] return values of handed-over subtrees
-    unsigned char *lstk = shared + kTreeSharedHdr;                      // local task stack
+    unsigned char *lstk = shared + tree_shared_hdr<G>();                    // local task stack
     const uint32_t todo_bytes = (uint32_t)round16((uint64_t)(D + 1) * 8);
     const uint32_t cm_bytes = (uint32_t)round16((uint64_t)(D + 1) * K * sizeof(vm_t));
     const uint32_t msk_bytes = (uint32_t)round16((uint64_t)(D + 1) * sizeof(vm_t));
@@ -838,6 +845,7 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
     uint32_t guard = 0;
 #ifdef PMX_PROF // build with PMX_CXXFLAGS=-DPMX_PROF: where a wave's time goes (s_memtime) and what it does
     unsigned long long pc_share = 0, pc_expand = 0, pc_adv = 0, pc_all = 0, pt0 = 0, pt1 = 0;
+    unsigned long long px_a = 0, px_b = 0, px_c = 0, px_d = 0, px_r = 0, px_n = 0, px_t = 0;
     unsigned pn_leaf = 0, pn_exp = 0, pn_desc = 0, pn_pl = 0, pn_vl = 0, pn_fill = 0, pn_ret = 0, pn_skip = 0, pn_exported = 0, pn_pruned = 0;
 #define PROF(x) x
 #else
@@ -882,11 +890,14 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
     if (TASKS) best = __longlong_as_double((long long)p.bestbuf[(size_t)li * G + c]); // maxima of the ligand's finished walkers
 
     // can the subtree below a child (frame fr + 1, conformer mask m, total t) still raise a conformer's maximum?
-    auto may_improve = [&](int fr, vm_t m, double t) -> bool {
-        const double r = *reinterpret_cast<const double *>(Rb + (((uint32_t)(fr + 1) << RSH) + 8u * (uint32_t)c));
+    auto bound_of = [&](int fr) -> double { // R[fr + 1][c]: what the levels below a child of frame fr can still add
+        return *reinterpret_cast<const double *>(Rb + (((uint32_t)(fr + 1) << RSH) + 8u * (uint32_t)c));
+    };
+    auto may_improve_r = [&](vm_t m, double t, double r) -> bool {
         const unsigned long long bal = __ballot(((m >> c) & 1) && (t + r) * kBoundSlack > best);
         return ((G == 64) ? bal : ((bal >> (g * G)) & ((1ull << G) - 1ull))) != 0;
     };
+    auto may_improve = [&](int fr, vm_t m, double t) -> bool { return may_improve_r(m, t, bound_of(fr)); };
     // start a walker on the subtree described by a task record (global queue or local stack)
     auto adopt = [&](const TaskHeader *th) {
         const int nm0 = th->nm;
@@ -1169,6 +1180,7 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
             if (!need_exp) {
                 for (uint32_t inner = 0; inner < step_cap; ++inner) { // optional bound on the work of one step (PMX_STEP_CAP)
                     PMX_GUARD(13);
+                    PROF(px_t = __builtin_amdgcn_s_memtime(); ++px_n);
                     uchar4 F = frm[f];
                     const int nm = F.w;
                     const bool matched = F.z & F_MATCHED;
@@ -1197,15 +1209,21 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
                             PROF(++pn_fill);
                         }
                         PROF(pn_pl += (unsigned)nm);
+                        PROF({ const unsigned long long z = __builtin_amdgcn_s_memtime(); px_a += z - px_t; px_t = z; });
                         // parent + self + accumulated pair (tree.py:38-41)
                         const uint32_t bc = ((uint32_t)b << PSH) + 4u * (uint32_t)c;
+                        // the bound row goes out with the table loads (one memory round trip per child, not two); frames
+                        // f < nl only, so row f + 1 exists
+                        const double rbound = bound_of(f);
                         const float self = *reinterpret_cast<const float *>(Sb + (((uint32_t)ksf << PSH) + bc));
                         const double t = tget(nm) + (double)self + pair_sum_eb<G>(Pb, eb, nm, bc);
+                        PROF({ asm volatile("" :: "v"(t)); const unsigned long long z = __builtin_amdgcn_s_memtime(); px_b += z - px_t; px_t = z; });
                         if (nm >= 4) { // the child holds >= 5 matches: its subtree is a pure enumeration of leaves
-                            if (!may_improve(f, m, t)) { // no leaf below can exceed the maxima found so far
+                            if (!may_improve_r(m, t, rbound)) { // no leaf below can exceed the maxima found so far
                                 F.y = F.y > 1 ? F.y : 1; // the dropped child returns at least 1
                                 frm[f] = F;
                                 PROF(++pn_pruned);
+                                PROF({ const unsigned long long z = __builtin_amdgcn_s_memtime(); px_c += z - px_t; px_t = z; });
                                 continue;
                             }
                             if (export_mode && nl - (f + 1) >= (int)min_levels) {
@@ -1231,6 +1249,7 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
                         frm[f] = make_uchar4(0, 0, F_MATCHED, (unsigned char)(nm + 1));
                         if (f < sfr) sfr = f;
                         PROF(++pn_desc);
+                        PROF({ const unsigned long long z = __builtin_amdgcn_s_memtime(); px_d += z - px_t; px_t = z; });
                         need_exp = true;
                         break;
                     }
@@ -1256,6 +1275,7 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
                     uchar4 Pf = frm[f];
                     Pf.y = Pf.y > ret ? Pf.y : ret;
                     frm[f] = Pf;
+                    PROF({ const unsigned long long z = __builtin_amdgcn_s_memtime(); px_r += z - px_t; px_t = z; });
                 }
             }
             if (need_exp) expand(f);
@@ -1295,6 +1315,8 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
         if (lane == 0) {
             atomicAdd(pr + 0, pc_all); atomicAdd(pr + 1, pc_share); atomicAdd(pr + 2, pc_expand); atomicAdd(pr + 3, pc_adv);
             atomicAdd(pr + 4, total_iters);
+            unsigned long long *px = reinterpret_cast<unsigned long long *>(p.dbg + 160) + (TASKS ? 8 : 0);
+            atomicAdd(px + 0, px_a); atomicAdd(px + 1, px_b); atomicAdd(px + 2, px_c); atomicAdd(px + 3, px_d); atomicAdd(px + 4, px_r); atomicAdd(px + 5, px_n);
         }
         if (c == 0) {
             atomicAdd(pr + 5, (unsigned long long)pn_leaf); atomicAdd(pr + 6, (unsigned long long)pn_exp);
@@ -1313,9 +1335,10 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
         best = o > best ? o : best;
     }
     if (lane == 0) {
-        atomicAdd(p.nsteps, nsteps);
-        atomicAdd(p.nsteps + 1, total_iters);
-        atomicMax(p.nsteps + (TASKS ? 3 : 2), total_iters); // longest job of the launch (tail diagnostics)
+        unsigned long long *st = p.nsteps + 4 * (blockIdx.x & (kStatShards - 1));
+        atomicAdd(st, nsteps);
+        atomicAdd(st + 1, total_iters);
+        atomicMax(st + (TASKS ? 3 : 2), total_iters); // longest job of the launch (tail diagnostics)
     }
     exported = __ballot(exported) != 0;
     if (TASKS || exported) { // split ligand: combine across waves, score comes from finalize_kernel
