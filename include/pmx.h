@@ -150,8 +150,10 @@ int pmx_topk_allgather(pmx_comm *comm, const float *scores_k_dev, const uint64_t
  * feature (`pharmacophore_list` order, ligand_utils.py:80-88) its type id, the atom indices and the centre indices, with
  * flags bit 0 / bit 1 telling whether atom_indices / center_indices was a tuple rather than an int (an int and a
  * 1-tuple are different node keys, ligand.py:137); positions float32 [n_atoms][n_conformers][3] per molecule.
- * offsets_out[n_mols + 1] and data_out receive the library; *data_bytes the bytes written (or needed, when data_cap is
- * too small - call once with data_cap = 0 to size the buffer). status_out (may be NULL): 1 for a molecule outside the
+ * offsets_out[n_mols + 1] and data_out receive the library; *data_bytes the bytes written. Sizing: a call with data_out =
+ * NULL packs nothing and returns in *data_bytes an upper bound (every feature a node) - allocate that, pack once, keep the
+ * first *data_bytes bytes. With a data_cap that turns out too small the call fails and *data_bytes holds the exact need.
+ * status_out (may be NULL): 1 for a molecule outside the
  * structural limits above, which becomes a header-only record that pmx_score reports as PMX_LIGAND_UNSUPPORTED.
  */
 typedef struct {

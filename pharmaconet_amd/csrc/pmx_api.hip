@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -380,13 +381,18 @@ static bool trace_on() {
     if (v < 0) v = std::getenv("PMX_TRACE") ? 1 : 0;
     return v == 1;
 }
-#define TRACE(...)                        \
-    do {                                  \
-        if (trace_on()) {                 \
-            fprintf(stderr, "[pmx] " __VA_ARGS__); \
-            fprintf(stderr, "\n");        \
-            fflush(stderr);               \
-        }                                 \
+static double trace_ms() { // milliseconds since the first trace line of the process
+    static const auto t0 = std::chrono::steady_clock::now();
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+#define TRACE(...)                                       \
+    do {                                                 \
+        if (trace_on()) {                                \
+            fprintf(stderr, "[pmx %10.3f] ", trace_ms()); \
+            fprintf(stderr, __VA_ARGS__);                \
+            fprintf(stderr, "\n");                       \
+            fflush(stderr);                              \
+        }                                                \
     } while (0)
 
 static constexpr int kRetrySmaller = -100; // internal: the chunk's tables exceed the arena limit

@@ -294,6 +294,10 @@ extern "C" int pmx_pack_features(const pmx_feature_batch *b, int threads, uint64
         const uint64_t c = (uint64_t)std::max(b->n_conf[i], 1);
         room[i + 1] = room[i] + ((8 + 2 * nf + 3 + 12 * nf * c + 15) & ~15ull) + 16;
     }
+    if (!data_out) { // sizing call: the bound, without packing anything
+        *data_bytes = room[n];
+        return PMX_OK;
+    }
     std::unique_ptr<uint8_t[]> scratch_mem(new uint8_t[room[n] + 16]); // not zero-filled: pack_one clears what it writes
     uint8_t *scratch = scratch_mem.get();
     std::vector<int64_t> sizes(n, 0);
@@ -342,7 +346,7 @@ extern "C" int pmx_pack_features(const pmx_feature_batch *b, int threads, uint64
     }
     offsets_out[n] = total;
     *data_bytes = total;
-    if (total > data_cap) return data_out ? pmx_topk_fail(PMX_ERR_INVALID, "data_out too small (data_bytes holds the size needed)") : PMX_OK;
+    if (total > data_cap) return pmx_topk_fail(PMX_ERR_INVALID, "data_out too small (data_bytes holds the size needed)");
     next = 0;
     auto compact = [&]() {
         for (;;) {

@@ -347,10 +347,10 @@ def pack_features_native(mols: Sequence[LigandFeatures] | dict[str, np.ndarray],
     status = np.zeros(n, dtype=np.int32)
     nbytes = ctypes.c_uint64(0)
     _ffi.check(lib.pmx_pack_features(ctypes.byref(batch), int(threads), offsets.ctypes.data, None, 0, ctypes.byref(nbytes), status.ctypes.data))
-    data = np.zeros(int(nbytes.value), dtype=np.uint8)
+    data = np.empty(int(nbytes.value), dtype=np.uint8)  # the sizing call returns an upper bound; the molecules are packed once
     _ffi.check(lib.pmx_pack_features(ctypes.byref(batch), int(threads), offsets.ctypes.data, data.ctypes.data, data.size, ctypes.byref(nbytes),
                                      status.ctypes.data))
-    return PackedLibrary(offsets, data), status
+    return PackedLibrary(offsets, data[: int(nbytes.value)]), status
 
 
 class LigandTooLarge(ValueError):

@@ -6,7 +6,9 @@ Per ligand-conformer it counts
   unique      distinct (u, v, m, n) among them (a model node sits in several clusters: density_map.py:131-177)
   unique_all  distinct (u, v, m, n) without the cluster-distance prefilter (graph_match.py:263-268)
   direct_all  terms without the prefilter
-and the sizes that decide a lane mapping (entries, near entries, items, node-list lengths).
+and the sizes that decide a lane mapping (entries, near entries, items, node-list lengths); then it replays
+tables_kernel_v2's mapping (8 items side by side, columns in batches of W) and prints the share of term slots that
+carry a term, for W = 1, 2, 3 (the kernel uses 3).
 
     python tools/analyze_terms.py [--ligands 400] [--model tests/golden/model_6oim_like.pm]
 """
@@ -163,6 +165,47 @@ def main():
     print(f"  self: direct {tot['self_direct'] / N:.1f} unique {tot['self_unique'] / N:.1f}")
     nz = np.nonzero(hist_listlen)[0]
     print("  node-list length histogram (|A_a ∩ T(u)|):", {int(k): int(hist_listlen[k]) for k in nz})
+    lane_mapping(lib, fm, cn, tnodes, K)
+
+
+def lane_mapping(lib, fm, cn, tnodes, K, slots=8, chunk=32):
+    """tables_kernel_v2 gives the items (entry, u, v) of a cluster pair to its 8 lane groups in order, 32 entries at a
+    time; a wave step costs, row by row, the widest padded column list among the groups still having that row."""
+    pc = lambda x: bin(x).count("1")
+    ideal = 0
+    cost = {1: 0, 2: 0, 3: 0}
+    for li in range(len(lib)):
+        r = lib.unpack(li)
+        tm, ends = r["typemask"], r["cluster_end"]
+        levels, start = [], 0
+        for ci in range(r["n_clusters"]):
+            end, lmask = int(ends[ci]), 0
+            for u in range(start, end):
+                lmask |= int(tm[u])
+            cand = [a for a in range(K) if int(fm.cluster_typemask[a]) & lmask]
+            if cand and len(levels) < 20:
+                levels.append((start, end, cand))
+            start = end
+        for i in range(len(levels)):
+            si, ei, ci_ = levels[i]
+            for j in range(i + 1, len(levels)):
+                sj, ej, cj_ = levels[j]
+                entries = [(a, b) for a in ci_ for b in cj_]
+                for e0 in range(0, len(entries), chunk):
+                    items = [(pc(cn[a] & tnodes[int(tm[u])]), pc(cn[b] & tnodes[int(tm[v])]))
+                             for (a, b) in entries[e0:e0 + chunk] for u in range(si, ei) for v in range(sj, ej)]
+                    ideal += sum(na * nb for na, nb in items)
+                    for w0 in range(0, len(items), slots):
+                        grp = [x for x in items[w0:w0 + slots] if x[0] * x[1]]
+                        if not grp:
+                            continue
+                        for W in cost:
+                            for row in range(max(x[0] for x in grp)):
+                                cost[W] += max(W * ((x[1] + W - 1) // W) for x in grp if x[0] > row)
+    n = len(lib)
+    print(f"  lane mapping of tables_kernel_v2 (pair tables, prefilter ignored): {ideal / n / slots:.0f} wave-terms per ligand if every slot carried a term;")
+    for W in sorted(cost):
+        print(f"    column batches of {W}: {cost[W] / n:.0f} term slots per ligand, {ideal / slots / cost[W]:.1%} filled")
 
 
 if __name__ == "__main__":

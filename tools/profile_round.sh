@@ -2,6 +2,9 @@
 # Run on the GPU box (through gpurun): kernel stats, the PMC passes (separate runs, --pmc only) and the bench line of the
 # production pipeline, then tools/collect_profiles.py turns them into the tracked summaries under profiles/.
 #   gpurun -- 'bash tools/profile_round.sh'
+# then, in the repository (gpurun merges gpurun_out/ back, not profiles/):
+#   O=gpurun_out/prof_r2; python tools/collect_profiles.py $O/bench.json $O/stats/*kernel_stats.csv $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_SQ 200704
+#   cp $O/fused_engine_traffic.json profiles/r2_fused_engine_traffic.json
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_r2
@@ -41,8 +44,14 @@ try:
 except Exception as e:
     res["bench"] = repr(e)
 json.dump(res, open("profiles/r2_fused_engine_traffic.json", "w"), indent=1)
+json.dump(res, open("$OUT/fused_engine_traffic.json", "w"), indent=1)  # gpurun brings back gpurun_out/ only: copy it into profiles/ afterwards
 print("fused engine:", res["total_hbm_bytes_per_ligand"], "B/ligand", res["bench"])
 PY
 STATS=$(ls $OUT/stats/*kernel_stats.csv | head -1)
 python tools/collect_profiles.py $OUT/bench.json $STATS $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_SQ 200704
-tail -1 $OUT/bench.json | cut -c1-400
+tail -1 $OUT/bench.json | cut -c1-400; rm -f $OUT/pipelines.txt
+# concurrency sweep for DESIGN.md section 3 (stream discipline)
+for p in 1 2 3 4; do
+  echo "pipelines=$p $(PMX_PIPELINES=$p python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-serial-leg 2>/dev/null | tail -1 | python -c 'import json,sys; d=json.loads(sys.stdin.read()); print(d["value"], d["ms_per_step"])')" >> $OUT/pipelines.txt
+done
+cat $OUT/pipelines.txt
