@@ -8,9 +8,11 @@
  *
  * Conventions: every function returns 0 on success and a non-zero pmx_status otherwise;
  * pmx_last_error() gives the calling thread's last message. No exceptions cross the boundary.
- * Handles are opaque; a handle is bound to the device it was created on. Calls on one handle are
- * not re-entrant; distinct handles / streams are independent. `stream` is a hipStream_t passed as
- * void* (NULL = the default stream). Pointers named *_dev are device pointers on that device.
+ * Handles are opaque; a handle is bound to the device it was created on. Every entry point may be called from
+ * any thread. pmx_score / pmx_score_multi of the default engine share per-device workspaces and are serialised by
+ * one process-wide lock (a second caller waits; each call already fills the GPU with its own concurrent pipelines);
+ * creating, uploading, ranking, packing and the communicator calls do not take that lock. `stream` is a hipStream_t
+ * passed as void* (NULL = the default stream). Pointers named *_dev are device pointers on that device.
  */
 #ifndef PMX_H
 #define PMX_H

@@ -119,6 +119,9 @@ __device__ inline void wave_lds_sync() {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 }
 
+#ifndef PMX_V2_BATCH
+#define PMX_V2_BATCH 3 // columns per batch of the term loops: 3 measured best (1 fills more slots but gives up the read batching)
+#endif
 // --------------------------------------------------------------------------- table kernels: helpers
 
 struct Pos {
@@ -208,7 +211,7 @@ __device__ inline void node_pair(const float4 *tab, int Ns, uint64_t A, uint64_t
 // (count != 0xff). `tab` has Ns = Nm + 1 columns; column Nm is neutral ({0, 0, -1, 0}: contributes exactly 0 to
 // the sum and never counts as a pass), so the padding of the last batch needs no per-term masking.
 __device__ inline void node_pair_lists(const float4 *tab, int Ns, const uint4 la, const uint4 lb, float d, float &acc, int &npass) {
-    constexpr int W = 3, NCOL = 12;
+    constexpr int W = PMX_V2_BATCH, NCOL = 12;
     const int na = (int)(la.x & 255u), nc = (int)(lb.x & 255u);
     int col[NCOL]; // absent columns hold the neutral column (weight 0, threshold -1): no masking per term
     col[0] = (lb.x >> 8) & 255u, col[1] = (lb.x >> 16) & 255u, col[2] = lb.x >> 24;

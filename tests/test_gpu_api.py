@@ -228,3 +228,35 @@ def test_scores_do_not_depend_on_how_the_work_is_cut(monkeypatch):
             assert stats["n_chunks"] >= 8
         if env.get("PMX_TREE_FLAGS") == "4":
             assert stats["n_steps"] > 2 * steps_default  # the bound test is what keeps the trees small
+
+
+def test_concurrent_callers_are_serialised_not_corrupted():
+    """include/pmx.h: pmx_score may be called from any thread; calls of the default engine share per-device workspaces
+    and take one lock. Two threads screening different libraries at once get the scores they get alone."""
+    import threading
+
+    import torch
+
+    model, lib, _, expected = load_golden("set_6oim_c8")
+    model2, lib2, _, expected2 = load_golden("set_c21_c8")
+    alone = [model.screen(lib).scores.cpu().numpy(), model2.screen(lib2).scores.cpu().numpy()]
+    got = [None, None]
+    errors = []
+
+    def worker(slot, m, l):
+        try:
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                for _ in range(3):
+                    got[slot] = m.screen(l).scores.cpu().numpy()
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(0, model, lib)), threading.Thread(target=worker, args=(1, model2, lib2))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    np.testing.assert_array_equal(got[0], alone[0])
+    np.testing.assert_array_equal(got[1], alone[1])

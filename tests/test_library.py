@@ -125,3 +125,34 @@ def test_native_packer_marks_oversized_molecules():
     lib, status = pack_features_native([small, big, small], threads=2)
     assert status.tolist() == [0, 1, 0]
     assert lib.record(1) == UNSUPPORTED_RECORD and lib.record(0) == lib.record(2) == pack_ligand(small)
+
+
+def test_native_packer_sizing_protocol():
+    """include/pmx.h: a call without a buffer packs nothing and returns an upper bound; a buffer that turns out too small
+    makes the call fail with the exact need in *data_bytes; with room, *data_bytes is what was written."""
+    import ctypes
+
+    from pharmaconet_amd import _ffi
+    from pharmaconet_amd.library import flatten_features
+
+    mols = list(golden_molecules("set_6oim_c8"))
+    want = PackedLibrary.load(GOLDEN / "set_6oim_c8.pmxlib")
+    flat = flatten_features(mols)
+    lib = _ffi.load(need_torch=False)
+    n = len(mols)
+    batch = _ffi.FeatureBatch(n, *(flat[k].ctypes.data for k in (
+        "atom_off", "atomic_num", "nbr_off", "nbr", "feat_off", "feat_type", "feat_flags", "feat_atom_off", "feat_atoms",
+        "feat_center_off", "feat_centers", "n_conf", "pos_off", "positions")))
+    offsets = np.zeros(n + 1, dtype=np.uint64)
+    nbytes = ctypes.c_uint64(0)
+    assert lib.pmx_pack_features(ctypes.byref(batch), 2, offsets.ctypes.data, None, 0, ctypes.byref(nbytes), None) == 0
+    bound = int(nbytes.value)
+    assert bound >= want.data.size
+    small = np.zeros(want.data.size - 16, dtype=np.uint8)
+    assert lib.pmx_pack_features(ctypes.byref(batch), 2, offsets.ctypes.data, small.ctypes.data, small.size, ctypes.byref(nbytes), None) != 0
+    assert int(nbytes.value) == want.data.size  # the exact need
+    data = np.zeros(bound, dtype=np.uint8)
+    assert lib.pmx_pack_features(ctypes.byref(batch), 2, offsets.ctypes.data, data.ctypes.data, data.size, ctypes.byref(nbytes), None) == 0
+    assert int(nbytes.value) == want.data.size
+    assert data[: want.data.size].tobytes() == want.data.tobytes()
+    np.testing.assert_array_equal(offsets, want.offsets)
