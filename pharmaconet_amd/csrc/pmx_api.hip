@@ -273,7 +273,8 @@ extern "C" int pmx_library_destroy(pmx_library *lib) {
 // Chunks are software-pipelined over two buffer slots: while the tree kernels of chunk k run on the caller's
 // stream, the table kernels of chunk k + 1 run on an internal side stream. The two phases bind differently
 // (tables: VALU / LDS; tree search: memory latency), so their wavefronts share the CUs well.
-constexpr size_t kMetaBytes = 1024 + (size_t)kStatShards * 32; // counters + the tree kernels' sharded statistics
+constexpr size_t kMetaBytes = 1024 + (size_t)kStatShards * 32 + (size_t)kQueueShards * 4; // counters + the tree kernels' sharded statistics + the task queue's tails
+constexpr size_t kTailWord = 256 + (size_t)kStatShards * 8;                               // first tail, in 32-bit words
 
 struct Slot {
     uint32_t *units = nullptr;
@@ -281,7 +282,7 @@ struct Slot {
     uint64_t *taboff = nullptr;
     uint8_t *arena = nullptr;
     size_t arena_cap = 0;
-    uint32_t *meta = nullptr;      // device: [0] max levels, [1] fetch counter, [2..3] table bytes (u64), [4] task queue tail, [5] queue overflow, [14] / [15] ligand cursors of the table kernel, [32..] debug and profiling words; then kStatShards x 4 u64 of tree statistics
+    uint32_t *meta = nullptr;      // device: [0] max levels, [1] fetch counter, [2..3] table bytes (u64), [5] queue overflow flag, [14] / [15] ligand cursors of the table kernel, [32..] debug and profiling words; then kStatShards x 4 u64 of tree statistics and the kQueueShards tails of the task queue
     uint32_t *meta_host = nullptr; // pinned mirror
     BinInfo *bins = nullptr;               // table phase: LDS size classes of the chunk's ligands
     uint32_t *caps_dev = nullptr;
@@ -569,11 +570,11 @@ static int tree_phase(const pmx_model *model, const pmx_library *lib, int32_t *s
     tp.lib = lib->dl;
     tp.first = lig0;
     tp.count = n;
-    tp.task_lo = 0;
-    tp.counter = sl.meta + 1;
-    tp.qtail = sl.meta + 4;
+    tp.qtail = sl.meta + kTailWord;
+    tp.qflag = sl.meta + 5;
     tp.queue = ws.queue;
-    tp.qcap = (uint32_t)std::min<size_t>(ws.queue_bytes / task_bytes<G>(), 0x7fffffffu);
+    tp.qcap = (uint32_t)std::min<size_t>(ws.queue_bytes / task_bytes<G>() / kQueueShards, 0x7fffffffu / kQueueShards);
+    for (int sh = 0; sh < kQueueShards; ++sh) tp.shard_lo[sh] = tp.shard_hi[sh] = 0;
     tp.bestbuf = sl.bestbuf;
     tp.deferred = sl.deferred;
     tp.depth_cap = depth;
@@ -592,7 +593,7 @@ static int tree_phase(const pmx_model *model, const pmx_library *lib, int32_t *s
     HIPCHECK(hipGetLastError());
     if (g_profiling) HIPCHECK(hipEventRecord(sl.ev[4], stream));
     // rounds over the task queue: walkers that ran over budget appended subtrees
-    uint32_t lo = 0;
+    bool any_task = false;
     for (;;) {
         HIPCHECK(hipMemcpyAsync(sl.meta_host, sl.meta, kMetaBytes, hipMemcpyDeviceToHost, stream));
         HIPCHECK(hipStreamSynchronize(stream));
@@ -606,11 +607,17 @@ static int tree_phase(const pmx_model *model, const pmx_library *lib, int32_t *s
             tstat[2] = std::max(tstat[2], v[2]);
             tstat[3] = std::max(tstat[3], v[3]);
         }
-        if (lo == 0 && g_stats.n_rounds == 0) {
+        if (!any_task && g_stats.n_rounds == 0) {
             g_stats.n_steps_first += tstat[0];
         }
-        const uint32_t hi = std::min<uint32_t>(mh[4], tp.qcap);
-        TRACE("round: lo=%u hi=%u steps=%llu iters=%llu", lo, hi, tstat[0], tstat[1]);
+        // this round: what every shard of the queue has received since the last one
+        uint64_t round_tasks = 0;
+        for (int sh = 0; sh < kQueueShards; ++sh) {
+            tp.shard_lo[sh] = tp.shard_hi[sh];
+            tp.shard_hi[sh] = std::min<uint32_t>(mh[kTailWord + sh], tp.qcap);
+            round_tasks += tp.shard_hi[sh] - tp.shard_lo[sh];
+        }
+        TRACE("round: %llu tasks, steps=%llu iters=%llu", (unsigned long long)round_tasks, tstat[0], tstat[1]);
         if (mh[5]) g_stats.queue_overflow = 1;
         if (mh[32] == 2) return fail(PMX_ERR_INVALID, "tree kernel watchdog fired at location %u", mh[35]);
         if (mh[32]) {
@@ -622,7 +629,7 @@ static int tree_phase(const pmx_model *model, const pmx_library *lib, int32_t *s
             }
             return fail(PMX_ERR_INVALID, "%s", buf);
         }
-        if (hi <= lo) {
+        if (round_tasks == 0) {
             g_stats.n_steps += tstat[0];
             g_stats.n_iters += tstat[1];
             g_stats.max_iters_ligand = std::max<uint64_t>(g_stats.max_iters_ligand, tstat[2]);
@@ -641,15 +648,14 @@ static int tree_phase(const pmx_model *model, const pmx_library *lib, int32_t *s
 #endif
             break;
         }
-        tp.count = hi - lo;
-        tp.task_lo = lo;
+        tp.count = (uint32_t)round_tasks;
         tree_kernel<G, true><<<dim3(tp.count), dim3(64), lds, stream>>>(tp);
         HIPCHECK(hipGetLastError());
         g_stats.n_tasks += tp.count;
         g_stats.n_rounds += 1;
-        lo = hi;
+        any_task = true;
     }
-    if (lo > 0) {
+    if (any_task) {
         finalize_kernel<G><<<dim3((n + 255) / 256), dim3(256), 0, stream>>>(lib->dl, lig0, n, sl.deferred, sl.bestbuf, scores);
         HIPCHECK(hipGetLastError());
     }

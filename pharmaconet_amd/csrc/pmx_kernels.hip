@@ -658,6 +658,7 @@ __host__ __device__ constexpr uint32_t task_bytes() {
 }
 
 constexpr int kStatShards = 256;
+constexpr int kQueueShards = 64; // = the wave size: a task wave finds its record with one scan over the shards' ranges
 
 struct TreeParams {
     const uint8_t *arena;
@@ -665,12 +666,15 @@ struct TreeParams {
     const int32_t *status;
     DevLibrary lib;
     uint64_t first;      // library index of the chunk's first ligand
-    uint32_t count;      // jobs: ligands (TASKS = false) or tasks [task_lo, task_lo + count)
-    uint32_t task_lo;
-    uint32_t *counter;   // (unused by the block-per-job launch; kept for diagnostics)
-    uint32_t *qtail;     // task queue tail; qtail[1] = overflow flag
+    uint32_t count;      // jobs: ligands (TASKS = false) or the tasks of this round (TASKS = true)
+    // The task queue is kQueueShards independent queues (shard s owns records [s * qcap, (s + 1) * qcap)); a wave appends to
+    // shard blockIdx % kQueueShards. One tail for the whole GPU was a single address taking ~10^6 returning atomics per
+    // chunk: the exporting waves queued on it (12 % of the first-tier kernel with the appends already pooled per wave).
+    uint32_t *qtail;     // [kQueueShards] tails
+    uint32_t *qflag;     // set when a shard is full (the walker then keeps the subtree)
     uint8_t *queue;
-    uint32_t qcap;
+    uint32_t qcap;       // records per shard
+    uint32_t shard_lo[kQueueShards], shard_hi[kQueueShards]; // TASKS: this round's records of each shard
     unsigned long long *bestbuf; // [chunk][G]
     uint8_t *deferred;           // [chunk] ligand was split: score comes from bestbuf
     int depth_cap;
@@ -805,8 +809,10 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
     const uint32_t budget = p.budget, qcap = p.qcap, flags = p.flags, min_levels = p.min_levels, share_levels = p.share_levels;
     const uint32_t step_cap = p.step_cap;
     const unsigned long long max_iters = p.max_iters;
-    uint32_t *const qtail = p.qtail;
-    uint8_t *const queue = p.queue;
+    const uint32_t shard = blockIdx.x & (kQueueShards - 1);
+    uint32_t *const qtail = p.qtail + shard;
+    uint32_t *const qflag = p.qflag;
+    uint8_t *const queue = p.queue + (size_t)shard * qcap * task_bytes<G>(); // this wave's shard
     const unsigned long long below = (g == 0) ? 0ull : ((1ull << (g * G)) - 1ull); // lanes of lower groups
 
     // ---- LDS carve
@@ -944,6 +950,16 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
         return tget(nmr) + (double)St[(size_t)(ksr + b) * G + c] + pair_sum<G>(Pt, mat, nmr, ksr, kr, b, c);
     };
     // a frame may give children away once it has >= 4 matches (their subtrees hold >= 5, see above)
+    // One queue slot for every group that is exporting a subtree at this point of the program: the groups that got here
+    // together share one atomic on the queue tail (it is a single address for the whole GPU, ~10^6 exports per chunk)
+    auto reserve_slot = [&]() -> uint32_t {
+        const unsigned long long heads = __ballot(c == 0); // lane 0 of every group present
+        const int leader = __ffsll(heads) - 1;
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(qtail, (uint32_t)__popcll(heads));
+        base = __shfl(base, leader);
+        return base + (uint32_t)__popcll(heads & below);
+    };
     auto donatable = [&](int fr) -> bool {
         const uchar4 Fr = frm[fr];
         return Fr.w >= 4 && (Fr.z & F_EXPANDED) && todo[fr] != 0;
@@ -1128,11 +1144,9 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
                     uint64_t left = todo[fr];
                     while (left) {
                         PMX_GUARD(7);
-                        uint32_t slot = 0;
-                        if (c == 0) slot = atomicAdd(qtail, 1u);
-                        slot = __shfl(slot, g * G);
+                        const uint32_t slot = reserve_slot();
                         if (slot >= qcap) { // queue full: the walker keeps the rest
-                            if (c == 0) qtail[1] = 1;
+                            if (c == 0) *qflag = 1;
                             break;
                         }
                         const int b = __ffsll((unsigned long long)left) - 1;
@@ -1160,7 +1174,7 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
                         for (uint32_t w = c; w < task_bytes<G>() / 16; w += G) dst[w] = src[w];
                         gave = true;
                     } else if (c == 0) {
-                        qtail[1] = 1; // cannot happen in practice: entry is lost only if the queue is full
+                        *qflag = 1; // cannot happen in practice: entry is lost only if the queue is full
                     }
                 }
             }
@@ -1169,7 +1183,7 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
             // walker reaches them, so this wave only finishes the part of the tree it cannot split.
             export_mode = true;
             // entries that did not fit stay on the local stack only if the queue was full; keep them
-            if (!__builtin_amdgcn_readfirstlane((int)qtail[1])) sp = 0;
+            if (!__builtin_amdgcn_readfirstlane((int)*qflag)) sp = 0;
         }
 
         PROF(pt1 = __builtin_amdgcn_s_memtime(); pc_share += pt1 - pt0);
@@ -1230,9 +1244,7 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
                                 continue;
                             }
                             if (export_mode && nl - (f + 1) >= (int)min_levels) {
-                                uint32_t slot = 0;
-                                if (c == 0) slot = atomicAdd(qtail, 1u);
-                                slot = __shfl(slot, g * G);
+                                const uint32_t slot = reserve_slot();
                                 if (slot < qcap) {
                                     describe(reinterpret_cast<TaskHeader *>(queue + (size_t)slot * task_bytes<G>()), f, nm, b, m, t, false);
                                     F.y = F.y > 1 ? F.y : 1; // the child given away returns at least 1
@@ -1241,7 +1253,7 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
                                     PROF(++pn_exported);
                                     continue;
                                 }
-                                if (c == 0) qtail[1] = 1; // queue full: walk it here
+                                if (c == 0) *qflag = 1; // queue full: walk it here
                             }
                         }
                         tset(nm + 1, t);
@@ -1375,7 +1387,20 @@ __global__ __launch_bounds__(64, PMX_TREE_WAVES) void tree_kernel(const TreePara
     uint32_t li = nx;
     int status = PMX_LIGAND_OK;
     if (TASKS) {
-        task = reinterpret_cast<const TaskHeader *>(p.queue + (size_t)(p.task_lo + nx) * task_bytes<G>());
+        // block nx -> (shard, record): inclusive scan of the shards' record counts over the lanes
+        const uint32_t lo_l = p.shard_lo[lane], cnt_l = p.shard_hi[lane] - lo_l;
+        uint32_t inc = cnt_l;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = __shfl_up(inc, d);
+            if (lane >= d) inc += t;
+        }
+        const int sh = __popcll(__ballot(nx >= inc)); // shards wholly before block nx (inc is non-decreasing)
+        const uint32_t before = sh ? (uint32_t)__shfl(inc, sh - 1) : 0u;
+        const uint32_t rec = (uint32_t)__shfl(lo_l, sh) + (nx - before);
+        const uint64_t tbits = reinterpret_cast<uint64_t>(p.queue + ((size_t)sh * p.qcap + rec) * task_bytes<G>());
+        task = reinterpret_cast<const TaskHeader *>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(tbits >> 32)) << 32) |
+                                                    (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)tbits)); // wave-uniform
         li = __builtin_amdgcn_readfirstlane(task->lig);
     } else {
         status = __builtin_amdgcn_readfirstlane(p.status[li]);
