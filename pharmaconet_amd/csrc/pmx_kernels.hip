@@ -829,10 +829,9 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
     const uint32_t budget = p.budget, qcap = p.qcap, flags = p.flags, min_levels = p.min_levels, share_levels = p.share_levels;
     const uint32_t step_cap = p.step_cap;
     const unsigned long long max_iters = p.max_iters;
-    const uint32_t shard = blockIdx.x & (kQueueShards - 1);
-    uint32_t *const qtail = p.qtail + shard;
     uint32_t *const qflag = p.qflag;
-    uint8_t *const queue = p.queue + (size_t)shard * qcap * task_bytes<G>(); // this wave's shard
+    uint8_t *const queue = p.queue;
+    constexpr uint32_t kNoSlot = 0xffffffffu;
     const unsigned long long below = (g == 0) ? 0ull : ((1ull << (g * G)) - 1ull); // lanes of lower groups
 
     // ---- LDS carve
@@ -972,13 +971,20 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
     // a frame may give children away once it has >= 4 matches (their subtrees hold >= 5, see above)
     // One queue slot for every group that is exporting a subtree at this point of the program: the groups that got here
     // together share one atomic on the queue tail (it is a single address for the whole GPU, ~10^6 exports per chunk)
-    auto reserve_slot = [&]() -> uint32_t {
+    // The shard a wave appends to: its own (blockIdx mod kQueueShards) for 64 wave iterations at a time, then the next one -
+    // a wave's tasks stay together (consecutive task waves work on one ligand's tables) and a monster tree that exports for
+    // tens of thousands of iterations fills all shards, not one. (Derived from the iteration count, which is live anyway:
+    // the walker has no register to spare for a cursor.)
+    auto my_shard = [&]() -> uint32_t { return (blockIdx.x + (uint32_t)(total_iters >> 6)) & (kQueueShards - 1); };
+    auto reserve_slot = [&]() -> uint32_t { // record index in the whole queue, or kNoSlot when the shard is full
         const unsigned long long heads = __ballot(c == 0); // lane 0 of every group present
         const int leader = __ffsll(heads) - 1;
+        const uint32_t sh = my_shard();
         uint32_t base = 0;
-        if (lane == leader) base = atomicAdd(qtail, (uint32_t)__popcll(heads));
+        if (lane == leader) base = atomicAdd(p.qtail + sh, (uint32_t)__popcll(heads));
         base = __shfl(base, leader);
-        return base + (uint32_t)__popcll(heads & below);
+        const uint32_t slot = base + (uint32_t)__popcll(heads & below);
+        return slot < qcap ? sh * qcap + slot : kNoSlot;
     };
     auto donatable = [&](int fr) -> bool {
         const uchar4 Fr = frm[fr];
@@ -1165,7 +1171,7 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
                     while (left) {
                         PMX_GUARD(7);
                         const uint32_t slot = reserve_slot();
-                        if (slot >= qcap) { // queue full: the walker keeps the rest
+                        if (slot == kNoSlot) { // queue full: the walker keeps the rest
                             if (c == 0) *qflag = 1;
                             break;
                         }
@@ -1185,10 +1191,12 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
                 PMX_GUARD(8);
                 const int e = e0 + g;
                 uint32_t slot = 0;
-                if (e < sp && c == 0) slot = atomicAdd(qtail, 1u);
+                const uint32_t sh = my_shard();
+                if (e < sp && c == 0) slot = atomicAdd(p.qtail + sh, 1u);
                 slot = __shfl(slot, g * G);
                 if (e < sp) {
                     if (slot < qcap) {
+                        slot += sh * qcap;
                         const uint4 *src = reinterpret_cast<const uint4 *>(lstk + (size_t)e * task_bytes<G>());
                         uint4 *dst = reinterpret_cast<uint4 *>(queue + (size_t)slot * task_bytes<G>());
                         for (uint32_t w = c; w < task_bytes<G>() / 16; w += G) dst[w] = src[w];
@@ -1265,7 +1273,7 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
                             }
                             if (export_mode && nl - (f + 1) >= (int)min_levels) {
                                 const uint32_t slot = reserve_slot();
-                                if (slot < qcap) {
+                                if (slot != kNoSlot) {
                                     describe(reinterpret_cast<TaskHeader *>(queue + (size_t)slot * task_bytes<G>()), f, nm, b, m, t, false);
                                     F.y = F.y > 1 ? F.y : 1; // the child given away returns at least 1
                                     frm[f] = F;
