@@ -368,7 +368,7 @@ static int ensure_workspace(int device, int pipeline, Workspace **out) {
         }
     }
     if (!w.queue) {
-        w.queue_bytes = (size_t)std::max<long>(16, env_long("PMX_TASKQ_MB", 2048)) << 20;
+        w.queue_bytes = (size_t)std::max<long>(1, env_long("PMX_TASKQ_MB", 2048)) << 20;
         HIPCHECK(hipMalloc((void **)&w.queue, w.queue_bytes));
     }
     *out = &w;

@@ -260,3 +260,36 @@ def test_concurrent_callers_are_serialised_not_corrupted():
     assert not errors, errors
     np.testing.assert_array_equal(got[0], alone[0])
     np.testing.assert_array_equal(got[1], alone[1])
+
+
+def test_full_task_queue_changes_nothing_but_time(monkeypatch):
+    """The queue of exported subtrees is 64 shards of fixed size. When a wave finds its shard full it keeps the subtree
+    and walks it itself (and the call reports `queue_overflow`): same bits."""
+    import torch
+
+    from pharmaconet_amd import engine
+    from pharmaconet_amd.constants import TYPE_ID
+    from pharmaconet_amd.engine import DeviceLibrary
+    from pharmaconet_amd.synthetic import expand_library_on_device, synthetic_library
+
+    model, _, _, _ = load_golden("set_6oim_c8")
+    st = model.__getstate__()
+    centers = np.array([n["center"] for n in st["nodes"]])
+    types = np.array([TYPE_ID[n["type"]] for n in st["nodes"]])
+    base = synthetic_library(256, num_conformers=8, model_nodes=(centers, types), conformer_noise=0.0, seed=4242)
+    offsets, data = expand_library_on_device(base, 40, "cuda")  # 10,240 ligands
+    lib = DeviceLibrary.from_device_buffers(offsets, data)
+    want = model.screen(lib).scores
+    assert engine.last_score_stats()["queue_overflow"] == 0
+    engine.release_workspaces()  # the queue is sized when a workspace is created
+    try:
+        with monkeypatch.context() as mp:
+            mp.setenv("PMX_TASKQ_MB", "1")  # 128 records per shard
+            mp.setenv("PMX_BUDGET", "64")   # export early and often
+            mp.setenv("PMX_PIPELINES", "1")
+            got = model.screen(lib).scores
+            stats = engine.last_score_stats()
+        assert stats["queue_overflow"] == 1  # otherwise this test shows nothing
+        assert torch.equal(got, want)
+    finally:
+        engine.release_workspaces()
