@@ -169,6 +169,14 @@ extern "C" int pmx_model_create(const pmx_model_desc *d, int device, pmx_model *
     unsigned char *b8 = static_cast<unsigned char *>(blob);
     m->dm.Nm = Nm;
     m->dm.K = K;
+    m->dm.symmetric = 1;
+    for (int a = 0; a < Nm && m->dm.symmetric; ++a)
+        for (int b = 0; b < a; ++b)
+            if (std::memcmp(&d->edge_mean[a * Nm + b], &d->edge_mean[b * Nm + a], 4) || std::memcmp(&d->edge_std[a * Nm + b], &d->edge_std[b * Nm + a], 4)) {
+                m->dm.symmetric = 0;
+                break;
+            }
+    m->dm.pad_ = 0;
     m->dm.edge = reinterpret_cast<const float4 *>(b8 + off_edge);
     m->dm.node_type = b8 + off_type;
     m->dm.cnodes = reinterpret_cast<const uint64_t *>(b8 + off_cnodes);

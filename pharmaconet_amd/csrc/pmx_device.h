@@ -16,6 +16,8 @@ namespace pmx {
 //       (src/pmnet/scoring/match_utils.py:55-57) without a division in the inner loop.
 struct DevModel {
     int32_t Nm, K;
+    int32_t symmetric;        // edge[m][n] == edge[n][m] bit for bit (distances are; checked when the model is created)
+    int32_t pad_;
     const float4 *edge;       // [Nm * Nm]
     const uint8_t *node_type; // [64]
     const uint64_t *cnodes;   // [64]   model cluster -> node set

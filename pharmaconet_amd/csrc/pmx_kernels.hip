@@ -270,7 +270,12 @@ __device__ inline int cluster_node_pair(const DevModel &M, const float4 *tab, co
     const int na = (int)(la.x & 255u), nb = (int)(lb.x & 255u);
     if (na == 0 || nb == 0) return 0;
     if (na != 255 && nb != 255) {
-        node_pair_lists(tab, M.Nm + 1, la, lb, d, acc, npass);
+        // Columns come in batches of three, so the longer list makes the better columns (9 rows x 1 column costs 27 term
+        // slots, 1 row x 9 columns costs 9). The staged table is symmetric when the model's edges are (they are distances),
+        // so swapping the lists changes the order of the sum only.
+        const bool swap = M.symmetric && na * ((nb + 2) / 3) > nb * ((na + 2) / 3);
+        const uint4 rows = swap ? lb : la, cols = swap ? la : lb;
+        node_pair_lists(tab, M.Nm + 1, rows, cols, d, acc, npass);
         return na * nb;
     }
     const uint64_t A = cnodes[a] & tnodes[tmu], B = cnodes[b] & tnodes[tmv];
