@@ -1408,10 +1408,14 @@ __device__ __forceinline__ void run_job(const TreeParams &p, unsigned char *smem
 // block to whichever CU frees a slot, which is the dynamic load balancing a work counter would give,
 // and the kernel stays a straight line of wave-uniform branches around the walker.
 template <int G, bool TASKS>
-#ifndef PMX_TREE_WAVES
-#define PMX_TREE_WAVES 6 // waves per SIMD the register budget is set for: 6 -> <= 80 VGPRs, measured best (5 and 8 are slower)
+#define PMX_TREE_WAVES_DEFAULT 6
+#ifndef PMX_TASK_WAVES
+#define PMX_TASK_WAVES 4 // the task kernel: <= 128 VGPRs, nothing spilled - its short jobs gain more from that than from a fifth and sixth wave (98 vs 119 ms per pass; 3 is the same, 5 in between)
 #endif
-__global__ __launch_bounds__(64, PMX_TREE_WAVES) void tree_kernel(const TreeParams p) {
+#ifndef PMX_TREE_WAVES
+#define PMX_TREE_WAVES PMX_TREE_WAVES_DEFAULT // waves per SIMD the register budget is set for: 6 -> <= 80 VGPRs, measured best (5 and 8 are slower)
+#endif
+__global__ __launch_bounds__(64, TASKS ? PMX_TASK_WAVES : PMX_TREE_WAVES) void tree_kernel(const TreeParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const uint32_t nx = blockIdx.x;
