@@ -41,6 +41,7 @@ typedef enum {
 /* Per-ligand status written by pmx_score. */
 #define PMX_LIGAND_OK 0
 #define PMX_LIGAND_UNSUPPORTED 1 /* record exceeds a structural limit; score is NaN */
+#define PMX_LIGAND_TOO_LARGE 2   /* the ligand's score tables exceed the whole table arena (PMX_ARENA_MB); score is NaN */
 
 typedef struct pmx_model pmx_model;
 typedef struct pmx_library pmx_library;
@@ -194,6 +195,10 @@ typedef struct {
     uint64_t max_iters_ligand; /* wavefront iterations of the longest per-ligand job / task job (tail diagnostics) */
     uint64_t max_iters_task;
     uint64_t n_steps_first;  /* of which in the first (per-ligand) tree kernel of the first chunk with tasks */
+    uint64_t n_heavy;        /* ligands whose tree ran over its budget (their tables moved to the arena) */
+    uint64_t n_items;        /* (ligand node pair, table entry) items evaluated by the table phase, per conformer lane group */
+    uint64_t n_exact_cells;  /* items whose 2-sigma majority test was counted term by term (pass set not an interval) */
+    uint64_t n_overflow;     /* ligands whose tables did not fit a per-wavefront slice */
 } pmx_score_stats;
 int pmx_score_stats_get(pmx_score_stats *out);
 int pmx_set_profiling(int enabled); /* when enabled pmx_score records HIP events around each kernel (adds syncs) */

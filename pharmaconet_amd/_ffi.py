@@ -89,6 +89,10 @@ class ScoreStats(ctypes.Structure):
         ("max_iters_ligand", ctypes.c_uint64),
         ("max_iters_task", ctypes.c_uint64),
         ("n_steps_first", ctypes.c_uint64),
+        ("n_heavy", ctypes.c_uint64),
+        ("n_items", ctypes.c_uint64),
+        ("n_exact_cells", ctypes.c_uint64),
+        ("n_overflow", ctypes.c_uint64),
     ]
 
 

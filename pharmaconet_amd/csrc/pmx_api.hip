@@ -8,6 +8,8 @@
 #include <cstdlib>
 #include <chrono>
 #include <cstring>
+#include <cstddef>
+#include <memory>
 #include <map>
 #include <mutex>
 #include <string>
@@ -18,7 +20,7 @@
 
 #include "pmx.h"
 #include "pmx_kernels.hip"
-#include "pmx_match.hip"
+#include "pmx_screen.hip"
 
 using namespace pmx;
 
@@ -26,6 +28,10 @@ using namespace pmx;
 static thread_local char g_err[512] = "";
 static thread_local pmx_score_stats g_stats = {};
 static int g_profiling = 0;
+struct ScreenWs;
+static thread_local ScreenWs *g_last_screen = nullptr;
+static thread_local int g_last_device = 0;
+static int screen_stats(pmx_score_stats *out);
 
 static int fail(int code, const char *fmt, ...) {
     va_list ap;
@@ -49,20 +55,36 @@ extern "C" int pmx_set_profiling(int enabled) {
     g_profiling = enabled;
     return PMX_OK;
 }
-struct FusedWs;
-static int fused_stats(pmx_score_stats *out);
 extern "C" int pmx_score_stats_get(pmx_score_stats *out) {
     if (!out) return fail(PMX_ERR_INVALID, "null stats");
     *out = g_stats;
-    return fused_stats(out);
+    if (g_last_screen) return screen_stats(out);
+    return PMX_OK;
 }
 
 // -------------------------------------------------------------------------------------- model
+struct FnEntry { // tabulated pair functions for one set of type weights
+    Weights W;
+    FnCell *cells = nullptr;
+    hipEvent_t ready = nullptr; // recorded after fn_build_kernel on the stream that built it
+    uint64_t stamp = 0;
+};
+
 struct pmx_model {
     int device;
     DevModel dm;
     void *blob;
     uint8_t node_type[PMX_MAX_MODEL_NODES]; // host copy
+    // node subsets and tabulated pair functions (pmx_screen.hip)
+    uint32_t NS = 0, ncell = 0;
+    float h = 0.f;
+    uint16_t *sidtab = nullptr;  // device [K * 128]
+    uint64_t *subnodes = nullptr; // device [NS]
+    float2 *win = nullptr;        // device [NS * NS * ncell] exact pass windows
+    uint64_t n_complex_cells = 0;
+    std::mutex fn_mu;
+    std::vector<FnEntry> fn;
+    uint64_t fn_stamp = 0;
 };
 
 // Largest float T with fl(T / std) < 2 under round-to-nearest-even float32 division: the quotient
@@ -72,6 +94,171 @@ static float pass_threshold(float std) {
     float t = (float)bound;
     if ((double)t >= bound) t = std::nextafterf(t, -INFINITY);
     return t;
+}
+
+
+// ---------------------------------------------------------------------------- pair functions: subsets and pass windows
+// The floats d >= 0 with |fl(d - mean)| <= T, i.e. abs((d - mean) / std) < 2 in the reference's float32 arithmetic
+// (match_utils.py:55-57; T = pass_threshold(std)). fl(d - mean) is monotonic in d, so the set is an interval of floats;
+// its ends are found by bisection on the bit patterns (non-negative floats order like their bits).
+static bool edge_window(float mean, float T, float &lo, float &hi) {
+    auto f32 = [](uint32_t b) { float f; std::memcpy(&f, &b, 4); return f; };
+    auto ge = [&](uint32_t b) { volatile float x = f32(b) - mean; return x >= -T; };
+    auto le = [&](uint32_t b) { volatile float x = f32(b) - mean; return x <= T; };
+    const uint32_t top = 0x7f7fffffu;
+    if (!le(0u) || !ge(top)) return false;
+    uint32_t a = 0, b = top; // smallest b with ge
+    if (ge(0u)) b = 0;
+    else {
+        while (b - a > 1) {
+            const uint32_t m = a + (b - a) / 2;
+            if (ge(m)) b = m; else a = m;
+        }
+    }
+    const uint32_t lo_b = b;
+    a = 0, b = top; // largest a with le
+    if (le(top)) a = top;
+    else {
+        while (b - a > 1) {
+            const uint32_t m = a + (b - a) / 2;
+            if (le(m)) a = m; else b = m;
+        }
+    }
+    const uint32_t hi_b = a;
+    if (lo_b > hi_b) return false;
+    lo = f32(lo_b);
+    hi = f32(hi_b);
+    return true;
+}
+
+static int build_pair_functions(pmx_model *m, const pmx_model_desc *d, const std::vector<uint64_t> &cnodes, const uint64_t *tnodes) {
+    const int Nm = m->dm.Nm, K = m->dm.K;
+    // node subsets: (model cluster, ligand type mask) -> the cluster's nodes of those types (graph_match.py:148-150)
+    std::vector<uint64_t> subs(1, 0ull);
+    std::vector<uint16_t> sidtab((size_t)std::max(K, 1) * 128, 0);
+    for (int a = 0; a < K; ++a)
+        for (int mask = 0; mask < 128; ++mask) {
+            const uint64_t nodes = cnodes[a] & tnodes[mask];
+            if (!nodes) continue;
+            size_t id = 1;
+            for (; id < subs.size(); ++id)
+                if (subs[id] == nodes) break;
+            if (id == subs.size()) subs.push_back(nodes);
+            sidtab[(size_t)a * 128 + mask] = (uint16_t)id;
+        }
+    const uint32_t NS = (uint32_t)subs.size();
+    // grid: h = the largest power of two <= std_min / 5 (quintic Hermite error < 3e-8 of the peak, measured), range to mean + 7.5 std
+    float std_min = 1e30f, dmax = 1.f;
+    for (int i = 0; i < Nm * Nm; ++i) {
+        std_min = std::min(std_min, d->edge_std[i]);
+        dmax = std::max(dmax, d->edge_mean[i] + 7.5f * d->edge_std[i]);
+    }
+    if (Nm == 0) std_min = 1.f;
+    float h = 0.5f;
+    while (h > std_min / 5.f && h > 1.f / 64.f) h *= 0.5f;
+    const uint32_t ncell = (uint32_t)std::ceil((double)dmax / (double)h) + 1;
+    if (ncell > 16384 || (uint64_t)NS * NS * ncell * sizeof(FnCell) > (2ull << 30))
+        return fail(PMX_ERR_INVALID, "pair-function tables of this model would take %llu cells x %u x %u subsets", (unsigned long long)ncell, NS, NS);
+    // exact pass window of every model edge
+    std::vector<float> wlo((size_t)Nm * Nm), whi((size_t)Nm * Nm);
+    std::vector<uint8_t> wok((size_t)Nm * Nm);
+    for (int i = 0; i < Nm * Nm; ++i) wok[i] = edge_window(d->edge_mean[i], pass_threshold(d->edge_std[i]), wlo[i], whi[i]) ? 1 : 0;
+    const float INF = INFINITY;
+    std::vector<float2> win((size_t)NS * NS * ncell);
+    uint64_t n_complex = 0;
+    std::vector<std::pair<float, int>> ev;
+    std::vector<std::pair<float, float>> pass;
+    for (uint32_t sa = 0; sa < NS; ++sa)
+        for (uint32_t sb = 0; sb < NS; ++sb) {
+            float2 *out = win.data() + ((size_t)sa * NS + sb) * ncell;
+            const uint64_t A = subs[sa], B = subs[sb];
+            if (!A || !B) { // no item: never a fail
+                for (uint32_t i = 0; i < ncell; ++i) out[i] = make_float2(-INF, INF);
+                continue;
+            }
+            const int mn = __builtin_popcountll(A) * __builtin_popcountll(B);
+            ev.clear();
+            for (uint64_t am = A; am; am &= am - 1)
+                for (uint64_t bm = B; bm; bm &= bm - 1) {
+                    const int e = __builtin_ctzll(am) * Nm + __builtin_ctzll(bm);
+                    if (!wok[e]) continue;
+                    ev.emplace_back(wlo[e], +1);
+                    ev.emplace_back(std::nextafterf(whi[e], INF), -1); // first float after the window
+                }
+            std::sort(ev.begin(), ev.end());
+            pass.clear();
+            int cnt = 0;
+            bool in = false;
+            float start = 0.f;
+            for (size_t i = 0; i < ev.size();) {
+                const float x = ev[i].first;
+                for (; i < ev.size() && ev[i].first == x; ++i) cnt += ev[i].second;
+                const bool ok = 2 * cnt >= mn; // num_pass >= num_match * 0.5 (match_utils.py:61)
+                if (ok && !in) { in = true; start = x; }
+                else if (!ok && in) { in = false; pass.emplace_back(start, std::nextafterf(x, -INF)); }
+            }
+            if (in) pass.emplace_back(start, INF);
+            for (uint32_t i = 0; i < ncell; ++i) {
+                const float x0 = (float)i * h, x1 = (i + 1 == ncell) ? INF : (float)(i + 1) * h;
+                int hits = 0;
+                float2 w = make_float2(INF, -INF); // never passes
+                for (const auto &pr : pass)
+                    if (pr.first < x1 && pr.second >= x0) {
+                        ++hits;
+                        w = make_float2(pr.first, pr.second);
+                    }
+                if (hits > 1) {
+                    w = make_float2(NAN, NAN);
+                    ++n_complex;
+                }
+                out[i] = w;
+            }
+        }
+    HIPCHECK(hipMalloc((void **)&m->sidtab, sidtab.size() * 2));
+    HIPCHECK(hipMalloc((void **)&m->subnodes, (size_t)NS * 8));
+    HIPCHECK(hipMalloc((void **)&m->win, win.size() * sizeof(float2)));
+    HIPCHECK(hipMemcpy(m->sidtab, sidtab.data(), sidtab.size() * 2, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(m->subnodes, subs.data(), (size_t)NS * 8, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(m->win, win.data(), win.size() * sizeof(float2), hipMemcpyHostToDevice));
+    m->NS = NS;
+    m->ncell = ncell;
+    m->h = h;
+    m->n_complex_cells = n_complex;
+    return PMX_OK;
+}
+
+// The tabulated functions for the call's weights: built on `stream` the first time, kept for the last four weight sets.
+static int pair_functions(pmx_model *m, const Weights &W, hipStream_t stream, FnTable *out) {
+    std::lock_guard<std::mutex> lock(m->fn_mu);
+    FnEntry *hit = nullptr;
+    for (FnEntry &e : m->fn)
+        if (std::memcmp(&e.W, &W, sizeof(W)) == 0) hit = &e;
+    if (!hit) {
+        if (m->fn.size() < 4) {
+            m->fn.emplace_back();
+            hit = &m->fn.back();
+            HIPCHECK(hipMalloc((void **)&hit->cells, (size_t)m->NS * m->NS * m->ncell * sizeof(FnCell)));
+            HIPCHECK(hipEventCreateWithFlags(&hit->ready, hipEventDisableTiming));
+        } else { // recycle the least recently used entry once nothing queued still reads it
+            hit = &m->fn[0];
+            for (FnEntry &e : m->fn)
+                if (e.stamp < hit->stamp) hit = &e;
+            HIPCHECK(hipDeviceSynchronize());
+        }
+        hit->W = W;
+        fn_build_kernel<<<dim3(m->NS * m->NS), dim3(128), 0, stream>>>(m->dm, W, m->subnodes, m->NS, m->ncell, m->h, m->win, hit->cells);
+        HIPCHECK(hipGetLastError());
+        HIPCHECK(hipEventRecord(hit->ready, stream));
+    } else {
+        HIPCHECK(hipStreamWaitEvent(stream, hit->ready, 0));
+    }
+    hit->stamp = ++m->fn_stamp;
+    out->cells = hit->cells;
+    out->NS = m->NS;
+    out->ncell = m->ncell;
+    out->inv_h = 1.0f / m->h;
+    out->pad = 0;
+    return PMX_OK;
 }
 
 extern "C" int pmx_model_create(const pmx_model_desc *d, int device, pmx_model **out) {
@@ -185,6 +372,14 @@ extern "C" int pmx_model_create(const pmx_model_desc *d, int device, pmx_model *
     m->dm.cpair = reinterpret_cast<const float2 *>(b8 + off_cpair);
     m->dm.clist = reinterpret_cast<const uint4 *>(b8 + off_clist);
     m->dm.olist = reinterpret_cast<const uint4 *>(b8 + off_olist);
+    {
+        std::vector<uint64_t> cn(cnodes, cnodes + 64);
+        const int rc = build_pair_functions(m, d, cn, tnodes);
+        if (rc != PMX_OK) {
+            pmx_model_destroy(m);
+            return rc;
+        }
+    }
     *out = m;
     return PMX_OK;
 }
@@ -193,6 +388,13 @@ extern "C" int pmx_model_destroy(pmx_model *m) {
     if (!m) return PMX_OK;
     (void)hipSetDevice(m->device);
     (void)hipFree(m->blob);
+    if (m->sidtab) (void)hipFree(m->sidtab);
+    if (m->subnodes) (void)hipFree(m->subnodes);
+    if (m->win) (void)hipFree(m->win);
+    for (FnEntry &e : m->fn) {
+        if (e.cells) (void)hipFree(e.cells);
+        if (e.ready) (void)hipEventDestroy(e.ready);
+    }
     delete m;
     return PMX_OK;
 }
@@ -292,11 +494,6 @@ struct Slot {
     size_t arena_cap = 0;
     uint32_t *meta = nullptr;      // device: [0] max levels, [1] fetch counter, [2..3] table bytes (u64), [5] queue overflow flag, [14] / [15] ligand cursors of the table kernel, [32..] debug and profiling words; then kStatShards x 4 u64 of tree statistics and the kQueueShards tails of the task queue
     uint32_t *meta_host = nullptr; // pinned mirror
-    BinInfo *bins = nullptr;               // table phase: LDS size classes of the chunk's ligands
-    uint32_t *caps_dev = nullptr;
-    uint32_t *lists = nullptr;             // [kNumBins + 1][chunk_cap]
-    float4 *wtab = nullptr;                // the call's weights folded into the model's edge table
-    unsigned long long *bstats = nullptr;
     unsigned long long *bestbuf = nullptr; // [chunk_cap][64] per-conformer maxima of split ligands
     uint8_t *deferred = nullptr;           // [chunk_cap]
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // profiling: sizes | tables | tree start | tier 1 | tasks
@@ -345,8 +542,6 @@ static int ensure_workspace(int device, int pipeline, Workspace **out) {
             if (sl.taboff) (void)hipFree(sl.taboff);
             if (sl.bestbuf) (void)hipFree(sl.bestbuf);
             if (sl.deferred) (void)hipFree(sl.deferred);
-            if (sl.lists) (void)hipFree(sl.lists);
-            HIPCHECK(hipMalloc((void **)&sl.lists, (size_t)(kNumBins + 1) * cap * 4));
             HIPCHECK(hipMalloc((void **)&sl.units, (size_t)cap * 4));
             HIPCHECK(hipMalloc((void **)&sl.status, (size_t)cap * 4));
             HIPCHECK(hipMalloc((void **)&sl.taboff, ((size_t)cap + 1) * 8));
@@ -365,10 +560,6 @@ static int ensure_workspace(int device, int pipeline, Workspace **out) {
         HIPCHECK(hipEventCreateWithFlags(&w.done, hipEventDisableTiming));
         for (Slot &sl : w.slot) {
             HIPCHECK(hipMalloc((void **)&sl.meta, kMetaBytes));
-            HIPCHECK(hipMalloc((void **)&sl.bins, sizeof(BinInfo)));
-            HIPCHECK(hipMalloc((void **)&sl.caps_dev, sizeof(uint32_t) * kNumBins));
-            HIPCHECK(hipMalloc((void **)&sl.wtab, (size_t)PMX_MAX_MODEL_NODES * PMX_MAX_MODEL_NODES * sizeof(float4)));
-            HIPCHECK(hipMalloc((void **)&sl.bstats, 128 * sizeof(unsigned long long)));
             HIPCHECK(hipHostMalloc((void **)&sl.meta_host, kMetaBytes));
             for (auto &ev : sl.ev) HIPCHECK(hipEventCreate(&ev));
             HIPCHECK(hipEventCreateWithFlags(&sl.tables_done, hipEventDisableTiming));
@@ -444,92 +635,7 @@ static int table_phase(const pmx_model *model, const pmx_library *lib, const Wei
         sl.arena_cap = want;
     }
     if (g_profiling) HIPCHECK(hipEventRecord(sl.ev[1], q));
-    const long tables_version = env_long("PMX_TABLES", 2);
-    if (sl.table_total > 0 && (tables_version == 3 || tables_version == 4)) {
-        // tables_kernel_v3: ligands binned by the LDS their tables need, one persistent launch per size class
-        const int K = model->dm.K;
-        const uint32_t model_lds = model_lds_bytes(Nm, K);
-        if (model_lds + sizeof(MatchCtx) + 2048 > kLdsPerCu) return fail(PMX_ERR_INVALID, "model tables do not fit LDS");
-        const uint32_t max_cap = ((uint32_t)kLdsPerCu - model_lds - 64u) & ~15u;
-        static const uint32_t kCaps[kNumBins] = {6144, 8192, 12288, 16384, 24576, 32768, 49152, 65536, 98304, 0xffffffffu};
-        uint32_t caps[kNumBins];
-        for (int b = 0; b < kNumBins; ++b) caps[b] = std::min(kCaps[b], max_cap);
-        HIPCHECK(hipMemcpyAsync(sl.caps_dev, caps, sizeof(caps), hipMemcpyHostToDevice, q));
-        bins_init_kernel<<<dim3(1), dim3(64), 0, q>>>(sl.bins, sl.caps_dev, kNumBins + 1, sl.bstats);
-        fold_weights_kernel<<<dim3((Nm * Nm + 255) / 256), dim3(256), 0, q>>>(model->dm, W, sl.wtab);
-        bin_kernel<G><<<dim3((n + 255) / 256), dim3(256), 0, q>>>(lib->dl, model->dm.tclus, lig0, n, sl.bins, sl.lists, sl.lists, nullptr, nullptr);
-        MatchParams mp;
-        mp.M = model->dm;
-        mp.wtab = sl.wtab;
-        mp.nzw = 0;
-        for (int m = 0; m < Nm; ++m)
-            if (W.w[model->node_type[m]] != 0.f) mp.nzw |= 1ull << m;
-        mp.lib = lib->dl;
-        mp.first = lig0;
-        mp.bins = sl.bins;
-        mp.arena = nullptr;
-        mp.arena_bytes = 0;
-        mp.hlist = nullptr;
-        mp.roots = nullptr;
-        mp.roots_cap = 0;
-        mp.budget = 0;
-        mp.pool_bytes = 0;
-        mp.scores = nullptr;
-        mp.stats = sl.bstats;
-        mp.flags = (uint32_t)env_long("PMX_TREE_FLAGS", 0);
-        mp.seed = nullptr;
-        mp.seed_mode = 0;
-        mp.taboff = sl.taboff;
-        mp.out_arena = sl.arena;
-        const int num_cu = ws_num_cu;
-        for (int b = kNumBins - 1; b >= 0; --b) {
-            if (b > 0 && caps[b] == caps[b - 1]) continue;
-            mp.list = sl.lists + (size_t)b * n;
-            mp.bin = (uint32_t)b;
-            mp.wave_bytes = caps[b];
-            if (tables_version == 3) {
-                const uint32_t waves = std::max<uint32_t>(1, std::min<uint32_t>(16, ((uint32_t)kLdsPerCu - model_lds) / caps[b]));
-                const size_t lds = model_lds + (size_t)waves * caps[b];
-                tables_kernel_v3<G><<<dim3(num_cu), dim3(64 * waves), lds, q>>>(mp);
-            } else {
-                // a team of waves per ligand: the smallest team that still fills the CU (<= 32 waves) given the LDS per block
-                const uint32_t small = 64 * 8 + 128 * 8 + (uint32_t)round16((uint64_t)K * K * 8) + 16;
-                const uint32_t helper = 2 * kPairBuf + 32 * kListSlots;
-                uint32_t team = 2, best_waves = 0, blocks = 1;
-                for (uint32_t t : {2u, 4u, 8u, 16u}) {
-                    const uint32_t lds_t = small + caps[b] + (t - 1) * helper;
-                    if (lds_t > kLdsPerCu) break;
-                    const uint32_t fit = std::min<uint32_t>((uint32_t)kLdsPerCu / lds_t, 32u / t);
-                    const uint32_t wv = fit * t;
-                    if (wv > best_waves) {
-                        best_waves = wv;
-                        team = t;
-                        blocks = fit;
-                    }
-                    if (wv >= (uint32_t)std::max<long>(8, env_long("PMX_TEAM_WAVES", 24))) break;
-                }
-                const size_t lds = small + caps[b] + (size_t)(team - 1) * helper;
-                tables_kernel_v4<G><<<dim3(num_cu * blocks), dim3(64 * team), lds, q>>>(mp);
-            }
-        }
-        HIPCHECK(hipGetLastError());
-        // tables beyond the largest class: the generic kernel on those ligands only
-        {
-            const size_t model_lds2 = (size_t)Nm * (Nm + 1) * sizeof(float4) + 64 * 8 + 128 * 8;
-            const int v2_waves = (int)std::min<size_t>(8, (kLdsPerCu - 1024 - model_lds2) / tables_v2_wave_bytes<G>(model->dm.K));
-            const size_t lds2 = model_lds2 + (size_t)v2_waves * tables_v2_wave_bytes<G>(model->dm.K);
-            const unsigned v2_blocks = (unsigned)std::min<uint64_t>((n + v2_waves - 1) / v2_waves, (uint64_t)num_cu * 4);
-            if (zero_weight)
-                tables_kernel_v2<G, true><<<dim3(v2_blocks), dim3(64 * v2_waves), lds2, q>>>(
-                    model->dm, lib->dl, W, lig0, n, status, sl.taboff, sl.arena, sl.lists + (size_t)kNumBins * n, &sl.bins->count[kNumBins], sl.meta + 15);
-            else
-                tables_kernel_v2<G, false><<<dim3(v2_blocks), dim3(64 * v2_waves), lds2, q>>>(
-                    model->dm, lib->dl, W, lig0, n, status, sl.taboff, sl.arena, sl.lists + (size_t)kNumBins * n, &sl.bins->count[kNumBins], sl.meta + 15);
-            bounds_kernel<G><<<dim3((n + 3) / 4), dim3(256), 0, q>>>(n, status, sl.taboff, sl.arena, (int)(env_long("PMX_TREE_FLAGS", 0) & 4),
-                                                                     sl.lists + (size_t)kNumBins * n, &sl.bins->count[kNumBins]);
-        }
-        HIPCHECK(hipGetLastError());
-    } else if (sl.table_total > 0) {
+    if (sl.table_total > 0) {
         // <= 8 ligands (waves) per block share one staged model table; the 160 KB of LDS always hold at least one
         const size_t model_lds = (size_t)Nm * (Nm + 1) * sizeof(float4) + 64 * 8 + 128 * 8; // edge table + one neutral column
         if (model_lds + tables_v2_wave_bytes<G>(model->dm.K) + 1024 > kLdsPerCu) return fail(PMX_ERR_INVALID, "model tables do not fit LDS");
@@ -705,8 +811,6 @@ static int score_chunks(const pmx_model *const *models, int n_models, const pmx_
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));
         HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&tree_kernel<G, false>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));
-        HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&tables_kernel_v3<G>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));
-        HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&tables_kernel_v4<G>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));
         HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&tree_kernel<G, true>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));
         ws.lds_attr_set |= attr_bit;
@@ -747,152 +851,175 @@ static int score_chunks(const pmx_model *const *models, int n_models, const pmx_
     }
 }
 
-// ------------------------------------------------------------------------------- fused matcher (pmx_match.hip)
-// Everything is stream-ordered: bin the call's ligands by the LDS their tables need, then one persistent launch per
-// size class. No device-to-host read happens inside the call.
-struct FusedWs {
-    BinInfo *bins = nullptr;
-    uint32_t *caps_dev = nullptr;
-    uint32_t *lists = nullptr;
-    uint64_t lists_cap = 0; // ligands per class list
-    float4 *wtab = nullptr;
-    unsigned long long *stats = nullptr;
+
+
+// ------------------------------------------------------------------------------------ the screening engine (pmx_screen.hip)
+// Everything a call does is enqueued on the caller's stream: no device-to-host read, no host thread, no lock held while
+// kernels run. Per super-chunk of <= PMX_SUPER ligands: clear the control block; ligand_kernel over the range (tables in
+// per-wave slices); ligand_kernel over the ligands whose tables need the arena; a fixed number of task rounds (each a
+// snapshot of the queue + one persistent launch that exits at once when the round is empty; the last round never
+// queues); finalize; then the same once more for ligands the arena had no room for (normally none).
+struct ScreenWs {
+    Ctl *ctl = nullptr;
+    uint8_t *slices = nullptr;
+    size_t slices_bytes = 0;
     uint8_t *arena = nullptr;
     size_t arena_bytes = 0;
-    uint8_t *roots = nullptr;
-    size_t roots_bytes = 0;
+    uint8_t *queue = nullptr;
+    size_t queue_bytes = 0;
+    uint32_t *lists = nullptr; // ovf | carry | heavy
+    uint32_t list_cap = 0;
     int num_cu = 0;
-    uint32_t attr_set = 0;
-    hipStream_t stream = nullptr; // the stream of the last call (stats are read after synchronising it)
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr}; // profiling: start | ligand passes done | task rounds done
+    bool ev_valid = false;
+    hipStream_t last_stream = nullptr;
+    std::mutex mu; // held while a call enqueues (the workspace belongs to one call at a time, in stream order)
 };
-static std::map<std::pair<int, hipStream_t>, FusedWs> g_fused; // (device, stream)
-static thread_local FusedWs *g_last_fused = nullptr;
+static std::map<std::pair<int, hipStream_t>, std::unique_ptr<ScreenWs>> g_screen; // (device, stream)
 
-static int ensure_fused(int device, hipStream_t stream, uint64_t count, FusedWs **out) {
-    FusedWs *w;
+static int ensure_screen(int device, hipStream_t stream, ScreenWs **out) {
+    ScreenWs *w;
     {
         std::lock_guard<std::mutex> lock(g_mu);
-        w = &g_fused[std::make_pair(device, stream)];
+        auto &slot = g_screen[std::make_pair(device, stream)];
+        if (!slot) slot.reset(new ScreenWs());
+        w = slot.get();
     }
-    if (!w->bins) {
-        hipDeviceProp_t prop;
-        HIPCHECK(hipGetDeviceProperties(&prop, device));
-        w->num_cu = prop.multiProcessorCount;
-        HIPCHECK(hipMalloc((void **)&w->bins, sizeof(BinInfo)));
-        HIPCHECK(hipMalloc((void **)&w->caps_dev, sizeof(uint32_t) * kNumBins));
-        HIPCHECK(hipMalloc((void **)&w->wtab, (size_t)PMX_MAX_MODEL_NODES * PMX_MAX_MODEL_NODES * sizeof(float4)));
-        HIPCHECK(hipMalloc((void **)&w->stats, 128 * sizeof(unsigned long long)));
-        w->arena_bytes = (size_t)std::max<long>(16, env_long("PMX_ARENA_MB", 1024)) << 20;
-        HIPCHECK(hipMalloc((void **)&w->arena, w->arena_bytes));
-        w->roots_bytes = (size_t)std::max<long>(16, env_long("PMX_ROOTS_MB", 2048)) << 20;
-        HIPCHECK(hipMalloc((void **)&w->roots, w->roots_bytes));
-    }
-    if (w->lists_cap < count) {
-        if (w->lists) {
-            HIPCHECK(hipStreamSynchronize(stream));
-            (void)hipFree(w->lists);
-            w->lists = nullptr;
-            w->lists_cap = 0;
-        }
-        HIPCHECK(hipMalloc((void **)&w->lists, (size_t)2 * (kNumBins + 1) * count * sizeof(uint32_t)));
-        w->lists_cap = count;
-    }
-    w->stream = stream;
     *out = w;
     return PMX_OK;
 }
 
+template <typename T>
+static int grow(T **ptr, size_t *have, size_t want, hipStream_t stream) {
+    if (*have >= want) return PMX_OK;
+    if (*ptr) {
+        HIPCHECK(hipStreamSynchronize(stream)); // queued work may still use the old buffer (only when a buffer grows)
+        (void)hipFree(*ptr);
+        *ptr = nullptr;
+        *have = 0;
+    }
+    HIPCHECK(hipMalloc((void **)ptr, want));
+    *have = want;
+    return PMX_OK;
+}
+
 template <int G>
-static int score_fused(const pmx_model *model, const pmx_library *lib, const Weights &W, uint64_t first, uint64_t count, float *scores_dev,
-                       int32_t *status_dev, hipStream_t stream, FusedWs &ws) {
+static int score_screen(const pmx_model *model, const pmx_library *lib, const Weights &W, uint64_t first, uint64_t count, float *scores_dev,
+                        int32_t *status_dev, hipStream_t stream, ScreenWs &ws, bool first_model) {
     if (count > 0xfffffff0ull) return fail(PMX_ERR_INVALID, "more than 2^32 ligands in one call");
-    const int Nm = model->dm.Nm, K = model->dm.K;
-    const uint32_t n = (uint32_t)count;
-    const uint32_t model_lds = model_lds_bytes(Nm, K);
-    constexpr uint32_t wave_state = std::max<uint32_t>(1024, (PMX_MAX_LEVELS + 1 + 43) * G * 8); // a helper wave's build buffers, then its path totals + lookahead sums (typical ksumtot)
-    const uint32_t coop_fixed = model_lds + (uint32_t)sizeof(CoopShared);
-    if (coop_fixed + sizeof(MatchCtx) + 1024 > kLdsPerCu) return fail(PMX_ERR_INVALID, "model tables do not fit LDS");
-    const uint32_t max_cap = ((uint32_t)kLdsPerCu - coop_fixed - 64u) & ~15u;
-    static const uint32_t kCaps[kNumBins] = {6144, 8192, 12288, 16384, 24576, 32768, 49152, 65536, 98304, 0xffffffffu};
-    uint32_t caps[kNumBins];
-    for (int b = 0; b < kNumBins; ++b) caps[b] = std::min(kCaps[b], max_cap);
-    HIPCHECK(hipMemcpyAsync(ws.caps_dev, caps, sizeof(caps), hipMemcpyHostToDevice, stream));
-    // classes whose tables leave room for fewer than four ligands per CU are scored by whole blocks from the start
-    const uint32_t coop_kb = (uint32_t)std::max<long>(1, env_long("PMX_COOP_KB", 32));
-    uint32_t coop_from = kNumBins;
-    for (int b = kNumBins - 1; b >= 0; --b)
-        if (caps[b] >= coop_kb * 1024u) coop_from = (uint32_t)b;
-    const uint32_t attr_bit = 1u << __builtin_ctz((unsigned)G);
-    if (!(ws.attr_set & attr_bit)) {
-        HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&match_kernel<G, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));
-        HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&coop_kernel<G, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));
-        HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&coop_kernel<G, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu));
-        ws.attr_set |= attr_bit;
+    if (!ws.ctl) {
+        hipDeviceProp_t prop;
+        HIPCHECK(hipGetDeviceProperties(&prop, lib->device));
+        ws.num_cu = prop.multiProcessorCount;
+        HIPCHECK(hipMalloc((void **)&ws.ctl, sizeof(Ctl)));
+        for (auto &e : ws.ev) HIPCHECK(hipEventCreate(&e));
     }
-    uint32_t *lists = ws.lists, *hlists = ws.lists + (size_t)(kNumBins + 1) * n;
-    bins_init_kernel<<<dim3(1), dim3(64), 0, stream>>>(ws.bins, ws.caps_dev, coop_from, ws.stats);
-    fold_weights_kernel<<<dim3((Nm * Nm + 255) / 256), dim3(256), 0, stream>>>(model->dm, W, ws.wtab);
-    bin_kernel<G><<<dim3((n + 255) / 256), dim3(256), 0, stream>>>(lib->dl, model->dm.tclus, first, n, ws.bins, lists, hlists, status_dev, scores_dev);
-    HIPCHECK(hipGetLastError());
-    MatchParams mp;
-    mp.M = model->dm;
-    mp.wtab = ws.wtab;
-    mp.nzw = 0;
-    for (int m = 0; m < Nm; ++m)
-        if (W.w[model->node_type[m]] != 0.f) mp.nzw |= 1ull << m;
-    mp.lib = lib->dl;
-    mp.first = first;
-    mp.bins = ws.bins;
-    mp.arena = ws.arena;
-    mp.arena_bytes = ws.arena_bytes;
-    mp.roots = ws.roots;
-    mp.scores = scores_dev;
-    mp.stats = ws.stats;
-    mp.flags = (uint32_t)env_long("PMX_TREE_FLAGS", 0);
-    mp.budget = (uint32_t)std::max<long>(16, env_long("PMX_BUDGET", 2048));
-    mp.seed_mode = (int)env_long("PMX_SEED_BEST", 0);
-    mp.seed = nullptr;
-    if (mp.seed_mode) {
-        static double *seedbuf = nullptr;
-        if (!seedbuf) HIPCHECK(hipMalloc((void **)&seedbuf, (size_t)n * G * 8));
-        mp.seed = seedbuf;
+    ScreenParams p;
+    p.M = model->dm;
+    int rc = pair_functions(const_cast<pmx_model *>(model), W, stream, &p.F);
+    if (rc) return rc;
+    p.lib = lib->dl;
+    p.sidtab = model->sidtab;
+    p.subnodes = model->subnodes;
+    p.W = W;
+    p.first = first;
+    p.ctl = ws.ctl;
+    p.flags = (uint32_t)env_long("PMX_TREE_FLAGS", 0);
+    p.max_nodes = (uint32_t)std::max(4, std::min(lib->info.max_nodes, PMX_MAX_LIGAND_NODES));
+    const WaveShape<G> shape = wave_shape<G>(model->dm.K, (int)p.max_nodes);
+    const uint32_t waves_per_cu = (uint32_t)std::max<long>(1, std::min<long>({(long)(kLdsPerCu / shape.bytes), 4L * PMX_SCREEN_WAVES, env_long("PMX_WAVES_PER_CU", 32)}));
+    const uint32_t grid = (uint32_t)ws.num_cu * waves_per_cu;
+    p.slice_bytes = (uint32_t)std::max<long>(4, env_long("PMX_SLICE_KB", 48)) * 1024u;
+    rc = grow(&ws.slices, &ws.slices_bytes, (size_t)grid * p.slice_bytes, stream);
+    if (rc) return rc;
+    rc = grow(&ws.arena, &ws.arena_bytes, (size_t)std::max<long>(16, env_long("PMX_ARENA_MB", 2048)) << 20, stream);
+    if (rc) return rc;
+    rc = grow(&ws.queue, &ws.queue_bytes, (size_t)std::max<long>(1, env_long("PMX_TASKQ_MB", 1024)) << 20, stream);
+    if (rc) return rc;
+    const uint32_t super = (uint32_t)std::max<long>(1024, std::min<long>(env_long("PMX_SUPER", 1 << 20), 1 << 24));
+    {
+        size_t have = (size_t)ws.list_cap * 12;
+        rc = grow(&ws.lists, &have, (size_t)super * 12, stream);
+        if (rc) return rc;
+        ws.list_cap = super;
     }
-    // one wavefront per ligand: the classes with small tables, largest first
-    for (int b = (int)coop_from - 1; b >= 0; --b) {
-        if (b > 0 && caps[b] == caps[b - 1]) continue; // clamped duplicate: bin_kernel never fills it
-        const uint32_t waves = std::max<uint32_t>(1, std::min<uint32_t>(16, ((uint32_t)kLdsPerCu - model_lds) / caps[b]));
-        mp.list = lists + (size_t)b * n;
-        mp.hlist = hlists + (size_t)b * n;
-        mp.bin = (uint32_t)b;
-        mp.wave_bytes = caps[b];
-        mp.roots_cap = 0;
-        mp.pool_bytes = 0;
-        const size_t lds = model_lds + (size_t)waves * caps[b];
-        match_kernel<G, true><<<dim3(ws.num_cu), dim3(64 * waves), lds, stream>>>(mp);
-    }
-    // one block per ligand: large tables, and the trees the wavefronts above gave up on
-    const uint32_t max_coop_waves = (uint32_t)std::max<long>(1, std::min<long>(16, env_long("PMX_COOP_WAVES", 8)));
-    for (int b = kNumBins; b >= 0; --b) {
-        const bool hbm = b == kNumBins;
-        if (!hbm && b > 0 && caps[b] == caps[b - 1]) continue;
-        const uint32_t cap = hbm ? (uint32_t)sizeof(MatchCtx) : caps[b];
-        const uint32_t room = (uint32_t)kLdsPerCu - model_lds - (uint32_t)sizeof(CoopShared) - cap;
-        const uint32_t waves = std::max<uint32_t>(1, std::min<uint32_t>(max_coop_waves, 1 + room / wave_state));
-        mp.pool_bytes = (waves - 1) * wave_state;
-        const size_t lds = model_lds + sizeof(CoopShared) + cap + mp.pool_bytes;
-        const uint32_t per_cu = std::max<uint32_t>(1, std::min<uint32_t>({(uint32_t)(kLdsPerCu / lds), 32u / waves, 8u}));
-        const uint32_t grid = (uint32_t)ws.num_cu * per_cu;
-        mp.list = nullptr;
-        mp.hlist = hlists + (size_t)b * n;
-        mp.bin = (uint32_t)b;
-        mp.wave_bytes = hbm ? 0u : caps[b];
-        mp.roots_cap = (uint32_t)std::min<size_t>(ws.roots_bytes / ((size_t)grid * root_bytes<G>()), 0x7fffffffu);
-        if (hbm)
-            coop_kernel<G, false><<<dim3(grid), dim3(64 * waves), lds, stream>>>(mp);
-        else
-            coop_kernel<G, true><<<dim3(grid), dim3(64 * waves), lds, stream>>>(mp);
+    p.slices = ws.slices;
+    p.arena = ws.arena;
+    p.arena_bytes = std::min<unsigned long long>(ws.arena_bytes, (1ull << 36) - 4096);
+    p.ovf_list = ws.lists;
+    p.carry_list = ws.lists + super;
+    p.heavy_list = ws.lists + 2 * (size_t)super;
+    p.list_cap = super;
+    p.queue = ws.queue;
+    p.qcap = (uint32_t)std::min<size_t>(ws.queue_bytes / task_rec_bytes<G>() / kShards, 0x7fffffffu / kShards);
+    p.budget = (uint32_t)std::max<long>(16, env_long("PMX_BUDGET", 2048));
+    p.min_levels = (uint32_t)std::max<long>(0, env_long("PMX_MIN_LEVELS", 2));
+    p.max_passes = (unsigned long long)std::max<long>(1, env_long("PMX_MAXITERS", 1L << 40));
+    p.scores = scores_dev;
+    p.status = status_dev;
+    const int rounds = (int)std::max<long>(1, env_long("PMX_ROUNDS", 6));
+    const bool exact = (p.flags & 8) != 0;
+    const size_t lds = shape.bytes;
+    if (g_profiling && first_model) HIPCHECK(hipEventRecord(ws.ev[0], stream));
+    auto ligands = [&](int mode) {
+        p.mode = mode;
+        if (exact) ligand_kernel<G, true><<<dim3(grid), dim3(64), lds, stream>>>(p);
+        else ligand_kernel<G, false><<<dim3(grid), dim3(64), lds, stream>>>(p);
+    };
+    auto tasks_and_finalize = [&]() {
+        for (int r = 0; r < rounds; ++r) {
+            round_kernel<<<dim3(1), dim3(64), 0, stream>>>(ws.ctl, p.qcap);
+            task_kernel<G><<<dim3(grid), dim3(64), lds, stream>>>(p, r + 1 == rounds ? 1 : 0);
+        }
+        finalize_kernel<G><<<dim3((super + 255) / 256), dim3(256), 0, stream>>>(p);
+    };
+    for (uint64_t lo = 0; lo < count; lo += super) {
+        p.lo = (uint32_t)lo;
+        p.hi = (uint32_t)std::min<uint64_t>(count, lo + super);
+        ctl_clear_kernel<<<dim3((sizeof(Ctl) / 4 + 255) / 256), dim3(256), 0, stream>>>(ws.ctl, (lo == 0 && first_model) ? 1 : 0, 0);
+        ligands(0);
+        ligands(1);
+        tasks_and_finalize();
+        // ligands the arena had no room for: once more with an empty arena
+        ctl_clear_kernel<<<dim3((sizeof(Ctl) / 4 + 255) / 256), dim3(256), 0, stream>>>(ws.ctl, 0, 1);
+        ligands(2);
+        tasks_and_finalize();
     }
     HIPCHECK(hipGetLastError());
+    if (g_profiling) HIPCHECK(hipEventRecord(ws.ev[1], stream));
+    ws.ev_valid = g_profiling != 0;
+    ws.last_stream = stream;
+    return PMX_OK;
+}
+
+// Statistics of the last call on this thread's workspace: synchronises the stream the call ran on.
+static int screen_stats(pmx_score_stats *out) {
+    ScreenWs *w = g_last_screen;
+    if (!w || !w->ctl) return PMX_OK;
+    HIPCHECK(hipSetDevice(g_last_device));
+    HIPCHECK(hipStreamSynchronize(w->last_stream));
+    std::vector<unsigned char> host(sizeof(Ctl));
+    HIPCHECK(hipMemcpy(host.data(), w->ctl, sizeof(Ctl), hipMemcpyDeviceToHost));
+    const Ctl *c = reinterpret_cast<const Ctl *>(host.data());
+    unsigned long long st[kStatWords] = {0};
+    for (int sh = 0; sh < kScreenStatShards; ++sh)
+        for (int i = 0; i < kStatWords; ++i) st[i] = (i == 5) ? std::max(st[i], c->stats[sh][i]) : st[i] + c->stats[sh][i];
+    *out = pmx_score_stats{};
+    out->n_steps = st[0];
+    out->n_iters = st[1];
+    out->n_heavy = st[2];
+    out->n_items = st[3];
+    out->n_exact_cells = st[4];
+    out->max_iters_ligand = st[5];
+    out->n_tasks = st[6];
+    out->n_overflow = st[7];
+    out->queue_overflow = c->qflag;
+    if (w->ev_valid) {
+        float ms = 0.f;
+        HIPCHECK(hipEventElapsedTime(&ms, w->ev[0], w->ev[1]));
+        out->ms_total = ms;
+    }
+    if (c->err) return fail(PMX_ERR_INVALID, "tree walk hit the iteration cap (PMX_MAXITERS)");
     return PMX_OK;
 }
 
@@ -911,31 +1038,34 @@ extern "C" int pmx_score_multi(const pmx_model *const *models, int n_models, con
         if (models[i]->device != lib->device) return fail(PMX_ERR_INVALID, "model and library live on different devices");
     }
     if (first > lib->info.n_ligands || count > lib->info.n_ligands - first) return fail(PMX_ERR_INVALID, "ligand range out of bounds");
-    if (env_long("PMX_ENGINE", 1) == 2) {
+    if (env_long("PMX_ENGINE", 3) == 3) {
         g_stats = pmx_score_stats{};
+        g_last_screen = nullptr;
         if (count == 0 || n_models == 0) return PMX_OK;
         HIPCHECK(hipSetDevice(lib->device));
         Weights W;
         for (int t = 0; t < PMX_NUM_TYPES; ++t) W.w[t] = weights[t];
         hipStream_t stream = static_cast<hipStream_t>(stream_);
         const int G = next_pow2(std::max(1, std::min(lib->info.max_conformers, PMX_MAX_CONFORMERS)));
-        FusedWs *ws = nullptr;
-        int rc = ensure_fused(lib->device, stream, count, &ws);
+        ScreenWs *ws = nullptr;
+        int rc = ensure_screen(lib->device, stream, &ws);
         if (rc) return rc;
-        g_last_fused = ws;
+        std::lock_guard<std::mutex> lock(ws->mu);
         for (int m = 0; m < n_models && rc == PMX_OK; ++m) {
             float *sc = scores_dev + (size_t)m * count;
             int32_t *st = m == 0 ? status_dev : nullptr;
             switch (G) {
-            case 1: rc = score_fused<1>(models[m], lib, W, first, count, sc, st, stream, *ws); break;
-            case 2: rc = score_fused<2>(models[m], lib, W, first, count, sc, st, stream, *ws); break;
-            case 4: rc = score_fused<4>(models[m], lib, W, first, count, sc, st, stream, *ws); break;
-            case 8: rc = score_fused<8>(models[m], lib, W, first, count, sc, st, stream, *ws); break;
-            case 16: rc = score_fused<16>(models[m], lib, W, first, count, sc, st, stream, *ws); break;
-            case 32: rc = score_fused<32>(models[m], lib, W, first, count, sc, st, stream, *ws); break;
-            default: rc = score_fused<64>(models[m], lib, W, first, count, sc, st, stream, *ws); break;
+            case 1: rc = score_screen<1>(models[m], lib, W, first, count, sc, st, stream, *ws, m == 0); break;
+            case 2: rc = score_screen<2>(models[m], lib, W, first, count, sc, st, stream, *ws, m == 0); break;
+            case 4: rc = score_screen<4>(models[m], lib, W, first, count, sc, st, stream, *ws, m == 0); break;
+            case 8: rc = score_screen<8>(models[m], lib, W, first, count, sc, st, stream, *ws, m == 0); break;
+            case 16: rc = score_screen<16>(models[m], lib, W, first, count, sc, st, stream, *ws, m == 0); break;
+            case 32: rc = score_screen<32>(models[m], lib, W, first, count, sc, st, stream, *ws, m == 0); break;
+            default: rc = score_screen<64>(models[m], lib, W, first, count, sc, st, stream, *ws, m == 0); break;
             }
         }
+        g_last_screen = ws;
+        g_last_device = lib->device;
         return rc;
     }
     std::lock_guard<std::mutex> lock(g_mu);
@@ -1039,30 +1169,6 @@ extern "C" int pmx_score(const pmx_model *model, const pmx_library *lib, const f
     return pmx_score_multi(&model, 1, lib, weights, first, count, scores_dev, status_dev, stream);
 }
 
-static int fused_stats(pmx_score_stats *out) {
-    FusedWs *w = g_last_fused;
-    if (!w || !w->stats) return PMX_OK;
-    unsigned long long st[128];
-    HIPCHECK(hipStreamSynchronize(w->stream));
-    HIPCHECK(hipMemcpy(st, w->stats, sizeof(st), hipMemcpyDeviceToHost));
-    if (trace_on()) {
-        fprintf(stderr, "[pmx] steps %llu batches %llu wave-terms %llu max steps/ligand %llu\n", st[0], st[1], st[2], st[3]);
-        for (int b = 0; b < 12; ++b)
-            fprintf(stderr, "[pmx]   steps in [4^%d,4^%d): %llu ligands, %llu steps, %llu of them at frames with < 4 matches\n", b, b + 1, st[4 + b], st[16 + b], st[32 + b]);
-        fprintf(stderr, "[pmx] steps walked by cooperating blocks: %llu\n", st[74]);
-        fprintf(stderr, "[pmx] coop blocks: %llu ligands; block cycles setup %llu build %llu finish+bounds %llu top %llu subtrees %llu; roots %llu (max %llu) overflowed ligands %llu\n",
-                st[107], st[100], st[101], st[102], st[103], st[104], st[105], st[108], st[106]);
-        fprintf(stderr, "[pmx] wave cycles: tables %llu walk %llu | setup %llu batches %llu finish %llu bounds %llu\n", st[44], st[45], st[70], st[71], st[72], st[73]);
-        for (int b = 0; b <= kNumBins; ++b)
-            fprintf(stderr, "[pmx]   class %d: tables %llu walk %llu | wave-terms %llu steps %llu batches %llu batch cycles %llu -> %.1f cycles/wave-term %.1f cycles/step\n", b,
-                    st[46 + 2 * b], st[47 + 2 * b], st[80 + 4 * b], st[81 + 4 * b], st[82 + 4 * b], st[83 + 4 * b],
-                    (double)st[83 + 4 * b] / (double)std::max<unsigned long long>(st[80 + 4 * b], 1), (double)st[47 + 2 * b] / (double)std::max<unsigned long long>(st[81 + 4 * b], 1));
-    }
-    out->n_steps = st[0];
-    out->n_iters = st[1];
-    out->table_bytes = st[2];
-    return PMX_OK;
-}
 
 // Frees the cached scoring workspaces of `device` (table arenas, task queues, class lists, fused-engine buffers): they are
 // grown on demand and kept between calls, which is what a screening loop wants and what a long-lived host program that
@@ -1079,8 +1185,7 @@ extern "C" int pmx_release_workspaces(int device) {
         }
         Workspace &w = it->second;
         for (Slot &sl : w.slot) {
-            for (void *q : {(void *)sl.units, (void *)sl.status, (void *)sl.taboff, (void *)sl.arena, (void *)sl.meta, (void *)sl.bins, (void *)sl.caps_dev,
-                            (void *)sl.lists, (void *)sl.wtab, (void *)sl.bstats, (void *)sl.bestbuf, (void *)sl.deferred})
+            for (void *q : {(void *)sl.units, (void *)sl.status, (void *)sl.taboff, (void *)sl.arena, (void *)sl.meta, (void *)sl.bestbuf, (void *)sl.deferred})
                 if (q) (void)hipFree(q);
             if (sl.meta_host) (void)hipHostFree(sl.meta_host);
             for (auto &ev : sl.ev)
@@ -1094,17 +1199,6 @@ extern "C" int pmx_release_workspaces(int device) {
         if (w.entry) (void)hipEventDestroy(w.entry);
         if (w.done) (void)hipEventDestroy(w.done);
         it = g_ws.erase(it);
-    }
-    for (auto it = g_fused.begin(); it != g_fused.end();) {
-        if (it->first.first != device) {
-            ++it;
-            continue;
-        }
-        FusedWs &w = it->second;
-        for (void *q : {(void *)w.bins, (void *)w.caps_dev, (void *)w.lists, (void *)w.wtab, (void *)w.stats, (void *)w.arena, (void *)w.roots})
-            if (q) (void)hipFree(q);
-        if (g_last_fused == &w) g_last_fused = nullptr;
-        it = g_fused.erase(it);
     }
     return pmx_topk_release(device);
 }

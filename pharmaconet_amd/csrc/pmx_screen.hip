@@ -1,0 +1,1148 @@
+// pmx_screen.hip - the screening hot path on gfx950 (CDNA4, wave64): one wavefront scores one ligand from its packed
+// record to its score.
+//
+// Reference path: PharmacophoreModel._scoring -> GraphMatcher.run() (src/pmnet/scoring/graph_match.py:63-279,
+// scoring/match_utils.py:9-122, scoring/tree.py:15-104); citations below are relative to /root/reference/src/pmnet.
+//
+// Lanes. A wavefront is 64 / G *slots* of G lanes; lane c of a slot is conformer c (G = 2^ceil(log2(max conformers)):
+// 8 at BASELINE.json's 8-conformer shape). What a slot stands for changes with the phase:
+//   * table phase: a slot owns one table entry - (ligand cluster i, model cluster a) for the self table S, ((i, a), (j, b))
+//     for the pair table P - and walks that entry's ligand node pairs (u, v) in a wave-uniform loop. The sum over the
+//     compatible model node pairs of one (u, v),
+//         F(d) = 1 / (|A||B|) * sum_{m in A, n in B} w_m w_n / std_mn * exp(-((d - mean_mn) / std_mn)^2 / 2),
+//     depends on the ligand only through the scalar d = |x_u - x_v|: it is a property of the model (and the call's type
+//     weights). fn_build_kernel tabulates every such F once per (model, weights) as piecewise quintic Hermite cells (from
+//     F, F', F'' evaluated in float64 at the knots; measured deviation from the exact sum < 3e-9 of the function's peak at
+//     h <= std_min / 5), so that an item costs one 32-byte gather and five FMAs instead of |A||B| (27 on average, up to
+//     169) Gaussian terms. The discrete part of match_utils.py - `num_pass < num_match * 0.5` (:61) - is NOT approximated:
+//     the set of distances where at least half of the model node pairs lie within 2 sigma is a union of float intervals
+//     computed exactly on the host when the model is created (pmx_api.hip, fn_windows) and stored with the cells; cells
+//     where that set is not one interval are flagged and counted term by term on the device.
+//   * tree phase: ONE depth-first walker per wavefront with wave-uniform control (scalar registers, scalar branches);
+//     a slot evaluates one candidate child of the current frame, so that a frame's children - their conformer
+//     masks, float64 totals and bound tests - are one pass of independent loads. The walker's stack lives in lane-indexed
+//     registers (v_readlane / v_writelane), the float64 path totals in 1.3 KB of LDS; nothing is spilled.
+//
+// Memory. The score tables of a ligand (S, P, search bounds R; 11 KB on average) are written to a per-wavefront slice of
+// global memory and read back by the same wavefront: they stay in the CU's L1 / the XCD's L2 and are overwritten by the
+// wave's next ligand - there is no per-chunk table arena, no size pass, no host read. Ligands whose tables exceed the
+// slice, and trees that run over their budget, move to a bump-allocated arena: over-budget walkers append the open
+// subtrees with >= 5 matches to a task queue (exactness argument: see walk()), which later launches of task_kernel drain.
+// Everything is ordered on the caller's stream.
+#include "pmx_device.h"
+
+#pragma clang fp contract(off)
+
+namespace pmx {
+
+// One cell of a tabulated pair function: value(t) = c0 + t (c1 + t (c2 + t (c3 + t (c4 + t c5)))), t in [0, 1) the position
+// inside the cell; the item passes the 2-sigma majority test of match_utils.py:56-61 iff lo <= d <= hi (lo = NaN: the pass
+// set is not an interval inside this cell - count the terms).
+struct FnCell {
+    float c[6];
+    float lo, hi;
+};
+static_assert(sizeof(FnCell) == 32, "FnCell layout");
+
+struct FnTable {
+    const FnCell *cells; // [NS * NS][ncell]
+    uint32_t NS;         // node subsets (0 = empty)
+    uint32_t ncell;
+    float inv_h;
+    uint32_t pad;
+};
+
+// Header of one ligand's tables, in a wave's slice or in the arena:
+//   [RecHeader][best u64[G]][S float[ksumtot][G]][P float[T][G]][R double[nl + 1][G]]
+// Pair entry ((i, a), (j, b)), i < j: rowbase[i] + k[i] * (ksum[j] - ksum[i + 1]) + a * k[j] + b.
+struct RecHeader {
+    uint32_t lig; // ligand index relative to the call's `first`
+    uint32_t nl, T, ksumtot;
+    uint32_t bytes; // of the whole record
+    uint32_t C;
+    uint32_t pad[2];
+    uint8_t k[PMX_MAX_LEVELS];
+    uint8_t pad2[12];
+    uint16_t ksum[PMX_MAX_LEVELS + 4];
+    uint32_t rowbase[PMX_MAX_LEVELS];
+    uint8_t pad3[64];
+};
+static_assert(sizeof(RecHeader) == 256, "RecHeader layout");
+
+template <int G>
+__host__ __device__ constexpr uint32_t rec_s_off() {
+    return sizeof(RecHeader) + G * 8;
+}
+template <int G>
+__host__ __device__ inline uint32_t rec_p_off(uint32_t ksumtot) {
+    return rec_s_off<G>() + (uint32_t)round16((uint64_t)ksumtot * G * 4);
+}
+template <int G>
+__host__ __device__ inline uint32_t rec_r_off(uint32_t ksumtot, uint32_t T) {
+    return rec_p_off<G>(ksumtot) + (uint32_t)round16((uint64_t)T * G * 4);
+}
+template <int G>
+__host__ __device__ inline uint64_t rec_bytes(uint32_t ksumtot, uint32_t T, uint32_t nl) {
+    return (uint64_t)rec_s_off<G>() + round16((uint64_t)ksumtot * G * 4) + round16((uint64_t)T * G * 4) + (uint64_t)(nl + 1) * G * 8;
+}
+
+// A subtree handed to the task queue: its root has >= 5 matches (see walk()).
+struct TaskRec { // 64 bytes, followed by double tot[G]
+    uint32_t rec16; // arena offset of the ligand's record, in 16-byte units
+    uint8_t f0;     // frame of the subtree's root
+    uint8_t nm;     // matches on the path, root included
+    uint16_t pad;
+    uint64_t mask;                    // conformer mask of the root
+    uint8_t path[2 * PMX_MAX_LEVELS]; // (level, candidate) of every match on the path
+    uint8_t pad2[8];
+};
+static_assert(sizeof(TaskRec) == 64, "TaskRec layout");
+template <int G>
+__host__ __device__ constexpr uint32_t task_rec_bytes() {
+    return sizeof(TaskRec) + G * 8;
+}
+
+constexpr int kShards = 64; // task queue shards (= the wave size: a task wave finds its record with one scan over the shards)
+constexpr int kStatWords = 16;
+constexpr int kScreenStatShards = 64;
+
+// Device-side control block of one call (zeroed by ctl_clear_kernel at the start of every super-chunk).
+struct Ctl {
+    uint32_t cursor[4];   // ligand cursors of the launches of a super-chunk: [0] slice pass, [1] arena pass, [2] carry pass
+    uint32_t ovf_count;   // ligands whose tables do not fit a slice
+    uint32_t carry_count; // ligands whose tables did not fit the arena this time
+    uint32_t heavy_count; // records in the arena that finalize has to score
+    uint32_t task_cursor;
+    unsigned long long arena_top; // bump allocator (bytes)
+    uint32_t qflag;               // a queue shard was full (the walker then keeps the subtree: exact, only slower)
+    uint32_t err;                 // iteration cap hit (cannot happen for a finite tree)
+    uint32_t qtail[kShards];
+    uint32_t round_lo[kShards], round_hi[kShards];
+    uint32_t round_total;
+    uint32_t pad[3];
+    unsigned long long stats[kScreenStatShards][kStatWords]; // sharded: [0] frames [1] passes [2] ligand waves over budget [3] items [4] exact-count cells [5] longest walk
+};
+
+struct ScreenParams {
+    DevModel M;
+    FnTable F;
+    DevLibrary lib;
+    const uint16_t *sidtab;    // [K * 128] node subset of (model cluster, ligand type mask); 0 = empty
+    const uint64_t *subnodes;  // [NS] node set of a subset
+    Weights W;                 // for the exact-term debug path
+    uint64_t first;            // library index of the call's first ligand
+    uint32_t lo, hi;           // ligands [lo, hi) of the call (relative to first) are this super-chunk
+    Ctl *ctl;
+    uint8_t *slices;           // [waves][slice_bytes]
+    uint32_t slice_bytes;
+    uint8_t *arena;
+    unsigned long long arena_bytes;
+    uint32_t *ovf_list, *carry_list, *heavy_list; // ligand indices / arena offsets (16-byte units)
+    uint32_t list_cap;
+    uint8_t *queue;
+    uint32_t qcap;             // records per shard
+    uint32_t budget;           // passes after which a walker starts handing subtrees to the queue
+    uint32_t min_levels;       // only subtrees with at least this many levels below their root are queued
+    uint32_t flags;            // 2: never queue, 4: no bound test, 8: exact Gaussian terms instead of the tabulated functions
+    uint32_t max_nodes;        // of the library (sizes the LDS node tables)
+    unsigned long long max_passes;
+    float *scores;
+    int32_t *status;
+    int mode;                  // 0: slice pass over [lo, hi); 1: arena pass over ovf_list; 2: arena pass over carry_list
+};
+
+// ------------------------------------------------------------------------------------------------ helpers
+__device__ inline int rl(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+// lane `lane` (wave-uniform) of v := value (this clang has no v_writelane builtin; a compare + select does it)
+__device__ inline int wl(int v, int lane, int value) { return (int)(threadIdx.x & 63) == lane ? value : v; }
+// The lane id as a value the optimiser cannot see through: address arithmetic derived from it stays inside the loop that uses it
+// (hoisted out of the persistent loops it was kept live - spilled - for the whole kernel).
+__device__ inline int lane_id() {
+    int l = (int)(threadIdx.x & 63);
+    asm volatile("" : "+v"(l));
+    return l;
+}
+__device__ inline int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ inline uint64_t uni64(uint64_t v) {
+    return ((uint64_t)(uint32_t)uni((int)(v >> 32)) << 32) | (uint64_t)(uint32_t)uni((int)(uint32_t)v);
+}
+template <typename T>
+__device__ inline T *uniptr(T *p) {
+    return reinterpret_cast<T *>(uni64(reinterpret_cast<uint64_t>(p)));
+}
+__device__ inline void wave_sync() { // LDS / global hand-over between the lanes of one wavefront
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+}
+__device__ inline float norm3f(float dx, float dy, float dz) { // np.linalg.norm of a float32 3-vector (ligand.py:349-351)
+    float s = dx * dx;
+    s = s + dy * dy;
+    s = s + dz * dz;
+    return sqrtf(s);
+}
+
+// ------------------------------------------------------------------------------------ fn_build_kernel
+// Tabulates F_(sa, sb)(d) for every pair of node subsets on the grid x_i = i * h: quintic Hermite cells from F, F', F''
+// at the two ends of a cell, evaluated in float64. `win` holds the exact pass windows of every cell (host, model-only).
+// A subset pair with a zero weight sum scores NaN in the reference (0 * (1 / 0), match_utils.py:50-52,69): NaN cells.
+__global__ void fn_build_kernel(DevModel M, Weights W, const uint64_t *subnodes, uint32_t NS, uint32_t ncell, float h,
+                                const float2 *win, FnCell *cells) {
+    const uint32_t fid = blockIdx.x;
+    const uint32_t sa = fid / NS, sb = fid - sa * NS;
+    const uint64_t A = subnodes[sa], B = subnodes[sb];
+    const int Nm = M.Nm;
+    bool a_nz = false, b_nz = false;
+    for (uint64_t x = A; x; x &= x - 1) a_nz = a_nz || W.w[M.node_type[__ffsll((unsigned long long)x) - 1]] != 0.f;
+    for (uint64_t x = B; x; x &= x - 1) b_nz = b_nz || W.w[M.node_type[__ffsll((unsigned long long)x) - 1]] != 0.f;
+    const bool empty = A == 0 || B == 0;
+    const bool nanfn = !empty && (!a_nz || !b_nz);
+    const double inv_mn = empty ? 0.0 : 1.0 / (double)(__popcll(A) * __popcll(B));
+    for (uint32_t i = threadIdx.x; i < ncell; i += blockDim.x) {
+        double f[2], d1[2], d2[2];
+        for (int e = 0; e < 2; ++e) {
+            const double x = (double)(i + e) * (double)h;
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+            if (!empty && !nanfn) {
+                for (uint64_t am = A; am; am &= am - 1) {
+                    const int m = __ffsll((unsigned long long)am) - 1;
+                    for (uint64_t bm = B; bm; bm &= bm - 1) {
+                        const int n = __ffsll((unsigned long long)bm) - 1;
+                        const float4 eg = M.edge[m * Nm + n]; // {mean, s, T, std}
+                        const float wprod = W.w[M.node_type[m]] * W.w[M.node_type[n]];
+                        const double coef = (double)(wprod / eg.w); // weights / stds in float32 (match_utils.py:65)
+                        const double sd = (double)eg.w, z = (x - (double)eg.x) / sd;
+                        const double g = exp(-0.5 * z * z);
+                        s0 += coef * g;
+                        s1 += coef * g * (-z / sd);
+                        s2 += coef * g * ((z * z - 1.0) / (sd * sd));
+                    }
+                }
+            }
+            f[e] = s0 * inv_mn;
+            d1[e] = s1 * inv_mn * (double)h;
+            d2[e] = s2 * inv_mn * (double)h * (double)h;
+        }
+        const double df = f[1] - f[0];
+        FnCell c;
+        c.c[0] = (float)f[0];
+        c.c[1] = (float)d1[0];
+        c.c[2] = (float)(0.5 * d2[0]);
+        c.c[3] = (float)(10.0 * df - 6.0 * d1[0] - 4.0 * d1[1] - 1.5 * d2[0] + 0.5 * d2[1]);
+        c.c[4] = (float)(-15.0 * df + 8.0 * d1[0] + 7.0 * d1[1] + 1.5 * d2[0] - d2[1]);
+        c.c[5] = (float)(6.0 * df - 3.0 * d1[0] - 3.0 * d1[1] - 0.5 * d2[0] + 0.5 * d2[1]);
+        if (nanfn) c.c[0] = __builtin_nanf("");
+        const float2 w = win[(size_t)fid * ncell + i];
+        c.lo = w.x;
+        c.hi = w.y;
+        cells[(size_t)fid * ncell + i] = c;
+    }
+}
+
+// ------------------------------------------------------------------------------------------- LDS of a wave
+template <int G>
+struct WaveShape {
+    uint32_t kp;     // candidates per level, padded
+    uint32_t nc_cap; // node-candidate entries
+    uint32_t off_cand, off_lcnt, off_nc, off_tot, off_pool, bytes;
+};
+template <int G>
+__host__ __device__ inline WaveShape<G> wave_shape(int K, int max_nodes) {
+    WaveShape<G> w;
+    w.kp = (uint32_t)((K + 3) & ~3);
+    w.nc_cap = w.kp * (uint32_t)((max_nodes + 3) & ~3);
+    uint32_t o = 512; // fixed part: type masks, level arrays
+    w.off_cand = o;
+    o += PMX_MAX_LEVELS * w.kp;
+    w.off_lcnt = o;
+    o += PMX_MAX_LEVELS * w.kp;
+    o = (o + 15u) & ~15u;
+    w.off_nc = o;
+    o += w.nc_cap * 2;
+    o = (o + 15u) & ~15u;
+    w.off_tot = o;
+    o += (PMX_MAX_LEVELS + 1) * G * 8;
+    w.off_pool = o;
+    o += G * 8;
+    w.bytes = o;
+    return w;
+}
+// fixed part (512 bytes): tm[64] | lstart[20] lend[20] lk[20] pad[4] | ksum u16[24] | ncoff u16[24] | rowbase u32[20] | cand bits u64[20]
+constexpr uint32_t kOffTm = 0, kOffStart = 64, kOffEnd = 84, kOffK = 104, kOffKsum = 128, kOffNcoff = 176, kOffRow = 224, kOffBits = 304;
+static_assert(kOffBits + 8 * PMX_MAX_LEVELS <= 512, "fixed LDS part");
+
+// ------------------------------------------------------------------------------------------------- walker
+// Iterative form of ClusterMatchTree.dfs_run (tree.py:55-104) with wave-uniform control. Frame f is the tree node whose
+// children are the candidates of level f (frame 0 = root). State of the current frame in scalars: nm = matches on the
+// path, mask = conformers still valid (tree.py:78-84), nb = next candidate to look at, mx = max_num_matches so far
+// (tree.py:96-97), flags = {this node is a match, a candidate child existed, skip child done}.
+//
+// One *pass* evaluates the next 64 / G candidates b of the frame at once (slot s <-> candidate nb + s, lane c <-> conformer):
+//   valid(b, c) = mask(c) and P[q -> (f, b)][c] > 0 for every matched ancestor q          (tree.py:78-84)
+//   total(b, c) = (total(parent, c) + S[f][b][c]) + sum_q P[q -> (f, b)][c]   in float64   (tree.py:38-41)
+// and the walker descends into the first candidate that exists (some conformer valid). After the return the remaining
+// candidates are evaluated again from nb on - nothing is cached per frame, which is what keeps the state in registers.
+// A frame at the last level is finished inside its pass: every existing candidate is a leaf that feeds the per-conformer
+// maximum (graph_match.py:103-109), then the skip leaf (tree.py:98-101).
+//
+// Exactness of pruning and splitting. `num_matches(A) + max_num_matches(A)` (tree.py:98) is the largest match count of a leaf
+// below A's candidate children, so the skip rule only asks whether a node with >= 5 matches exists there. For a child Y
+// of a frame with >= 4 matches (Y holds >= 5): every ancestor's skip decision is settled by Y's existence, decisions
+// inside Y's subtree depend on candidate existence only (nm + mx < 5 is never true there), and its leaves only feed a
+// per-conformer maximum. So Y may be (i) dropped when no leaf below it can exceed the maxima found so far - leaf totals
+// are bounded by total(Y) + R[f + 1] (build_bounds) - and (ii) walked by another wavefront (task queue); both count as
+// "returned >= 1" for the parent. Scores and every skip decision stay what the reference computes.
+template <int G>
+struct Walk {
+    // tables of the job
+    const unsigned char *Sb, *Pb, *Rb;
+    int nl;
+    int hk, hks, hrow; // lane l: k[l], ksum[l], rowbase[l]
+    // path: lane q holds match q
+    int matRB = 0, matKA = 0; // rowbase[j] - k_j * ksum[j + 1] | k_j | a << 8 | j << 16
+    // stack: lane f holds frame f
+    int stA = 0, stB = 0, stC = 0; // mask lo, mask hi, nb | mx << 8 | flags << 16 | nm << 24
+    double best = 0.0, flushed = 0.0;
+    unsigned long long frames = 0, passes = 0;
+    // current frame (kept here so that a walk can be interrupted and resumed, see kOverBudget)
+    int f = 0, f0 = 0, nm = 0, nb = 0, mx = 0;
+    unsigned flags = 0;
+    uint64_t mask = 0;
+};
+constexpr int kOverBudget = -1;
+template <int G>
+__host__ __device__ constexpr uint64_t group_mask() {
+    return G >= 64 ? ~0ull : ((1ull << (G & 63)) - 1ull);
+}
+
+constexpr unsigned kMatched = 1, kAny = 2, kSkipped = 4;
+constexpr double kBoundSlack = 1.0 + 1e-9; // covers the float64 rounding of the sums the bound is compared with
+
+template <int G>
+__device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *tot, unsigned long long *pool,
+                                    uint32_t rec16 /* arena record of the job (exports refer to it) */, bool export_mode,
+                                    unsigned long long budget, uint32_t wave_id) {
+    constexpr int SLOTS = 64 / G;
+    constexpr int PSH = G == 1 ? 2 : G == 2 ? 3 : G == 4 ? 4 : G == 8 ? 5 : G == 16 ? 6 : G == 32 ? 7 : 8; // log2 bytes of an entry
+    constexpr uint64_t GM = group_mask<G>();
+    const int lane = lane_id();
+    const int s = lane / G, c = lane % G;
+    const uint32_t lane_off = (uint32_t)lane * 4u; // (s * G + c) floats: candidate nb + s, conformer c
+    const int nl = w.nl;
+    const unsigned char *Sb = w.Sb, *Pb = w.Pb, *Rb = w.Rb;
+    const bool no_bound = (p.flags & 4) != 0;
+
+    const int f0 = w.f0;
+    int f = w.f, nm = w.nm, nb = w.nb, mx = w.mx;
+    unsigned flags = w.flags;
+    uint64_t mask = w.mask;
+    int ret = 0;
+    for (;;) {
+        if (!export_mode && w.passes > budget) { // over budget: the caller moves the job's tables to the arena and resumes in export mode
+            w.f = f, w.nm = nm, w.nb = nb, w.mx = mx, w.flags = flags, w.mask = mask;
+            return kOverBudget;
+        }
+        if (w.passes > p.max_passes) { // cannot happen for a finite tree; report instead of spinning
+            if (lane == 0) p.ctl->err = 1;
+            break;
+        }
+        const int kf = rl(w.hk, f), ksf = rl(w.hks, f);
+        const bool leaf_level = f == nl - 1;
+        bool descended = false;
+        const double tparent = tot[nm * G + c];
+        if (nb < kf) {
+            // pair-table rows of the matched ancestors against level f: lane q
+            const int ebv = w.matRB + __mul24(w.matKA & 255, ksf) + __mul24((w.matKA >> 8) & 255, kf);
+            while (nb < kf) {
+                const int b = nb + s;
+                const bool on = b < kf;
+                const uint32_t bo = on ? lane_off : (uint32_t)c * 4u; // idle slots read candidate nb (in bounds)
+                const float self = *reinterpret_cast<const float *>(Sb + (((uint32_t)(ksf + nb) << PSH) + bo));
+                bool valid = on && ((mask >> c) & 1ull);
+                double sum = 0.0;
+                int q = 0;
+                for (; q + 4 <= nm; q += 4) {
+                    float v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float *>(Pb + (((uint32_t)(rl(ebv, q + u) + nb) << PSH) + bo));
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        valid = valid && v[u] > 0.f;
+                        sum += (double)v[u];
+                    }
+                }
+                for (; q < nm; ++q) {
+                    const float v = *reinterpret_cast<const float *>(Pb + (((uint32_t)(rl(ebv, q) + nb) << PSH) + bo));
+                    valid = valid && v > 0.f;
+                    sum += (double)v;
+                }
+                const double t = (tparent + (double)self) + sum; // parent + self + accumulated pair (tree.py:38-41)
+                const unsigned long long vb = __ballot(valid);
+                ++w.passes;
+                if (vb) flags |= kAny;
+                if (leaf_level) {
+                    if (valid && t > w.best) w.best = t; // graph_match.py:105-108
+                    nb += SLOTS;
+                    continue;
+                }
+                unsigned long long ab = vb;
+                if (nm >= 4 && vb && !no_bound) { // the children hold >= 5 matches: drop those that cannot raise a maximum
+                    const double r = *reinterpret_cast<const double *>(Rb + (((uint32_t)(f + 1) << (PSH + 1)) + 8u * (uint32_t)c));
+                    const double pooled = __longlong_as_double((long long)pool[c]);
+                    const double bp = pooled > w.best ? pooled : w.best;
+                    ab = __ballot(valid && (t + r) * kBoundSlack > bp);
+                }
+                if (ab) {
+                    const int first = __ffsll(ab) - 1;
+                    const int ss = first / G;
+                    const unsigned long long before = ss == 0 ? 0ull : (vb & ((1ull << (ss * G)) - 1ull));
+                    if (before) mx = mx > 1 ? mx : 1; // existing children dropped by the bound test return at least 1
+                    const int bsel = nb + ss;
+                    nb = bsel + 1;
+                    const uint64_t cmask = (vb >> (ss * G)) & GM;
+                    if (export_mode && nm >= 4 && nl - (f + 1) >= (int)p.min_levels) {
+                        // hand the subtree to the task queue
+                        const uint32_t sh = (wave_id + (uint32_t)(w.passes >> 6)) & (kShards - 1);
+                        uint32_t slot = 0;
+                        if (lane == 0) slot = atomicAdd(&p.ctl->qtail[sh], 1u);
+                        slot = (uint32_t)uni((int)slot);
+                        if (slot < p.qcap) {
+                            unsigned char *tr = p.queue + ((size_t)sh * p.qcap + slot) * task_rec_bytes<G>();
+                            TaskRec *th = reinterpret_cast<TaskRec *>(tr);
+                            if (lane == 0) {
+                                th->rec16 = rec16;
+                                th->f0 = (uint8_t)(f + 1);
+                                th->nm = (uint8_t)(nm + 1);
+                                th->pad = 0;
+                                th->mask = cmask;
+                            }
+                            if (lane < nm) {
+                                th->path[2 * lane] = (uint8_t)(w.matKA >> 16);
+                                th->path[2 * lane + 1] = (uint8_t)(w.matKA >> 8);
+                            }
+                            if (lane == nm) {
+                                th->path[2 * lane] = (uint8_t)f;
+                                th->path[2 * lane + 1] = (uint8_t)bsel;
+                            }
+                            if (s == ss) reinterpret_cast<double *>(tr + sizeof(TaskRec))[c] = t;
+                            mx = mx > 1 ? mx : 1; // the child given away returns at least 1
+                            continue;
+                        }
+                        if (lane == 0) p.ctl->qflag = 1; // shard full: walk it here
+                    }
+                    // descend (tree.py:94-97)
+                    if (s == ss) tot[(nm + 1) * G + c] = t;
+                    w.stA = wl(w.stA, f, (int)(uint32_t)mask);
+                    if (G > 32) w.stB = wl(w.stB, f, (int)(uint32_t)(mask >> 32));
+                    w.stC = wl(w.stC, f, nb | (mx << 8) | ((int)flags << 16) | (nm << 24));
+                    // entry(this match, level f', b') = rowbase[f] + k_f * (ksum[f'] - ksum[f + 1]) + b * k_f' + b'
+                    w.matRB = wl(w.matRB, nm, rl(w.hrow, f) - kf * rl(w.hks, f + 1));
+                    w.matKA = wl(w.matKA, nm, kf | (bsel << 8) | (f << 16));
+                    ++f;
+                    ++nm;
+                    mask = cmask;
+                    flags = kMatched;
+                    nb = 0;
+                    mx = 0;
+                    ++w.frames;
+                    descended = true;
+                    break;
+                }
+                if (vb) mx = mx > 1 ? mx : 1; // every existing child of this pass was dropped
+                nb += SLOTS;
+            }
+            if (descended) {
+                wave_sync(); // the child's total is read by all slots
+                continue;
+            }
+        }
+        // the candidates of this frame are done
+        if (leaf_level) {
+            mx = (flags & kAny) ? 1 : 0;
+            if (!(flags & kAny) || nm + mx < 5) { // skip leaf (tree.py:98-101, :42-43): this node's totals
+                if (((mask >> c) & 1ull) && tparent > w.best) w.best = tparent;
+            }
+            // publish improved maxima to the other slots (the bound test reads them)
+            const bool up = w.best > w.flushed;
+            if (__ballot(up)) {
+                if (up) {
+                    atomicMax(&pool[c], (unsigned long long)__double_as_longlong(w.best));
+                    w.flushed = w.best;
+                }
+            }
+        } else if (!(flags & kSkipped) && (!(flags & kAny) || nm + mx < 5)) { // skip child (tree.py:98-101)
+            flags |= kSkipped;
+            w.stA = wl(w.stA, f, (int)(uint32_t)mask);
+            if (G > 32) w.stB = wl(w.stB, f, (int)(uint32_t)(mask >> 32));
+            w.stC = wl(w.stC, f, nb | (mx << 8) | ((int)flags << 16) | (nm << 24));
+            ++f;
+            flags = 0;
+            nb = 0;
+            mx = 0;
+            ++w.frames;
+            continue;
+        }
+        // return max_num_matches + matched (tree.py:102)
+        ret = mx + ((flags & kMatched) ? 1 : 0);
+        --f;
+        if (f < f0) break;
+        {
+            const int sc = rl(w.stC, f);
+            mask = (uint64_t)(uint32_t)rl(w.stA, f);
+            if (G > 32) mask |= (uint64_t)(uint32_t)rl(w.stB, f) << 32;
+            nb = sc & 255;
+            mx = (sc >> 8) & 255;
+            flags = (unsigned)(sc >> 16) & 255u;
+            nm = (sc >> 24) & 255;
+            mx = mx > ret ? mx : ret;
+        }
+    }
+    return ret;
+}
+
+
+// ------------------------------------------------------------------------------------------ table phase
+// One (ligand node, ligand node) item of match_utils.py:26-69 for the subset pair `fid` at distance d: the tabulated sum
+// (already divided by |A||B|) and whether the item fails the majority test of :56-61.
+template <bool EXACT>
+__device__ __forceinline__ void item(const ScreenParams &p, uint32_t sidu, uint32_t sidv, float d, float &acc, int &fails,
+                                     uint32_t &n_exact) {
+    if (!EXACT) {
+        const float x = d * p.F.inv_h; // exact: inv_h is a power of two
+        const int ci = min((int)x, (int)p.F.ncell - 1);
+        const float t = fminf(x - (float)ci, 1.0f);
+        const float4 *cell = reinterpret_cast<const float4 *>(p.F.cells + ((sidu * p.F.NS + sidv) * p.F.ncell + (uint32_t)ci));
+        const float4 a = cell[0], b = cell[1];
+        float v = __builtin_fmaf(t, b.y, b.x);
+        v = __builtin_fmaf(t, v, a.w);
+        v = __builtin_fmaf(t, v, a.z);
+        v = __builtin_fmaf(t, v, a.y);
+        v = __builtin_fmaf(t, v, a.x);
+        acc = acc + v;
+        if (__builtin_expect(b.z != b.z, 0)) { // the pass set is not one interval inside this cell: count the terms
+            const uint64_t A = p.subnodes[sidu], B = p.subnodes[sidv];
+            int np = 0;
+            for (uint64_t am = A; am; am &= am - 1)
+                for (uint64_t bm = B; bm; bm &= bm - 1) {
+                    const float4 e = p.M.edge[(__ffsll((unsigned long long)am) - 1) * p.M.Nm + (__ffsll((unsigned long long)bm) - 1)];
+                    np += fabsf(d - e.x) <= e.z ? 1 : 0;
+                }
+            fails += 2 * np < __popcll(A) * __popcll(B) ? 1 : 0;
+            ++n_exact;
+        } else {
+            fails += (d >= b.z && d <= b.w) ? 0 : 1;
+        }
+        return;
+    }
+    // debug / validation (flags & 8): the Gaussian terms themselves, float32 like match_utils.py, one v_exp_f32 per term
+    const uint64_t A = p.subnodes[sidu], B = p.subnodes[sidv];
+    if (!A || !B) return;
+    float sum = 0.f;
+    int np = 0;
+    bool a_nz = false, b_nz = false;
+    for (uint64_t am = A; am; am &= am - 1) a_nz = a_nz || p.W.w[p.M.node_type[__ffsll((unsigned long long)am) - 1]] != 0.f;
+    for (uint64_t bm = B; bm; bm &= bm - 1) b_nz = b_nz || p.W.w[p.M.node_type[__ffsll((unsigned long long)bm) - 1]] != 0.f;
+    for (uint64_t am = A; am; am &= am - 1) {
+        const int m = __ffsll((unsigned long long)am) - 1;
+        for (uint64_t bm = B; bm; bm &= bm - 1) {
+            const int n = __ffsll((unsigned long long)bm) - 1;
+            const float4 e = p.M.edge[m * p.M.Nm + n];
+            const float coef = (p.W.w[p.M.node_type[m]] * p.W.w[p.M.node_type[n]]) / e.w;
+            const float t = fabsf(d - e.x), q = t * e.y;
+            sum = __builtin_fmaf(coef, __builtin_amdgcn_exp2f(-(q * q)), sum);
+            np += t <= e.z ? 1 : 0;
+        }
+    }
+    const int mn = __popcll(A) * __popcll(B);
+    acc = acc + ((a_nz && b_nz) ? sum / (float)mn : __builtin_nanf(""));
+    fails += 2 * np < mn ? 1 : 0;
+}
+
+struct LevelInfo {
+    int nl;
+    uint32_t ksumtot, T;
+};
+
+// Cluster candidates and tree levels (graph_match.py:124-137, :87-88) of the record, into the wave's LDS: clusters arrive
+// sorted by priority_fn; a cluster is kept if some model cluster shares a type with it; at most 20 are kept. Then the
+// node-candidate table nc[level][candidate][node] = node subset of the model cluster compatible with the ligand node
+// (graph_match.py:145-155) and the counts L of ligand nodes with a non-empty subset (graph_match.py:164-171).
+template <int G>
+__device__ __forceinline__ LevelInfo scan_ligand(const ScreenParams &p, unsigned char *lds, const WaveShape<G> &ws, const Record &r) {
+    const int lane = lane_id();
+    uint8_t *tm = lds + kOffTm, *lstart = lds + kOffStart, *lend = lds + kOffEnd, *lk = lds + kOffK;
+    uint16_t *ksum = reinterpret_cast<uint16_t *>(lds + kOffKsum), *ncoff = reinterpret_cast<uint16_t *>(lds + kOffNcoff);
+    uint32_t *rowbase = reinterpret_cast<uint32_t *>(lds + kOffRow);
+    uint64_t *bits = reinterpret_cast<uint64_t *>(lds + kOffBits);
+    uint32_t *scal = reinterpret_cast<uint32_t *>(lds + kOffBits + 8 * PMX_MAX_LEVELS); // ksumtot, T
+    uint8_t *cand = lds + ws.off_cand, *lcnt = lds + ws.off_lcnt;
+    uint16_t *nc = reinterpret_cast<uint16_t *>(lds + ws.off_nc);
+    if (lane < r.n) tm[lane] = r.typemask[lane];
+    wave_sync();
+    int cs = 0, ce = 0;
+    uint64_t cb = 0;
+    if (lane < r.ncl) {
+        cs = lane ? r.cluster_end[lane - 1] : 0;
+        ce = r.cluster_end[lane];
+        unsigned lm = 0;
+        for (int u = cs; u < ce; ++u) lm |= tm[u];
+        cb = p.M.tclus[lm & 127u];
+    }
+    const unsigned long long bal = __ballot(cb != 0);
+    const int lev = __popcll(bal & ((1ull << lane) - 1ull));
+    const int nl = min((int)__popcll(bal), PMX_MAX_LEVELS);
+    if (cb && lev < PMX_MAX_LEVELS) {
+        lstart[lev] = (uint8_t)cs;
+        lend[lev] = (uint8_t)ce;
+        lk[lev] = (uint8_t)__popcll(cb);
+        bits[lev] = cb;
+    }
+    wave_sync();
+    if (lane == 0) {
+        uint32_t ks = 0, no = 0;
+        for (int l = 0; l < nl; ++l) {
+            ksum[l] = (uint16_t)ks;
+            ncoff[l] = (uint16_t)no;
+            ks += lk[l];
+            no += (uint32_t)lk[l] * (uint32_t)(lend[l] - lstart[l]);
+        }
+        ksum[nl] = (uint16_t)ks;
+        uint32_t rb = 0, run = 0;
+        for (int l = 0; l < nl; ++l) {
+            rowbase[l] = rb;
+            run += lk[l];
+            rb += (uint32_t)lk[l] * (ks - run);
+        }
+        scal[0] = ks;
+        scal[1] = rb;
+    }
+    if (lane < nl) {
+        uint64_t x = bits[lane];
+        for (int q = 0; x; x &= x - 1, ++q) cand[lane * ws.kp + q] = (uint8_t)(__ffsll((unsigned long long)x) - 1);
+    }
+    wave_sync();
+    for (int l = 0; l < nl; ++l) {
+        const int s0 = uni(lstart[l]), n = uni(lend[l]) - s0, k = uni(lk[l]), base = uni(ncoff[l]);
+        const float inv_n = 1.0f / (float)n;
+        for (int idx = lane; idx < k * n; idx += 64) {
+            const int q = (int)(((float)idx + 0.5f) * inv_n), u = idx - q * n;
+            nc[base + idx] = p.sidtab[(uint32_t)cand[l * ws.kp + q] * 128u + tm[s0 + u]];
+        }
+    }
+    wave_sync();
+    for (int l = 0; l < nl; ++l) {
+        const int n = uni(lend[l]) - uni(lstart[l]), k = uni(lk[l]), base = uni(ncoff[l]);
+        if (lane < k) {
+            int cnt = 0;
+            for (int u = 0; u < n; ++u) cnt += nc[base + lane * n + u] != 0 ? 1 : 0;
+            lcnt[l * ws.kp + lane] = (uint8_t)cnt;
+        }
+    }
+    wave_sync();
+    LevelInfo L;
+    L.nl = nl;
+    L.ksumtot = (uint32_t)uni((int)scal[0]);
+    L.T = (uint32_t)uni((int)scal[1]);
+    return L;
+}
+
+struct Pos3 {
+    float x, y, z;
+};
+
+// LigandNodeCluster.center / .size for one conformer (ligand.py:458-473).
+__device__ __forceinline__ void center_size(const float *xyz, int C, int start, int end, int cc, Pos3 &center, float &size) {
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (int u = start; u < end; ++u) {
+        const uint32_t o = (uint32_t)(u * 3 * C + cc);
+        sx = sx + xyz[o];
+        sy = sy + xyz[o + C];
+        sz = sz + xyz[o + 2 * C];
+    }
+    const float cnt = (float)(end - start);
+    center = Pos3{sx / cnt, sy / cnt, sz / cnt};
+    float mx = 0.f;
+    for (int u = start; u < end; ++u) {
+        const uint32_t o = (uint32_t)(u * 3 * C + cc);
+        const float r = norm3f(xyz[o] - center.x, xyz[o + C] - center.y, xyz[o + 2 * C] - center.z);
+        mx = (u == start || r > mx) ? r : mx;
+    }
+    size = mx;
+}
+
+// The self / pair score tables of match_utils.py for the ligand whose levels are in LDS, into `rec`.
+template <int G, bool EXACT>
+__device__ __forceinline__ void build_tables(const ScreenParams &p, unsigned char *lds, const WaveShape<G> &ws, const Record &r, const LevelInfo &L,
+                                             unsigned char *rec, uint32_t &n_items, uint32_t &n_exact) {
+    constexpr int SLOTS = 64 / G;
+    constexpr uint64_t GM = group_mask<G>();
+    const int lane = lane_id();
+    const int s = lane / G, c = lane % G;
+    const int C = r.C, cc = c < C ? c : C - 1;
+    const bool lane_live = c < C;
+    const uint8_t *lstart = lds + kOffStart, *lend = lds + kOffEnd, *lk = lds + kOffK;
+    const uint16_t *ksum = reinterpret_cast<const uint16_t *>(lds + kOffKsum), *ncoff = reinterpret_cast<const uint16_t *>(lds + kOffNcoff);
+    const uint8_t *cand = lds + ws.off_cand, *lcnt = lds + ws.off_lcnt;
+    const uint16_t *nc = reinterpret_cast<const uint16_t *>(lds + ws.off_nc);
+    const float *xyz = uniptr(r.xyz);
+    float *St = reinterpret_cast<float *>(rec + rec_s_off<G>());
+    float *Pt = reinterpret_cast<float *>(rec + rec_p_off<G>(L.ksumtot));
+    const int nl = L.nl, K = p.M.K;
+    uint32_t pair_base = 0;
+    for (int i = 0; i < nl; ++i) {
+        const int si = uni(lstart[i]), ni = uni(lend[i]) - si, ki = uni(lk[i]), nci = uni(ncoff[i]), ksi = uni(ksum[i]);
+        // ---- self table S[i][a] (match_utils.py:77-122): node pairs u < v of the cluster
+        for (int q0 = 0; q0 < ki; q0 += SLOTS) {
+            const int q = q0 + s;
+            const bool on = q < ki;
+            const int row = nci + (on ? q : 0) * ni;
+            float acc = 0.f;
+            int fails = 0;
+            for (int u = 0; u + 1 < ni; ++u) {
+                const uint32_t ou = (uint32_t)((si + u) * 3 * C + cc);
+                const float ux = xyz[ou], uy = xyz[ou + C], uz = xyz[ou + 2 * C];
+                const uint32_t sidu = nc[row + u];
+                for (int v = u + 1; v < ni; ++v) {
+                    const uint32_t ov = (uint32_t)((si + v) * 3 * C + cc);
+                    const float d = norm3f(ux - xyz[ov], uy - xyz[ov + C], uz - xyz[ov + 2 * C]);
+                    item<EXACT>(p, sidu, nc[row + v], d, acc, fails, n_exact);
+                    ++n_items;
+                }
+            }
+            if (on) St[(size_t)(ksi + q) * G + c] = acc;
+        }
+        Pos3 ctr_i;
+        float size_i;
+        center_size(xyz, C, si, si + ni, cc, ctr_i, size_i);
+        for (int j = i + 1; j < nl; ++j) {
+            const int sj = uni(lstart[j]), nj = uni(lend[j]) - sj, kj = uni(lk[j]), ncj = uni(ncoff[j]);
+            Pos3 ctr_j;
+            float size_j;
+            center_size(xyz, C, sj, sj + nj, cc, ctr_j, size_j);
+            const float ldist = norm3f(ctr_i.x - ctr_j.x, ctr_i.y - ctr_j.y, ctr_i.z - ctr_j.z); // graph_match.py:240
+            const float lsize = size_i + size_j;                                                  // :241
+            const int E = ki * kj;
+            const float inv_kj = 1.0f / (float)kj;
+            for (int e0 = 0; e0 < E; e0 += SLOTS) {
+                const int e = e0 + s;
+                const bool on = e < E;
+                const int ee = on ? e : e0;
+                const int sa = (int)(((float)ee + 0.5f) * inv_kj), sb = ee - sa * kj;
+                const int a = cand[i * ws.kp + sa], b = cand[j * ws.kp + sb];
+                // cluster-distance prefilter (graph_match.py:263-268): the entry is computed if some conformer passes
+                const float2 mp = p.M.cpair[a * K + b];
+                const bool near = on && lane_live && !((fabsf(ldist - mp.x) - lsize) > mp.y);
+                const unsigned long long nbal = __ballot(near);
+                float acc = 0.f;
+                int fails = 0;
+                if (nbal) {
+                    const int rowa = nci + sa * ni, rowb = ncj + sb * nj;
+                    for (int u = 0; u < ni; ++u) {
+                        const uint32_t ou = (uint32_t)((si + u) * 3 * C + cc);
+                        const float ux = xyz[ou], uy = xyz[ou + C], uz = xyz[ou + 2 * C];
+                        const uint32_t sidu = nc[rowa + u];
+                        for (int v = 0; v < nj; ++v) {
+                            const uint32_t ov = (uint32_t)((sj + v) * 3 * C + cc);
+                            const float d = norm3f(ux - xyz[ov], uy - xyz[ov + C], uz - xyz[ov + 2 * C]);
+                            item<EXACT>(p, sidu, nc[rowb + v], d, acc, fails, n_exact);
+                        }
+                    }
+                    n_items += (uint32_t)(ni * nj);
+                }
+                const bool near_any = ((nbal >> (s * G)) & GM) != 0;
+                const int L1 = lcnt[i * ws.kp + sa], L2 = lcnt[j * ws.kp + sb]; // graph_match.py:164-171
+                // match_utils.py:71-74: -1 unless num_fails <= L1 * L2 / 2; entries that fail the prefilter are -1 (graph_match.py:266-268)
+                const float value = (near_any && 2 * fails <= L1 * L2) ? acc : -1.f;
+                if (on) Pt[(size_t)(pair_base + (uint32_t)e) * G + c] = value;
+            }
+            pair_base += (uint32_t)E;
+        }
+    }
+}
+
+// Upper bounds for the tree search: level l can add at most
+//   U[l][c] = max(0, max_b (S[l][b][c] + sum_{j < l} max(0, max_a P[(j, a), (l, b)][c])))
+// to a conformer's total whatever is picked on the other levels, so R[f][c] = sum_{l >= f} U[l][c] bounds everything the
+// levels f.. add. (The reported score only needs the per-conformer maximum over leaves, graph_match.py:103-109.)
+template <int G>
+__device__ __forceinline__ void build_bounds(const ScreenParams &p, unsigned char *lds, const LevelInfo &L, unsigned char *rec) {
+    constexpr int SLOTS = 64 / G;
+    const int lane = lane_id();
+    const int s = lane / G, c = lane % G;
+    const uint8_t *lk = lds + kOffK;
+    const uint16_t *ksum = reinterpret_cast<const uint16_t *>(lds + kOffKsum);
+    const uint32_t *rowbase = reinterpret_cast<const uint32_t *>(lds + kOffRow);
+    const float *St = reinterpret_cast<const float *>(rec + rec_s_off<G>());
+    const float *Pt = reinterpret_cast<const float *>(rec + rec_p_off<G>(L.ksumtot));
+    double *Rt = reinterpret_cast<double *>(rec + rec_r_off<G>(L.ksumtot, L.T));
+    const int nl = L.nl;
+    if (p.flags & 4) { // debug: nothing is ever dropped
+        for (int l = s; l <= nl; l += SLOTS) Rt[(size_t)l * G + c] = __builtin_inf();
+        return;
+    }
+    double suffix = 0.0;
+    if (s == 0) Rt[(size_t)nl * G + c] = 0.0;
+    for (int l = nl - 1; l >= 0; --l) {
+        const int kl = uni(lk[l]), ksl = uni(ksum[l]);
+        double u = 0.0;
+        for (int b = s; b < kl; b += SLOTS) {
+            double v = (double)St[(size_t)(ksl + b) * G + c];
+            for (int j = 0; j < l; ++j) {
+                const int kj = uni(lk[j]);
+                const uint32_t e0 = (uint32_t)uni((int)rowbase[j]) + (uint32_t)kj * (uint32_t)(ksl - uni((int)ksum[j + 1])) + (uint32_t)b;
+                float m = 0.f;
+                for (int a = 0; a < kj; ++a) {
+                    const float pv = Pt[(size_t)(e0 + (uint32_t)a * (uint32_t)kl) * G + c];
+                    m = pv > m ? pv : m;
+                }
+                v += (double)m;
+            }
+            u = v > u ? v : u;
+        }
+#pragma unroll
+        for (int d = G; d < 64; d <<= 1) {
+            const double o = __shfl_xor(u, d);
+            u = o > u ? o : u;
+        }
+        suffix += u;
+        if (s == 0) Rt[(size_t)l * G + c] = suffix;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ kernels
+__device__ inline void flush_stats(Ctl *ctl, uint32_t wave_id, unsigned long long frames, unsigned long long passes, unsigned long long over,
+                                   unsigned long long items, unsigned long long exact, unsigned long long longest) {
+    unsigned long long *st = ctl->stats[wave_id & (kScreenStatShards - 1)];
+    atomicAdd(st + 0, frames);
+    atomicAdd(st + 1, passes);
+    atomicAdd(st + 2, over);
+    atomicAdd(st + 3, items);
+    atomicAdd(st + 4, exact);
+    atomicMax(st + 5, longest);
+}
+
+// Bump allocation in the arena by lane 0; returns the byte offset or ~0ull.
+__device__ inline unsigned long long arena_alloc(const ScreenParams &p, uint32_t bytes) {
+    unsigned long long off = 0;
+    if ((threadIdx.x & 63) == 0) off = atomicAdd(&p.ctl->arena_top, (unsigned long long)((bytes + 255u) & ~255u));
+    off = uni64(off);
+    return off + bytes <= p.arena_bytes ? off : ~0ull;
+}
+
+#ifndef PMX_SCREEN_WAVES
+#define PMX_SCREEN_WAVES 6 // waves per SIMD the register budget is set for (<= 80 VGPRs: nothing spilled to memory)
+#endif
+
+struct WaveStats {
+    unsigned long long frames = 0, passes = 0, over = 0, items = 0, exact = 0, longest = 0;
+};
+
+// One ligand, from its record to its score. The lane id is taken afresh (lane_id() is opaque to the optimiser): address
+// arithmetic of this body that only depends on the lane would otherwise be hoisted out of the persistent loop and spilled.
+template <int G, bool EXACT>
+__device__ __forceinline__ void score_ligand(const ScreenParams &p, unsigned char *lds, const uint32_t li, const uint32_t wave_id, WaveStats &stat) {
+    const int lane = lane_id();
+    const int s = lane / G, c = lane % G;
+    const WaveShape<G> ws = wave_shape<G>(p.M.K, (int)p.max_nodes);
+    double *tot = reinterpret_cast<double *>(lds + ws.off_tot);
+    unsigned long long *pool = reinterpret_cast<unsigned long long *>(lds + ws.off_pool);
+    unsigned char *slice = p.slices + (size_t)wave_id * p.slice_bytes;
+    Record r = parse_record(uniptr(p.lib.data + p.lib.offsets[p.first + li]));
+    r.n = uni(r.n), r.C = uni(r.C), r.ncl = uni(r.ncl); // the record is the same for the whole wave: say so
+    r.typemask = uniptr(r.typemask), r.cluster_end = uniptr(r.cluster_end), r.xyz = uniptr(r.xyz);
+    if (p.mode == 0) {
+        if (!record_supported(r)) {
+            if (lane == 0) {
+                p.scores[li] = __builtin_nanf("");
+                if (p.status) p.status[li] = PMX_LIGAND_UNSUPPORTED;
+            }
+            return;
+        }
+        if (lane == 0 && p.status) p.status[li] = PMX_LIGAND_OK;
+    }
+    const LevelInfo L = scan_ligand<G>(p, lds, ws, r);
+    if (L.nl == 0) { // no ligand cluster has a candidate (graph_match.py:95-99)
+        if (lane == 0) p.scores[li] = 0.f;
+        return;
+    }
+    const uint64_t bytes64 = rec_bytes<G>(L.ksumtot, L.T, (uint32_t)L.nl);
+    unsigned char *rec = slice;
+    uint32_t rec16 = 0;
+    bool in_arena = false;
+    if (p.mode == 0) {
+        if (bytes64 > p.slice_bytes) { // tables do not fit the slice: the arena pass takes this ligand
+            if (lane == 0) {
+                const uint32_t o = atomicAdd(&p.ctl->ovf_count, 1u);
+                if (o < p.list_cap) p.ovf_list[o] = li;
+                atomicAdd(&p.ctl->stats[wave_id & (kScreenStatShards - 1)][7], 1ull);
+            }
+            return;
+        }
+    } else {
+        const unsigned long long off = bytes64 < (1ull << 31) ? arena_alloc(p, (uint32_t)bytes64) : ~0ull;
+        if (off == ~0ull) {
+            if (lane == 0) {
+                if (p.mode == 1) {
+                    const uint32_t o = atomicAdd(&p.ctl->carry_count, 1u);
+                    if (o < p.list_cap) p.carry_list[o] = li;
+                } else { // larger than the whole arena
+                    p.scores[li] = __builtin_nanf("");
+                    if (p.status) p.status[li] = PMX_LIGAND_TOO_LARGE;
+                }
+            }
+            return;
+        }
+        rec = p.arena + off;
+        rec16 = (uint32_t)(off >> 4);
+        in_arena = true;
+    }
+    // ---- header
+    RecHeader *H = reinterpret_cast<RecHeader *>(rec);
+    {
+        const uint8_t *lk = lds + kOffK;
+        const uint16_t *ksum = reinterpret_cast<const uint16_t *>(lds + kOffKsum);
+        const uint32_t *rowbase = reinterpret_cast<const uint32_t *>(lds + kOffRow);
+        if (lane == 0) {
+            H->lig = li;
+            H->nl = (uint32_t)L.nl;
+            H->T = L.T;
+            H->ksumtot = L.ksumtot;
+            H->bytes = (uint32_t)bytes64;
+            H->C = (uint32_t)r.C;
+        }
+        if (lane < L.nl) {
+            H->k[lane] = lk[lane];
+            H->rowbase[lane] = rowbase[lane];
+        }
+        if (lane <= L.nl) H->ksum[lane] = ksum[lane];
+        if (lane < G) reinterpret_cast<unsigned long long *>(rec + sizeof(RecHeader))[lane] = 0ull;
+    }
+    uint32_t n_items = 0, n_exact = 0;
+#ifndef XNO_TABLES
+    build_tables<G, EXACT>(p, lds, ws, r, L, rec, n_items, n_exact);
+#endif
+    wave_sync();
+#ifndef XNO_BOUNDS
+    build_bounds<G>(p, lds, L, rec);
+#endif
+    // ---- tree search
+    Walk<G> w;
+    w.Sb = rec + rec_s_off<G>();
+    w.Pb = rec + rec_p_off<G>(L.ksumtot);
+    w.Rb = rec + rec_r_off<G>(L.ksumtot, L.T);
+    w.nl = L.nl;
+    {
+        const uint8_t *lk = lds + kOffK;
+        const uint16_t *ksum = reinterpret_cast<const uint16_t *>(lds + kOffKsum);
+        const uint32_t *rowbase = reinterpret_cast<const uint32_t *>(lds + kOffRow);
+        w.hk = lane < L.nl ? (int)lk[lane] : 0;
+        w.hks = lane <= L.nl ? (int)ksum[lane] : 0;
+        w.hrow = lane < L.nl ? (int)rowbase[lane] : 0;
+    }
+    if (s == 0) {
+        tot[c] = 0.0;
+        pool[c] = 0ull;
+    }
+    w.f = w.f0 = 0;
+    w.nm = 0;
+    w.mask = (r.C >= 64) ? ~0ull : ((1ull << r.C) - 1ull);
+    w.flags = 0;
+    wave_sync();
+    // The walk is interrupted once, when it runs over its budget: the tables then move to the arena (queued subtrees refer
+    // to them) and the walk resumes handing subtrees with >= 5 matches to the task queue.
+    unsigned long long budget = (p.flags & 2) ? ~0ull : (unsigned long long)p.budget;
+    bool heavy = false, export_mode = false;
+    for (;;) {
+        const int rc = walk<G>(w, p, tot, pool, rec16, export_mode, budget, wave_id);
+        if (rc != kOverBudget) break;
+        ++stat.over;
+        budget = ~0ull;
+        if (!in_arena) {
+            const unsigned long long off = arena_alloc(p, (uint32_t)bytes64);
+            if (off != ~0ull) {
+                const uint4 *src = reinterpret_cast<const uint4 *>(rec);
+                uint4 *dst = reinterpret_cast<uint4 *>(p.arena + off);
+                const uint32_t n16 = ((uint32_t)bytes64 + 15u) / 16u;
+                for (uint32_t i = lane; i < n16; i += 64) dst[i] = src[i];
+                rec16 = (uint32_t)(off >> 4);
+                in_arena = true;
+            }
+        }
+        if (in_arena) { // (arena full otherwise: the wave walks the tree alone - exact, only slower)
+            heavy = export_mode = true;
+            if (lane == 0) {
+                const uint32_t o = atomicAdd(&p.ctl->heavy_count, 1u);
+                if (o < p.list_cap) p.heavy_list[o] = rec16;
+            }
+            __threadfence(); // the arena copy is read by later kernels
+        }
+    }
+    stat.frames += w.frames;
+    stat.passes += w.passes;
+    stat.items += n_items;
+    stat.exact += n_exact;
+    stat.longest = w.passes > stat.longest ? w.passes : stat.longest;
+    // ---- per-conformer maxima over the slots -> score
+    if (w.best > 0.0) atomicMax(&pool[c], (unsigned long long)__double_as_longlong(w.best));
+    wave_sync();
+    const double bc = __longlong_as_double((long long)pool[c]);
+    if (heavy) { // split ligand: the task waves add their maxima, finalize_kernel takes the mean
+        if (s == 0 && bc > 0.0) atomicMax(reinterpret_cast<unsigned long long *>(p.arena + (size_t)rec16 * 16 + sizeof(RecHeader)) + c,
+                                          (unsigned long long)__double_as_longlong(bc));
+    } else { // mean over conformers (graph_match.py:109); lanes beyond C hold 0
+        double sum = (s == 0 && c < r.C) ? bc : 0.0;
+#pragma unroll
+        for (int d = 1; d < G; d <<= 1) sum += __shfl_xor(sum, d);
+        if (lane == 0) p.scores[li] = (float)(sum / (double)r.C);
+    }
+}
+
+// Persistent wavefronts (one per block): fetch a ligand, build its tables in the wave's slice (mode 0) or in the arena
+// (modes 1 / 2: ligands whose tables do not fit a slice), walk its tree, write its score.
+template <int G, bool EXACT>
+__global__ __launch_bounds__(64, PMX_SCREEN_WAVES) void ligand_kernel(const ScreenParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int lane = lane_id();
+    const uint32_t wave_id = blockIdx.x;
+    const uint32_t todo = p.mode == 0 ? p.hi - p.lo : (p.mode == 1 ? min(p.ctl->ovf_count, p.list_cap) : min(p.ctl->carry_count, p.list_cap));
+    const uint32_t *list = p.mode == 1 ? p.ovf_list : p.carry_list;
+    WaveStats stat;
+    for (;;) {
+        uint32_t next = 0;
+        if (lane == 0) next = atomicAdd(&p.ctl->cursor[p.mode], 1u);
+        next = (uint32_t)uni((int)next);
+        if (next >= todo) break;
+        const uint32_t li = p.mode == 0 ? p.lo + next : (uint32_t)uni((int)list[next]);
+        score_ligand<G, EXACT>(p, lds, li, wave_id, stat);
+    }
+    if (lane == 0) flush_stats(p.ctl, wave_id, stat.frames, stat.passes, stat.over, stat.items, stat.exact, stat.longest);
+}
+
+// Snapshot of the task queue between rounds: the records appended since the last round are this round's tasks.
+__global__ void round_kernel(Ctl *ctl, uint32_t qcap) {
+    const int lane = lane_id();
+    const uint32_t lo = ctl->round_hi[lane], hi = min(ctl->qtail[lane], qcap);
+    uint32_t n = hi - lo;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) n += __shfl_xor(n, d);
+    ctl->round_lo[lane] = lo;
+    ctl->round_hi[lane] = hi;
+    if (lane == 0) {
+        ctl->round_total = n;
+        ctl->task_cursor = 0;
+        ctl->stats[0][6] += n; // tasks of the call (this kernel is alone on the stream)
+    }
+}
+
+// Persistent wavefronts over the round's subtrees.
+template <int G>
+__global__ __launch_bounds__(64, PMX_SCREEN_WAVES) void task_kernel(const ScreenParams p, int last_round) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int lane = lane_id();
+    const int s = lane / G, c = lane % G;
+    const uint32_t wave_id = blockIdx.x;
+    const WaveShape<G> ws = wave_shape<G>(p.M.K, (int)p.max_nodes);
+    double *tot = reinterpret_cast<double *>(lds + ws.off_tot);
+    unsigned long long *pool = reinterpret_cast<unsigned long long *>(lds + ws.off_pool);
+    const uint32_t total = p.ctl->round_total;
+    // block nx -> (shard, record): inclusive scan of the shards' record counts over the lanes
+    const uint32_t lo_l = p.ctl->round_lo[lane], cnt_l = p.ctl->round_hi[lane] - lo_l;
+    uint32_t inc = cnt_l;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(inc, d);
+        if (lane >= d) inc += t;
+    }
+    unsigned long long st_frames = 0, st_passes = 0, st_longest = 0;
+    for (;;) {
+        uint32_t nx = 0;
+        if (lane == 0) nx = atomicAdd(&p.ctl->task_cursor, 1u);
+        nx = (uint32_t)uni((int)nx);
+        if (nx >= total) break;
+        const int sh = __popcll(__ballot(nx >= inc)); // shards wholly before task nx (inc is non-decreasing)
+        const uint32_t before = sh ? (uint32_t)__shfl(inc, sh - 1) : 0u;
+        const uint32_t recno = (uint32_t)__shfl(lo_l, sh) + (nx - before);
+        const unsigned char *tr = uniptr(p.queue + ((size_t)sh * p.qcap + recno) * task_rec_bytes<G>());
+        const TaskRec *th = reinterpret_cast<const TaskRec *>(tr);
+        const uint32_t rec16 = (uint32_t)uni((int)th->rec16);
+        const unsigned char *rec = p.arena + (size_t)rec16 * 16;
+        const RecHeader *H = reinterpret_cast<const RecHeader *>(rec);
+        const int nl = uni((int)H->nl);
+        const uint32_t ksumtot = (uint32_t)uni((int)H->ksumtot), T = (uint32_t)uni((int)H->T);
+        Walk<G> w;
+        w.Sb = rec + rec_s_off<G>();
+        w.Pb = rec + rec_p_off<G>(ksumtot);
+        w.Rb = rec + rec_r_off<G>(ksumtot, T);
+        w.nl = nl;
+        w.hk = lane < nl ? (int)H->k[lane] : 0;
+        w.hks = lane <= nl ? (int)H->ksum[lane] : 0;
+        w.hrow = lane < nl ? (int)H->rowbase[lane] : 0;
+        const int nm0 = uni((int)th->nm), f0 = uni((int)th->f0);
+        if (lane < nm0) {
+            const int j = th->path[2 * lane], a = th->path[2 * lane + 1];
+            const int kj = H->k[j];
+            w.matRB = (int)H->rowbase[j] - kj * (int)H->ksum[j + 1];
+            w.matKA = kj | (a << 8) | (j << 16);
+        }
+        const unsigned long long *gbest = reinterpret_cast<const unsigned long long *>(rec + sizeof(RecHeader));
+        if (s == 0) {
+            tot[nm0 * G + c] = reinterpret_cast<const double *>(tr + sizeof(TaskRec))[c];
+            pool[c] = gbest[c]; // maxima of the ligand's finished walkers
+        }
+        w.f = w.f0 = f0;
+        w.nm = nm0;
+        w.mask = uni64(th->mask);
+        w.flags = kMatched;
+        wave_sync();
+        // a subtree that can no longer raise any maximum (the maxima may have grown since it was queued) is not walked
+        bool go = true;
+        if (!(p.flags & 4) && f0 < nl) {
+            const double r = *reinterpret_cast<const double *>(w.Rb + ((size_t)f0 * G + c) * 8);
+            const double t = tot[nm0 * G + c];
+            go = __ballot(((w.mask >> c) & 1ull) && (t + r) * kBoundSlack > __longlong_as_double((long long)pool[c])) != 0;
+        }
+        if (go) {
+            const unsigned long long budget = (last_round || (p.flags & 2)) ? ~0ull : (unsigned long long)p.budget;
+            bool export_mode = false;
+            while (walk<G>(w, p, tot, pool, rec16, export_mode, export_mode ? ~0ull : budget, wave_id) == kOverBudget) export_mode = true;
+            if (w.best > 0.0) atomicMax(&pool[c], (unsigned long long)__double_as_longlong(w.best));
+            wave_sync();
+            const unsigned long long bc = pool[c];
+            if (s == 0 && bc > gbest[c]) atomicMax(reinterpret_cast<unsigned long long *>(p.arena + (size_t)rec16 * 16 + sizeof(RecHeader)) + c, bc);
+        }
+        st_frames += w.frames;
+        st_passes += w.passes;
+        st_longest = w.passes > st_longest ? w.passes : st_longest;
+        wave_sync();
+    }
+    if (lane == 0) flush_stats(p.ctl, wave_id, st_frames, st_passes, 0, 0, 0, st_longest);
+}
+
+// Scores of the ligands whose tree was split: mean over conformers of the combined maxima (graph_match.py:109).
+template <int G>
+__global__ void finalize_kernel(const ScreenParams p) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= min(p.ctl->heavy_count, p.list_cap)) return;
+    const unsigned char *rec = p.arena + (size_t)p.heavy_list[i] * 16;
+    const RecHeader *H = reinterpret_cast<const RecHeader *>(rec);
+    const unsigned long long *best = reinterpret_cast<const unsigned long long *>(rec + sizeof(RecHeader));
+    const int C = (int)H->C;
+    double sum = 0.0;
+    for (int c = 0; c < C; ++c) sum += __longlong_as_double((long long)best[c]);
+    p.scores[H->lig] = (float)(sum / (double)C);
+}
+
+// Start of a super-chunk: cursors, lists, arena and queue are empty again (the statistics survive unless asked).
+__global__ void ctl_clear_kernel(Ctl *ctl, int clear_stats, int keep_carry) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t head_words = offsetof(Ctl, stats) / 4, all_words = sizeof(Ctl) / 4;
+    uint32_t *w = reinterpret_cast<uint32_t *>(ctl);
+    if (i < head_words) {
+        if (i == offsetof(Ctl, carry_count) / 4 && keep_carry) return;
+        if (i != offsetof(Ctl, err) / 4 && i != offsetof(Ctl, qflag) / 4) w[i] = 0;
+        else if (clear_stats) w[i] = 0;
+    } else if (i < all_words && clear_stats) {
+        w[i] = 0;
+    }
+}
+
+} // namespace pmx

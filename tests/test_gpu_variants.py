@@ -71,12 +71,15 @@ def test_zero_type_weight_matches_oracle(oracle):
         assert np.abs(default - got).max() > 0.5  # the weight matters on this library
 
 
-@pytest.mark.parametrize("env", [{"PMX_ENGINE": "2"}, {"PMX_TABLES": "3"}, {"PMX_TABLES": "4"}],
-                         ids=["fused-matcher", "tables-v3", "tables-v4"])
+@pytest.mark.parametrize("env", [{"PMX_TREE_FLAGS": "8"}, {"PMX_TREE_FLAGS": "4"}, {"PMX_BUDGET": "16", "PMX_MIN_LEVELS": "0"},
+                                 {"PMX_SLICE_KB": "4"}, {"PMX_SLICE_KB": "4", "PMX_ARENA_MB": "16", "PMX_BUDGET": "64"}],
+                         ids=["exact-terms", "no-bound-test", "tiny-budget", "tiny-slices", "tiny-slices-and-arena"])
 @pytest.mark.parametrize("name", GOLDEN_SETS)
-def test_alternative_engines_match_reference_golden(name, env, monkeypatch):
-    """The LDS-resident fused matcher (pmx_match.hip, PMX_ENGINE=2) and its table builder inside the chunk pipeline
-    (PMX_TABLES=3) are held to the same fixtures as the production path."""
+def test_engine_settings_match_reference_golden(name, env, monkeypatch):
+    """The golden sets under settings that force the rarely taken paths of the engine: Gaussian terms evaluated one by
+    one instead of the tabulated pair functions (PMX_TREE_FLAGS=8), every subtree walked (4), almost every tree split
+    into queued subtrees, tables that do not fit the per-wavefront slices (arena pass), and an arena too small to hold
+    them all at once (carry pass)."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     model, lib, weights, d = load_golden(name)
