@@ -859,10 +859,15 @@ static int score_chunks(const pmx_model *const *models, int n_models, const pmx_
 // per-wave slices); ligand_kernel over the ligands whose tables need the arena; a fixed number of task rounds (each a
 // snapshot of the queue + one persistent launch that exits at once when the round is empty; the last round never
 // queues); finalize; then the same once more for ligands the arena had no room for (normally none).
+constexpr uint32_t kParamSlots = 64; // launches in flight on one stream never come near this
 struct ScreenWs {
     Ctl *ctl = nullptr;
+    ScreenParams *params = nullptr;
     uint8_t *slices = nullptr;
     size_t slices_bytes = 0;
+    uint8_t *big = nullptr;
+    size_t big_bytes = 0;
+    uint32_t epoch = 0;
     uint8_t *arena = nullptr;
     size_t arena_bytes = 0;
     uint8_t *queue = nullptr;
@@ -912,6 +917,7 @@ static int score_screen(const pmx_model *model, const pmx_library *lib, const We
         HIPCHECK(hipGetDeviceProperties(&prop, lib->device));
         ws.num_cu = prop.multiProcessorCount;
         HIPCHECK(hipMalloc((void **)&ws.ctl, sizeof(Ctl)));
+        HIPCHECK(hipMalloc((void **)&ws.params, sizeof(ScreenParams) * kParamSlots));
         for (auto &e : ws.ev) HIPCHECK(hipEventCreate(&e));
     }
     ScreenParams p;
@@ -929,21 +935,35 @@ static int score_screen(const pmx_model *model, const pmx_library *lib, const We
     const WaveShape<G> shape = wave_shape<G>(model->dm.K, (int)p.max_nodes);
     const uint32_t waves_per_cu = (uint32_t)std::max<long>(1, std::min<long>({(long)(kLdsPerCu / shape.bytes), 4L * PMX_SCREEN_WAVES, env_long("PMX_WAVES_PER_CU", 32)}));
     const uint32_t grid = (uint32_t)ws.num_cu * waves_per_cu;
-    p.slice_bytes = (uint32_t)std::max<long>(4, env_long("PMX_SLICE_KB", 48)) * 1024u;
-    rc = grow(&ws.slices, &ws.slices_bytes, (size_t)grid * p.slice_bytes, stream);
+    const uint32_t slice_bytes = (uint32_t)std::max<long>(4, env_long("PMX_SLICE_KB", 48)) * 1024u;
+    rc = grow(&ws.slices, &ws.slices_bytes, (size_t)grid * slice_bytes, stream);
     if (rc) return rc;
-    rc = grow(&ws.arena, &ws.arena_bytes, (size_t)std::max<long>(16, env_long("PMX_ARENA_MB", 2048)) << 20, stream);
+    // large slices for the ligands whose tables exceed a slice: as large as a table of this model and library can get, at most
+    // PMX_BIG_SLICE_MB each, PMX_BIG_TOTAL_MB together (what is larger still goes to the arena)
+    uint32_t big_bytes, big_grid;
+    {
+        const uint64_t nlmax = (uint64_t)std::min<int>(PMX_MAX_LEVELS, std::max(1, lib->info.max_clusters));
+        const uint64_t K = (uint64_t)std::max(1, model->dm.K);
+        const uint64_t worst = rec_bytes<G>((uint32_t)(nlmax * K), (uint32_t)(nlmax * (nlmax - 1) / 2 * K * K), (uint32_t)nlmax);
+        const uint64_t cap = (uint64_t)std::max<long>(1, env_long("PMX_BIG_SLICE_MB", 32)) << 20;
+        big_bytes = (uint32_t)std::max<uint64_t>(slice_bytes, (std::min(worst, cap) + 4095) & ~4095ull);
+        const uint64_t total = (uint64_t)std::max<long>(64, env_long("PMX_BIG_TOTAL_MB", 1024)) << 20;
+        big_grid = (uint32_t)std::max<uint64_t>(16, std::min<uint64_t>(grid, total / big_bytes));
+    }
+    rc = grow(&ws.big, &ws.big_bytes, (size_t)big_grid * big_bytes, stream);
     if (rc) return rc;
-    rc = grow(&ws.queue, &ws.queue_bytes, (size_t)std::max<long>(1, env_long("PMX_TASKQ_MB", 1024)) << 20, stream);
+    rc = grow(&ws.arena, &ws.arena_bytes, (size_t)std::max<long>(16, env_long("PMX_ARENA_MB", 6144)) << 20, stream);
     if (rc) return rc;
-    const uint32_t super = (uint32_t)std::max<long>(1024, std::min<long>(env_long("PMX_SUPER", 1 << 20), 1 << 24));
+    rc = grow(&ws.queue, &ws.queue_bytes, (size_t)std::max<long>(1, env_long("PMX_TASKQ_MB", 2048)) << 20, stream);
+    if (rc) return rc;
+    // super-chunk: the arena holds the tables of the ligands whose tree is split, until the chunk's subtrees are done
+    const uint32_t super = (uint32_t)std::max<long>(1024, std::min<long>(env_long("PMX_SUPER", (1L << 20) * 8 / std::max(G, 8)), 1 << 24));
     {
         size_t have = (size_t)ws.list_cap * 12;
         rc = grow(&ws.lists, &have, (size_t)super * 12, stream);
         if (rc) return rc;
         ws.list_cap = super;
     }
-    p.slices = ws.slices;
     p.arena = ws.arena;
     p.arena_bytes = std::min<unsigned long long>(ws.arena_bytes, (1ull << 36) - 4096);
     p.ovf_list = ws.lists;
@@ -951,39 +971,45 @@ static int score_screen(const pmx_model *model, const pmx_library *lib, const We
     p.heavy_list = ws.lists + 2 * (size_t)super;
     p.list_cap = super;
     p.queue = ws.queue;
-    p.qcap = (uint32_t)std::min<size_t>(ws.queue_bytes / task_rec_bytes<G>() / kShards, 0x7fffffffu / kShards);
+    p.qcap = (uint32_t)std::min<size_t>(ws.queue_bytes / task_rec_bytes<G>() / kShards, 0x3fffffffu / kShards);
     p.budget = (uint32_t)std::max<long>(16, env_long("PMX_BUDGET", 2048));
-    p.min_levels = (uint32_t)std::max<long>(0, env_long("PMX_MIN_LEVELS", 2));
+    p.min_levels = (uint32_t)std::max<long>(0, env_long("PMX_MIN_LEVELS", 3));
     p.max_passes = (unsigned long long)std::max<long>(1, env_long("PMX_MAXITERS", 1L << 40));
     p.scores = scores_dev;
     p.status = status_dev;
-    const int rounds = (int)std::max<long>(1, env_long("PMX_ROUNDS", 6));
+    const int rounds = (int)std::max<long>(1, env_long("PMX_ROUNDS", 8));
+    p.last_round = 0;
+    p.pad_ = 0;
     const bool exact = (p.flags & 8) != 0;
     const size_t lds = shape.bytes;
     if (g_profiling && first_model) HIPCHECK(hipEventRecord(ws.ev[0], stream));
-    auto ligands = [&](int mode) {
+    auto launch = [&](int mode, uint32_t blocks) {
         p.mode = mode;
-        if (exact) ligand_kernel<G, true><<<dim3(grid), dim3(64), lds, stream>>>(p);
-        else ligand_kernel<G, false><<<dim3(grid), dim3(64), lds, stream>>>(p);
-    };
-    auto tasks_and_finalize = [&]() {
-        for (int r = 0; r < rounds; ++r) {
-            round_kernel<<<dim3(1), dim3(64), 0, stream>>>(ws.ctl, p.qcap);
-            task_kernel<G><<<dim3(grid), dim3(64), lds, stream>>>(p, r + 1 == rounds ? 1 : 0);
-        }
-        finalize_kernel<G><<<dim3((super + 255) / 256), dim3(256), 0, stream>>>(p);
+        if (exact) ligand_kernel<G, true><<<dim3(blocks), dim3(64), lds, stream>>>(p);
+        else ligand_kernel<G, false><<<dim3(blocks), dim3(64), lds, stream>>>(p);
     };
     for (uint64_t lo = 0; lo < count; lo += super) {
         p.lo = (uint32_t)lo;
         p.hi = (uint32_t)std::min<uint64_t>(count, lo + super);
-        ctl_clear_kernel<<<dim3((sizeof(Ctl) / 4 + 255) / 256), dim3(256), 0, stream>>>(ws.ctl, (lo == 0 && first_model) ? 1 : 0, 0);
-        ligands(0);
-        ligands(1);
-        tasks_and_finalize();
-        // ligands the arena had no room for: once more with an empty arena
-        ctl_clear_kernel<<<dim3((sizeof(Ctl) / 4 + 255) / 256), dim3(256), 0, stream>>>(ws.ctl, 0, 1);
-        ligands(2);
-        tasks_and_finalize();
+        ctl_clear_kernel<<<dim3((sizeof(Ctl) / 4 + 255) / 256), dim3(256), 0, stream>>>(ws.ctl, (lo == 0 && first_model) ? 1 : 0);
+        // every ligand whose tables fit a slice
+        p.slices = ws.slices;
+        p.slice_bytes = slice_bytes;
+        launch(0, grid);
+        // the others with large slices (fewer wavefronts)
+        p.slices = ws.big;
+        p.slice_bytes = big_bytes;
+        launch(1, big_grid);
+        // and what exceeds those from the arena
+        launch(2, big_grid);
+        // the subtrees the over-budget walkers queued, and the ones those queue in turn: a fixed number of rounds, each a snapshot of
+        // the queue and one persistent launch (an empty round exits at once); the last round walks everything to its end
+        for (int r = 0; r < rounds; ++r) {
+            p.last_round = r + 1 == rounds ? 1u : 0u;
+            round_kernel<<<dim3(1), dim3(64), 0, stream>>>(ws.ctl, p.qcap);
+            task_kernel<G><<<dim3(std::min<uint32_t>(grid, (uint32_t)ws.num_cu * 4u * PMX_TASK_WAVES)), dim3(64), lds, stream>>>(p);
+        }
+        finalize_kernel<G><<<dim3((super + 255) / 256), dim3(256), 0, stream>>>(p);
     }
     HIPCHECK(hipGetLastError());
     if (g_profiling) HIPCHECK(hipEventRecord(ws.ev[1], stream));
@@ -1012,8 +1038,12 @@ static int screen_stats(pmx_score_stats *out) {
     out->n_exact_cells = st[4];
     out->max_iters_ligand = st[5];
     out->n_tasks = st[6];
-    out->n_overflow = st[7];
+    out->n_overflow = st[7] & 0xffffffffull;
+    out->n_steps_first = st[14]; // records written to the queue
     out->queue_overflow = c->qflag;
+    if (trace_on())
+        fprintf(stderr, "[pmx] wave ticks: scan %llu tables %llu bounds %llu walk %llu | alive %llu idle %llu | arena top %llu heavy %u ovf %u carry %u | probes %llu probe passes %llu exported %llu\n", st[8], st[9], st[10], st[11], st[12], st[13],
+                (unsigned long long)c->arena_top, c->heavy_count, c->ovf_count, c->carry_count, st[7] >> 32, st[15], st[14]);
     if (w->ev_valid) {
         float ms = 0.f;
         HIPCHECK(hipEventElapsedTime(&ms, w->ev[0], w->ev[1]));

@@ -27,7 +27,7 @@
 // global memory and read back by the same wavefront: they stay in the CU's L1 / the XCD's L2 and are overwritten by the
 // wave's next ligand - there is no per-chunk table arena, no size pass, no host read. Ligands whose tables exceed the
 // slice, and trees that run over their budget, move to a bump-allocated arena: over-budget walkers append the open
-// subtrees with >= 5 matches to a task queue (exactness argument: see walk()), which later launches of task_kernel drain.
+// subtrees with >= 5 matches to a task queue (exactness argument: see walk()), which launches of task_kernel drain in rounds.
 // Everything is ordered on the caller's stream.
 #include "pmx_device.h"
 
@@ -94,7 +94,7 @@ struct TaskRec { // 64 bytes, followed by double tot[G]
     uint16_t pad;
     uint64_t mask;                    // conformer mask of the root
     uint8_t path[2 * PMX_MAX_LEVELS]; // (level, candidate) of every match on the path
-    uint8_t pad2[8];
+    uint32_t pad2[2];
 };
 static_assert(sizeof(TaskRec) == 64, "TaskRec layout");
 template <int G>
@@ -107,20 +107,22 @@ constexpr int kStatWords = 16;
 constexpr int kScreenStatShards = 64;
 
 // Device-side control block of one call (zeroed by ctl_clear_kernel at the start of every super-chunk).
+// The task queue is kShards independent queues (shard s owns records [s * qcap, (s + 1) * qcap)): a device-scope atomic
+// on one address is a serial resource on this multi-XCD part, and exports come by the million.
 struct Ctl {
-    uint32_t cursor[4];   // ligand cursors of the launches of a super-chunk: [0] slice pass, [1] arena pass, [2] carry pass
+    uint32_t cursor[4];   // ligand cursors of the launches of a super-chunk: [0] slice pass, [1] large-slice pass, [2] arena pass
     uint32_t ovf_count;   // ligands whose tables do not fit a slice
-    uint32_t carry_count; // ligands whose tables did not fit the arena this time
+    uint32_t carry_count; // ligands whose tables do not fit a large slice either
     uint32_t heavy_count; // records in the arena that finalize has to score
-    uint32_t task_cursor;
+    uint32_t pad0;
     unsigned long long arena_top; // bump allocator (bytes)
     uint32_t qflag;               // a queue shard was full (the walker then keeps the subtree: exact, only slower)
-    uint32_t err;                 // iteration cap hit (cannot happen for a finite tree)
-    uint32_t qtail[kShards];
-    uint32_t round_lo[kShards], round_hi[kShards];
-    uint32_t round_total;
-    uint32_t pad[3];
-    unsigned long long stats[kScreenStatShards][kStatWords]; // sharded: [0] frames [1] passes [2] ligand waves over budget [3] items [4] exact-count cells [5] longest walk
+    uint32_t err;                 // 1: iteration cap hit (cannot happen for a finite tree), 2: a wave gave up waiting for work
+    uint32_t q_res[kShards];      // records reserved
+    uint32_t round_lo[kShards], round_hi[kShards]; // the records of the current round (round_kernel)
+    uint32_t round_total, task_cursor;
+    uint32_t pad[2];
+    unsigned long long stats[kScreenStatShards][kStatWords]; // sharded: [0] frames [1] passes [2] walks over budget [3] items [4] exact-count cells [5] longest walk [6] tasks [7] slice overflows [8..12] phase ticks
 };
 
 struct ScreenParams {
@@ -146,12 +148,16 @@ struct ScreenParams {
     uint32_t flags;            // 2: never queue, 4: no bound test, 8: exact Gaussian terms instead of the tabulated functions
     uint32_t max_nodes;        // of the library (sizes the LDS node tables)
     unsigned long long max_passes;
+    uint32_t last_round;       // task_kernel: never queue (walk every subtree to its end)
+    uint32_t pad_;
     float *scores;
     int32_t *status;
-    int mode;                  // 0: slice pass over [lo, hi); 1: arena pass over ovf_list; 2: arena pass over carry_list
+    int mode;                  // 0: slice pass over [lo, hi); 1: large-slice pass over ovf_list; 2: arena pass over carry_list
 };
 
+
 // ------------------------------------------------------------------------------------------------ helpers
+
 __device__ inline int rl(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 // lane `lane` (wave-uniform) of v := value (this clang has no v_writelane builtin; a compare + select does it)
 __device__ inline int wl(int v, int lane, int value) { return (int)(threadIdx.x & 63) == lane ? value : v; }
@@ -174,6 +180,8 @@ __device__ inline void wave_sync() { // LDS / global hand-over between the lanes
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 }
+// Hand-over through LDS only (does not wait for outstanding global stores)
+__device__ inline void lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 __device__ inline float norm3f(float dx, float dy, float dz) { // np.linalg.norm of a float32 3-vector (ligand.py:349-351)
     float s = dx * dx;
     s = s + dy * dy;
@@ -243,7 +251,7 @@ template <int G>
 struct WaveShape {
     uint32_t kp;     // candidates per level, padded
     uint32_t nc_cap; // node-candidate entries
-    uint32_t off_cand, off_lcnt, off_nc, off_tot, off_pool, bytes;
+    uint32_t off_cand, off_lcnt, off_nc, off_tot, off_pool, off_stat, off_task, bytes;
 };
 template <int G>
 __host__ __device__ inline WaveShape<G> wave_shape(int K, int max_nodes) {
@@ -263,12 +271,16 @@ __host__ __device__ inline WaveShape<G> wave_shape(int K, int max_nodes) {
     o += (PMX_MAX_LEVELS + 1) * G * 8;
     w.off_pool = o;
     o += G * 8;
+    w.off_stat = o; // the wave's statistics (kept out of the registers)
+    o += 128;
+    w.off_task = o; // subtree record of the root of the ligand in work
+    o += task_rec_bytes<G>();
     w.bytes = o;
     return w;
 }
-// fixed part (512 bytes): tm[64] | lstart[20] lend[20] lk[20] pad[4] | ksum u16[24] | ncoff u16[24] | rowbase u32[20] | cand bits u64[20]
-constexpr uint32_t kOffTm = 0, kOffStart = 64, kOffEnd = 84, kOffK = 104, kOffKsum = 128, kOffNcoff = 176, kOffRow = 224, kOffBits = 304;
-static_assert(kOffBits + 8 * PMX_MAX_LEVELS <= 512, "fixed LDS part");
+// fixed part (512 bytes): tm[64] | lstart[20] lend[20] lk[20] pad[4] | ksum u16[24] | ncoff u16[24] | rowbase u32[20] | cand bits u64[20] | ksumtot, T | path staging u16[20]
+constexpr uint32_t kOffTm = 0, kOffStart = 64, kOffEnd = 84, kOffK = 104, kOffKsum = 128, kOffNcoff = 176, kOffRow = 224, kOffBits = 304, kOffPath = 472;
+static_assert(kOffBits + 8 * PMX_MAX_LEVELS + 8 <= kOffPath && kOffPath + 2 * PMX_MAX_LEVELS <= 512, "fixed LDS part");
 
 // ------------------------------------------------------------------------------------------------- walker
 // Iterative form of ClusterMatchTree.dfs_run (tree.py:55-104) with wave-uniform control. Frame f is the tree node whose
@@ -303,6 +315,8 @@ struct Walk {
     int stA = 0, stB = 0, stC = 0; // mask lo, mask hi, nb | mx << 8 | flags << 16 | nm << 24
     double best = 0.0, flushed = 0.0;
     unsigned long long frames = 0, passes = 0;
+    uint32_t exported = 0, probes = 0;
+    unsigned long long probe_passes = 0;
     // current frame (kept here so that a walk can be interrupted and resumed, see kOverBudget)
     int f = 0, f0 = 0, nm = 0, nb = 0, mx = 0;
     unsigned flags = 0;
@@ -317,8 +331,103 @@ __host__ __device__ constexpr uint64_t group_mask() {
 constexpr unsigned kMatched = 1, kAny = 2, kSkipped = 4;
 constexpr double kBoundSlack = 1.0 + 1e-9; // covers the float64 rounding of the sums the bound is compared with
 
+// Can the child (frame f, candidate `cand`, conformer mask `cmask`) of the current frame, which holds nm matches, still
+// reach 5 matches - i.e. does the reference's tree hold a node with >= 5 matches below it? The same depth-first search on
+// validity alone (no totals), stopped at the first such node; it follows the skip rule of tree.py:98, under which a node
+// with >= 5 matches is reached whenever a valid assignment with >= 5 matches exists (see walk()). Uses the stack and path
+// lanes above the current frame, which the walker re-writes when it descends itself.
 template <int G>
-__device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *tot, unsigned long long *pool,
+__device__ __forceinline__ bool probe(Walk<G> &w, int f, int nm, int cand, uint64_t cmask, unsigned long long &passes) {
+    constexpr int SLOTS = 64 / G;
+    constexpr int PSH = G == 1 ? 2 : G == 2 ? 3 : G == 4 ? 4 : G == 8 ? 5 : G == 16 ? 6 : G == 32 ? 7 : 8;
+    constexpr uint64_t GM = group_mask<G>();
+    const int lane = lane_id();
+    const int s = lane / G, c = lane % G;
+    const uint32_t lane_off = (uint32_t)lane * 4u;
+    const int nl = w.nl;
+    const unsigned char *Pb = w.Pb;
+    if (nm + 1 >= 5) return true;
+    // enter the child
+    const int fbase = f;
+    {
+        const int kf = rl(w.hk, f);
+        w.matRB = wl(w.matRB, nm, rl(w.hrow, f) - kf * rl(w.hks, f + 1));
+        w.matKA = wl(w.matKA, nm, kf | (cand << 8) | (f << 16));
+    }
+    ++f;
+    ++nm;
+    uint64_t mask = cmask;
+    int nb = 0, mx = 0;
+    unsigned flags = kMatched;
+    for (;;) {
+        int ret;
+        if (f == nl) { // below the last level: a leaf
+            ret = (flags & kMatched) ? 1 : 0;
+        } else {
+            const int kf = rl(w.hk, f), ksf = rl(w.hks, f);
+            bool descended = false;
+            if (nb < kf) {
+                const int ebv = w.matRB + __mul24(w.matKA & 255, ksf) + __mul24((w.matKA >> 8) & 255, kf);
+                while (nb < kf) {
+                    const bool on = nb + s < kf;
+                    const uint32_t bo = on ? lane_off : (uint32_t)c * 4u;
+                    float lo = 1.f;
+                    for (int q = 0; q < nm; ++q) lo = fminf(lo, *reinterpret_cast<const float *>(Pb + (((uint32_t)(rl(ebv, q) + nb) << PSH) + bo)));
+                    const unsigned long long vb = __ballot(on && ((mask >> c) & 1ull) && lo > 0.f);
+                    ++passes;
+                    if (!vb) {
+                        nb += SLOTS;
+                        continue;
+                    }
+                    flags |= kAny;
+                    if (nm + 1 >= 5) return true; // a node with 5 matches
+                    const int ss = (__ffsll(vb) - 1) / G;
+                    const int bsel = nb + ss;
+                    nb = bsel + 1;
+                    w.stA = wl(w.stA, f, (int)(uint32_t)mask);
+                    if (G > 32) w.stB = wl(w.stB, f, (int)(uint32_t)(mask >> 32));
+                    w.stC = wl(w.stC, f, nb | (mx << 8) | ((int)flags << 16) | (nm << 24));
+                    w.matRB = wl(w.matRB, nm, rl(w.hrow, f) - kf * rl(w.hks, f + 1));
+                    w.matKA = wl(w.matKA, nm, kf | (bsel << 8) | (f << 16));
+                    mask = (vb >> (ss * G)) & GM;
+                    ++f;
+                    ++nm;
+                    flags = kMatched;
+                    nb = 0;
+                    mx = 0;
+                    descended = true;
+                    break;
+                }
+            }
+            if (descended) continue;
+            if (!(flags & kSkipped) && (!(flags & kAny) || nm + mx < 5)) { // skip child (tree.py:98-101)
+                flags |= kSkipped;
+                w.stA = wl(w.stA, f, (int)(uint32_t)mask);
+                if (G > 32) w.stB = wl(w.stB, f, (int)(uint32_t)(mask >> 32));
+                w.stC = wl(w.stC, f, nb | (mx << 8) | ((int)flags << 16) | (nm << 24));
+                ++f;
+                flags = 0;
+                nb = 0;
+                mx = 0;
+                continue;
+            }
+            ret = mx + ((flags & kMatched) ? 1 : 0);
+        }
+        --f;
+        if (f <= fbase) return false; // the child's subtree is exhausted: no node with 5 matches
+        const int sc = rl(w.stC, f);
+        mask = (uint64_t)(uint32_t)rl(w.stA, f);
+        if (G > 32) mask |= (uint64_t)(uint32_t)rl(w.stB, f) << 32;
+        nb = sc & 255;
+        mx = (sc >> 8) & 255;
+        flags = (unsigned)(sc >> 16) & 255u;
+        nm = (sc >> 24) & 255;
+        mx = mx > ret ? mx : ret;
+    }
+}
+
+template <int G>
+__device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *tot, unsigned long long *pool, uint16_t *pathbuf,
                                     uint32_t rec16 /* arena record of the job (exports refer to it) */, bool export_mode,
                                     unsigned long long budget, uint32_t wave_id) {
     constexpr int SLOTS = 64 / G;
@@ -349,6 +458,14 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
         const bool leaf_level = f == nl - 1;
         bool descended = false;
         const double tparent = tot[nm * G + c];
+        // the bound row and the pooled maxima go out with the table loads (one memory round trip per pass, not two); frames
+        // f < nl only, so row f + 1 exists
+        const bool bounded = nm >= 4 && !leaf_level && !no_bound;
+        double rbound = 0.0, pooled = 0.0;
+        if (bounded) {
+            rbound = *reinterpret_cast<const double *>(Rb + (((uint32_t)(f + 1) << (PSH + 1)) + 8u * (uint32_t)c));
+            pooled = __longlong_as_double((long long)pool[c]);
+        }
         if (nb < kf) {
             // pair-table rows of the matched ancestors against level f: lane q
             const int ebv = w.matRB + __mul24(w.matKA & 255, ksf) + __mul24((w.matKA >> 8) & 255, kf);
@@ -385,51 +502,81 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
                     continue;
                 }
                 unsigned long long ab = vb;
-                if (nm >= 4 && vb && !no_bound) { // the children hold >= 5 matches: drop those that cannot raise a maximum
-                    const double r = *reinterpret_cast<const double *>(Rb + (((uint32_t)(f + 1) << (PSH + 1)) + 8u * (uint32_t)c));
-                    const double pooled = __longlong_as_double((long long)pool[c]);
+                if (bounded && vb) { // the children hold >= 5 matches: drop those that cannot raise a maximum
                     const double bp = pooled > w.best ? pooled : w.best;
-                    ab = __ballot(valid && (t + r) * kBoundSlack > bp);
+                    ab = __ballot(valid && (t + rbound) * kBoundSlack > bp);
                 }
                 if (ab) {
-                    const int first = __ffsll(ab) - 1;
-                    const int ss = first / G;
+                    if (export_mode && nl - (f + 1) >= (int)p.min_levels) {
+                        // Over budget: hand the surviving children of this pass to the task queue - one reservation, one record
+                        // per slot. Children with >= 5 matches count as "returned >= 1" (see above). Below that the frame needs
+                        // to know whether a child reaches 5 matches (tree.py:98), which probe() answers: only the first
+                        // surviving child is handed over then, and this frame's max_num_matches is raised to 5 - nm if
+                        // the child can get there (what it returns beyond that changes no decision anywhere).
+                        const bool deep = nm >= 4;
+                        const int first_ss = (__ffsll(ab) - 1) / G;
+                        bool slot_alive = ((ab >> (s * G)) & GM) != 0;
+                        if (!deep) slot_alive = slot_alive && s == first_ss;
+                        const unsigned long long heads = __ballot(slot_alive && c == 0);
+                        const uint32_t n = (uint32_t)__popcll(heads);
+                        const uint32_t sh = (wave_id + (uint32_t)(w.passes >> 4)) & (kShards - 1);
+                        uint32_t base = 0xffffffffu;
+                        if (lane == 0) {
+                            uint32_t r = p.ctl->q_res[sh];
+                            while (r + n <= p.qcap) {
+                                const uint32_t old = atomicCAS(&p.ctl->q_res[sh], r, r + n);
+                                if (old == r) {
+                                    base = r;
+                                    break;
+                                }
+                                r = old;
+                            }
+                        }
+                        base = (uint32_t)uni((int)base);
+                        if (base != 0xffffffffu) {
+                            if (lane < nm) pathbuf[lane] = (uint16_t)(((w.matKA >> 16) & 255) | (((w.matKA >> 8) & 255) << 8));
+                            lds_sync();
+                            if (slot_alive) {
+                                const uint32_t rank = (uint32_t)__popcll(heads & ((1ull << (s * G)) - 1ull));
+                                unsigned char *tr = p.queue + ((size_t)sh * p.qcap + base + rank) * task_rec_bytes<G>();
+                                TaskRec *th = reinterpret_cast<TaskRec *>(tr);
+                                if (c == 0) {
+                                    th->rec16 = rec16;
+                                    th->f0 = (uint8_t)(f + 1);
+                                    th->nm = (uint8_t)(nm + 1);
+                                    th->pad = 0;
+                                    th->mask = (vb >> (s * G)) & GM;
+                                }
+                                const uint32_t mine = (uint32_t)f | ((uint32_t)(nb + s) << 8); // this slot's own match, entry nm
+                                for (int wd = c; wd < PMX_MAX_LEVELS / 2; wd += G) { // two path entries per 32-bit word
+                                    const int q0 = 2 * wd, q1 = 2 * wd + 1;
+                                    const uint32_t e0 = q0 < nm ? pathbuf[q0] : (q0 == nm ? mine : 0u);
+                                    const uint32_t e1 = q1 < nm ? pathbuf[q1] : (q1 == nm ? mine : 0u);
+                                    reinterpret_cast<uint32_t *>(th->path)[wd] = e0 | (e1 << 16);
+                                }
+                                reinterpret_cast<double *>(tr + sizeof(TaskRec))[c] = t;
+                            }
+                            w.exported += n;
+                            if (deep) {
+                                mx = mx > 1 ? mx : 1; // children given away (or dropped) return at least 1
+                                nb += SLOTS;
+                            } else {
+                                const bool reach = probe<G>(w, f, nm, nb + first_ss, (vb >> (first_ss * G)) & GM, w.probe_passes);
+                                ++w.probes;
+                                if (reach) mx = mx > 5 - nm ? mx : 5 - nm;
+                                nb = nb + first_ss + 1;
+                            }
+                            continue;
+                        }
+                        if (lane == 0) p.ctl->qflag = 1; // shard full: walk the subtree here
+                    }
+                    // descend into the first surviving child (tree.py:94-97)
+                    const int ss = (__ffsll(ab) - 1) / G;
                     const unsigned long long before = ss == 0 ? 0ull : (vb & ((1ull << (ss * G)) - 1ull));
                     if (before) mx = mx > 1 ? mx : 1; // existing children dropped by the bound test return at least 1
                     const int bsel = nb + ss;
                     nb = bsel + 1;
                     const uint64_t cmask = (vb >> (ss * G)) & GM;
-                    if (export_mode && nm >= 4 && nl - (f + 1) >= (int)p.min_levels) {
-                        // hand the subtree to the task queue
-                        const uint32_t sh = (wave_id + (uint32_t)(w.passes >> 6)) & (kShards - 1);
-                        uint32_t slot = 0;
-                        if (lane == 0) slot = atomicAdd(&p.ctl->qtail[sh], 1u);
-                        slot = (uint32_t)uni((int)slot);
-                        if (slot < p.qcap) {
-                            unsigned char *tr = p.queue + ((size_t)sh * p.qcap + slot) * task_rec_bytes<G>();
-                            TaskRec *th = reinterpret_cast<TaskRec *>(tr);
-                            if (lane == 0) {
-                                th->rec16 = rec16;
-                                th->f0 = (uint8_t)(f + 1);
-                                th->nm = (uint8_t)(nm + 1);
-                                th->pad = 0;
-                                th->mask = cmask;
-                            }
-                            if (lane < nm) {
-                                th->path[2 * lane] = (uint8_t)(w.matKA >> 16);
-                                th->path[2 * lane + 1] = (uint8_t)(w.matKA >> 8);
-                            }
-                            if (lane == nm) {
-                                th->path[2 * lane] = (uint8_t)f;
-                                th->path[2 * lane + 1] = (uint8_t)bsel;
-                            }
-                            if (s == ss) reinterpret_cast<double *>(tr + sizeof(TaskRec))[c] = t;
-                            mx = mx > 1 ? mx : 1; // the child given away returns at least 1
-                            continue;
-                        }
-                        if (lane == 0) p.ctl->qflag = 1; // shard full: walk it here
-                    }
-                    // descend (tree.py:94-97)
                     if (s == ss) tot[(nm + 1) * G + c] = t;
                     w.stA = wl(w.stA, f, (int)(uint32_t)mask);
                     if (G > 32) w.stB = wl(w.stB, f, (int)(uint32_t)(mask >> 32));
@@ -451,7 +598,7 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
                 nb += SLOTS;
             }
             if (descended) {
-                wave_sync(); // the child's total is read by all slots
+                lds_sync(); // the child's total is read by all slots
                 continue;
             }
         }
@@ -557,6 +704,50 @@ __device__ __forceinline__ void item(const ScreenParams &p, uint32_t sidu, uint3
     fails += 2 * np < mn ? 1 : 0;
 }
 
+// The same item in two steps, so that the loads of several items are in flight together: address + loads, then value + test.
+struct ItemLoad {
+    float4 a, b;
+    float t, d;
+    uint32_t sidu, sidv;
+};
+__device__ __forceinline__ ItemLoad item_load(const ScreenParams &p, uint32_t sidu, uint32_t sidv, float d) {
+    ItemLoad L;
+    const float x = d * p.F.inv_h; // exact: inv_h is a power of two
+    const int ci = min((int)x, (int)p.F.ncell - 1);
+    L.t = fminf(x - (float)ci, 1.0f);
+    L.d = d;
+    L.sidu = sidu, L.sidv = sidv;
+    const float4 *cell = reinterpret_cast<const float4 *>(p.F.cells + ((sidu * p.F.NS + sidv) * p.F.ncell + (uint32_t)ci));
+    L.a = cell[0];
+    L.b = cell[1];
+    return L;
+}
+__device__ __forceinline__ void item_finish(const ScreenParams &p, const ItemLoad &L, float &acc, int &fails, uint32_t &n_exact) {
+    const float t = L.t;
+    float v = __builtin_fmaf(t, L.b.y, L.b.x);
+    v = __builtin_fmaf(t, v, L.a.w);
+    v = __builtin_fmaf(t, v, L.a.z);
+    v = __builtin_fmaf(t, v, L.a.y);
+    v = __builtin_fmaf(t, v, L.a.x);
+    acc = acc + v;
+    if (__builtin_expect(L.b.z != L.b.z, 0)) { // the pass set is not one interval inside this cell: count the terms
+        const uint64_t A = p.subnodes[L.sidu], B = p.subnodes[L.sidv];
+        int np = 0;
+        for (uint64_t am = A; am; am &= am - 1)
+            for (uint64_t bm = B; bm; bm &= bm - 1) {
+                const float4 e = p.M.edge[(__ffsll((unsigned long long)am) - 1) * p.M.Nm + (__ffsll((unsigned long long)bm) - 1)];
+                np += fabsf(L.d - e.x) <= e.z ? 1 : 0;
+            }
+        fails += 2 * np < __popcll(A) * __popcll(B) ? 1 : 0;
+        ++n_exact;
+    } else {
+        fails += (L.d >= L.b.z && L.d <= L.b.w) ? 0 : 1;
+    }
+}
+
+#ifndef PMX_ITEM_BATCH
+#define PMX_ITEM_BATCH 2 // items whose loads are in flight together (4 costs 30 spilled registers at 80)
+#endif
 struct LevelInfo {
     int nl;
     uint32_t ksumtot, T;
@@ -736,14 +927,37 @@ __device__ __forceinline__ void build_tables(const ScreenParams &p, unsigned cha
                 int fails = 0;
                 if (nbal) {
                     const int rowa = nci + sa * ni, rowb = ncj + sb * nj;
-                    for (int u = 0; u < ni; ++u) {
-                        const uint32_t ou = (uint32_t)((si + u) * 3 * C + cc);
-                        const float ux = xyz[ou], uy = xyz[ou + C], uz = xyz[ou + 2 * C];
-                        const uint32_t sidu = nc[rowa + u];
-                        for (int v = 0; v < nj; ++v) {
-                            const uint32_t ov = (uint32_t)((sj + v) * 3 * C + cc);
-                            const float d = norm3f(ux - xyz[ov], uy - xyz[ov + C], uz - xyz[ov + 2 * C]);
-                            item<EXACT>(p, sidu, nc[rowb + v], d, acc, fails, n_exact);
+                    if (EXACT) {
+                        for (int u = 0; u < ni; ++u) {
+                            const uint32_t ou = (uint32_t)((si + u) * 3 * C + cc);
+                            const float ux = xyz[ou], uy = xyz[ou + C], uz = xyz[ou + 2 * C];
+                            const uint32_t sidu = nc[rowa + u];
+                            for (int v = 0; v < nj; ++v) {
+                                const uint32_t ov = (uint32_t)((sj + v) * 3 * C + cc);
+                                const float d = norm3f(ux - xyz[ov], uy - xyz[ov + C], uz - xyz[ov + 2 * C]);
+                                item<EXACT>(p, sidu, nc[rowb + v], d, acc, fails, n_exact);
+                            }
+                        }
+                    } else {
+                        // the node pairs (u, v) in the reference's order (u outer), four at a time: coordinates, distances and cell loads
+                        // of the four go out together, then the four values are added in order (items past the end are
+                        // the empty subset pair: value 0, never a fail)
+                        constexpr int IB = PMX_ITEM_BATCH;
+                        const int npair = ni * nj;
+                        int uu = 0, vv = 0;
+                        for (int t0 = 0; t0 < npair; t0 += IB) {
+                            ItemLoad L[IB];
+#pragma unroll
+                            for (int q = 0; q < IB; ++q) {
+                                const bool in = t0 + q < npair;
+                                const int u1 = in ? uu : 0, v1 = in ? vv : 0;
+                                const uint32_t ou = (uint32_t)((si + u1) * 3 * C + cc), ov = (uint32_t)((sj + v1) * 3 * C + cc);
+                                const float d = norm3f(xyz[ou] - xyz[ov], xyz[ou + C] - xyz[ov + C], xyz[ou + 2 * C] - xyz[ov + 2 * C]);
+                                L[q] = item_load(p, in ? (uint32_t)nc[rowa + u1] : 0u, in ? (uint32_t)nc[rowb + v1] : 0u, d);
+                                if (++vv == nj) vv = 0, ++uu;
+                            }
+#pragma unroll
+                            for (int q = 0; q < IB; ++q) item_finish(p, L[q], acc, fails, n_exact);
                         }
                     }
                     n_items += (uint32_t)(ni * nj);
@@ -809,21 +1023,10 @@ __device__ __forceinline__ void build_bounds(const ScreenParams &p, unsigned cha
 }
 
 // ------------------------------------------------------------------------------------------ kernels
-__device__ inline void flush_stats(Ctl *ctl, uint32_t wave_id, unsigned long long frames, unsigned long long passes, unsigned long long over,
-                                   unsigned long long items, unsigned long long exact, unsigned long long longest) {
-    unsigned long long *st = ctl->stats[wave_id & (kScreenStatShards - 1)];
-    atomicAdd(st + 0, frames);
-    atomicAdd(st + 1, passes);
-    atomicAdd(st + 2, over);
-    atomicAdd(st + 3, items);
-    atomicAdd(st + 4, exact);
-    atomicMax(st + 5, longest);
-}
-
-// Bump allocation in the arena by lane 0; returns the byte offset or ~0ull.
+// Bump allocation in the arena by lane 0; returns the byte offset (never 0: offset 0 means "not in the arena") or ~0ull.
 __device__ inline unsigned long long arena_alloc(const ScreenParams &p, uint32_t bytes) {
     unsigned long long off = 0;
-    if ((threadIdx.x & 63) == 0) off = atomicAdd(&p.ctl->arena_top, (unsigned long long)((bytes + 255u) & ~255u));
+    if ((threadIdx.x & 63) == 0) off = atomicAdd(&p.ctl->arena_top, (unsigned long long)((bytes + 255u) & ~255u)) + 256ull;
     off = uni64(off);
     return off + bytes <= p.arena_bytes ? off : ~0ull;
 }
@@ -832,20 +1035,22 @@ __device__ inline unsigned long long arena_alloc(const ScreenParams &p, uint32_t
 #define PMX_SCREEN_WAVES 6 // waves per SIMD the register budget is set for (<= 80 VGPRs: nothing spilled to memory)
 #endif
 
-struct WaveStats {
-    unsigned long long frames = 0, passes = 0, over = 0, items = 0, exact = 0, longest = 0;
+struct WaveStats { // lives in LDS, updated by lane 0
+    unsigned long long frames, passes, over, items, exact, longest, tasks, overflow;
+    unsigned long long cyc_scan, cyc_tables, cyc_bounds, cyc_walk, cyc_busy, cyc_idle, pad[2]; // s_memtime ticks per phase
 };
+static_assert(sizeof(WaveStats) == 128, "WaveStats layout");
 
-// One ligand, from its record to its score. The lane id is taken afresh (lane_id() is opaque to the optimiser): address
-// arithmetic of this body that only depends on the lane would otherwise be hoisted out of the persistent loop and spilled.
+// A job of a wavefront is a subtree record: one taken from the queue (the ligand's tables are in the arena), or the root of
+// a ligand whose tables this wave has just built (record in the wave's LDS, tables in its slice or in the arena).
+
+// Ligand -> job: levels, tables, bounds, and the root's subtree record in LDS. Returns the ligand's record (slice or arena), or
+// nullptr when the ligand is finished without a tree search (unsupported record, no candidates, tables too large for this pass).
 template <int G, bool EXACT>
-__device__ __forceinline__ void score_ligand(const ScreenParams &p, unsigned char *lds, const uint32_t li, const uint32_t wave_id, WaveStats &stat) {
+__device__ __forceinline__ unsigned char *prepare_ligand(const ScreenParams &p, unsigned char *lds, const WaveShape<G> &ws, const uint32_t li, const uint32_t wave_id,
+                                                         WaveStats *stat) {
     const int lane = lane_id();
-    const int s = lane / G, c = lane % G;
-    const WaveShape<G> ws = wave_shape<G>(p.M.K, (int)p.max_nodes);
-    double *tot = reinterpret_cast<double *>(lds + ws.off_tot);
-    unsigned long long *pool = reinterpret_cast<unsigned long long *>(lds + ws.off_pool);
-    unsigned char *slice = p.slices + (size_t)wave_id * p.slice_bytes;
+    const int c = lane % G;
     Record r = parse_record(uniptr(p.lib.data + p.lib.offsets[p.first + li]));
     r.n = uni(r.n), r.C = uni(r.C), r.ncl = uni(r.ncl); // the record is the same for the whole wave: say so
     r.typemask = uniptr(r.typemask), r.cluster_end = uniptr(r.cluster_end), r.xyz = uniptr(r.xyz);
@@ -855,172 +1060,281 @@ __device__ __forceinline__ void score_ligand(const ScreenParams &p, unsigned cha
                 p.scores[li] = __builtin_nanf("");
                 if (p.status) p.status[li] = PMX_LIGAND_UNSUPPORTED;
             }
-            return;
+            return nullptr;
         }
         if (lane == 0 && p.status) p.status[li] = PMX_LIGAND_OK;
     }
+    const unsigned long long t_a = __builtin_amdgcn_s_memtime();
     const LevelInfo L = scan_ligand<G>(p, lds, ws, r);
     if (L.nl == 0) { // no ligand cluster has a candidate (graph_match.py:95-99)
         if (lane == 0) p.scores[li] = 0.f;
-        return;
+        return nullptr;
     }
     const uint64_t bytes64 = rec_bytes<G>(L.ksumtot, L.T, (uint32_t)L.nl);
-    unsigned char *rec = slice;
+    unsigned char *rec = p.slices + (size_t)wave_id * p.slice_bytes;
     uint32_t rec16 = 0;
-    bool in_arena = false;
-    if (p.mode == 0) {
-        if (bytes64 > p.slice_bytes) { // tables do not fit the slice: the arena pass takes this ligand
+    if (p.mode != 2) {
+        if (bytes64 > p.slice_bytes) { // tables do not fit the slice: a later pass with larger slices (or the arena) takes this ligand
             if (lane == 0) {
-                const uint32_t o = atomicAdd(&p.ctl->ovf_count, 1u);
-                if (o < p.list_cap) p.ovf_list[o] = li;
-                atomicAdd(&p.ctl->stats[wave_id & (kScreenStatShards - 1)][7], 1ull);
+                if (p.mode == 0) {
+                    const uint32_t o = atomicAdd(&p.ctl->ovf_count, 1u);
+                    if (o < p.list_cap) p.ovf_list[o] = li;
+                    atomicAdd(&p.ctl->stats[wave_id & (kScreenStatShards - 1)][7], 1ull);
+                } else {
+                    const uint32_t o = atomicAdd(&p.ctl->carry_count, 1u);
+                    if (o < p.list_cap) p.carry_list[o] = li;
+                }
             }
-            return;
+            return nullptr;
         }
     } else {
         const unsigned long long off = bytes64 < (1ull << 31) ? arena_alloc(p, (uint32_t)bytes64) : ~0ull;
-        if (off == ~0ull) {
+        if (off == ~0ull) { // no room in the arena
             if (lane == 0) {
-                if (p.mode == 1) {
-                    const uint32_t o = atomicAdd(&p.ctl->carry_count, 1u);
-                    if (o < p.list_cap) p.carry_list[o] = li;
-                } else { // larger than the whole arena
-                    p.scores[li] = __builtin_nanf("");
-                    if (p.status) p.status[li] = PMX_LIGAND_TOO_LARGE;
-                }
+                p.scores[li] = __builtin_nanf("");
+                if (p.status) p.status[li] = PMX_LIGAND_TOO_LARGE;
             }
-            return;
+            return nullptr;
         }
         rec = p.arena + off;
         rec16 = (uint32_t)(off >> 4);
-        in_arena = true;
     }
     // ---- header
     RecHeader *H = reinterpret_cast<RecHeader *>(rec);
-    {
-        const uint8_t *lk = lds + kOffK;
-        const uint16_t *ksum = reinterpret_cast<const uint16_t *>(lds + kOffKsum);
-        const uint32_t *rowbase = reinterpret_cast<const uint32_t *>(lds + kOffRow);
-        if (lane == 0) {
-            H->lig = li;
-            H->nl = (uint32_t)L.nl;
-            H->T = L.T;
-            H->ksumtot = L.ksumtot;
-            H->bytes = (uint32_t)bytes64;
-            H->C = (uint32_t)r.C;
-        }
-        if (lane < L.nl) {
-            H->k[lane] = lk[lane];
-            H->rowbase[lane] = rowbase[lane];
-        }
-        if (lane <= L.nl) H->ksum[lane] = ksum[lane];
-        if (lane < G) reinterpret_cast<unsigned long long *>(rec + sizeof(RecHeader))[lane] = 0ull;
+    const uint8_t *lk = lds + kOffK;
+    const uint16_t *ksum = reinterpret_cast<const uint16_t *>(lds + kOffKsum);
+    const uint32_t *rowbase = reinterpret_cast<const uint32_t *>(lds + kOffRow);
+    if (lane == 0) {
+        H->lig = li;
+        H->nl = (uint32_t)L.nl;
+        H->T = L.T;
+        H->ksumtot = L.ksumtot;
+        H->bytes = (uint32_t)bytes64;
+        H->C = (uint32_t)r.C;
+        H->pad[0] = 0; // not (yet) registered for finalize_kernel
     }
+    if (lane < L.nl) {
+        H->k[lane] = lk[lane];
+        H->rowbase[lane] = rowbase[lane];
+    }
+    if (lane <= L.nl) H->ksum[lane] = ksum[lane];
+    if (lane < G) reinterpret_cast<unsigned long long *>(rec + sizeof(RecHeader))[lane] = 0ull;
     uint32_t n_items = 0, n_exact = 0;
-#ifndef XNO_TABLES
+    const unsigned long long t_b = __builtin_amdgcn_s_memtime();
     build_tables<G, EXACT>(p, lds, ws, r, L, rec, n_items, n_exact);
-#endif
     wave_sync();
-#ifndef XNO_BOUNDS
+    const unsigned long long t_c = __builtin_amdgcn_s_memtime();
     build_bounds<G>(p, lds, L, rec);
-#endif
-    // ---- tree search
-    Walk<G> w;
-    w.Sb = rec + rec_s_off<G>();
-    w.Pb = rec + rec_p_off<G>(L.ksumtot);
-    w.Rb = rec + rec_r_off<G>(L.ksumtot, L.T);
-    w.nl = L.nl;
+    // ---- the root as a subtree record (in LDS): frame 0, no matches, every conformer, totals 0
     {
-        const uint8_t *lk = lds + kOffK;
-        const uint16_t *ksum = reinterpret_cast<const uint16_t *>(lds + kOffKsum);
-        const uint32_t *rowbase = reinterpret_cast<const uint32_t *>(lds + kOffRow);
-        w.hk = lane < L.nl ? (int)lk[lane] : 0;
-        w.hks = lane <= L.nl ? (int)ksum[lane] : 0;
-        w.hrow = lane < L.nl ? (int)rowbase[lane] : 0;
+        unsigned char *tr = lds + ws.off_task;
+        TaskRec *th = reinterpret_cast<TaskRec *>(tr);
+        if (lane == 0) {
+            th->rec16 = rec16;
+            th->f0 = 0;
+            th->nm = 0;
+            th->pad = 0;
+            th->mask = (r.C >= 64) ? ~0ull : ((1ull << r.C) - 1ull);
+        }
+        if (lane < G) reinterpret_cast<double *>(tr + sizeof(TaskRec))[c] = 0.0;
     }
-    if (s == 0) {
-        tot[c] = 0.0;
-        pool[c] = 0ull;
-    }
-    w.f = w.f0 = 0;
-    w.nm = 0;
-    w.mask = (r.C >= 64) ? ~0ull : ((1ull << r.C) - 1ull);
-    w.flags = 0;
     wave_sync();
-    // The walk is interrupted once, when it runs over its budget: the tables then move to the arena (queued subtrees refer
-    // to them) and the walk resumes handing subtrees with >= 5 matches to the task queue.
-    unsigned long long budget = (p.flags & 2) ? ~0ull : (unsigned long long)p.budget;
-    bool heavy = false, export_mode = false;
+    const unsigned long long t_d = __builtin_amdgcn_s_memtime();
+    if (lane == 0) {
+        stat->cyc_scan += t_b - t_a, stat->cyc_tables += t_c - t_b, stat->cyc_bounds += t_d - t_c;
+        stat->items += n_items;
+    }
+    if (n_exact) atomicAdd(&stat->exact, (unsigned long long)n_exact);
+    return rec;
+}
+
+// Subtree record -> walker state. Returns false when the subtree can no longer raise any maximum (the maxima may have grown
+// since it was queued) and is dropped unwalked.
+template <int G>
+__device__ __forceinline__ bool prepare_walk(const ScreenParams &p, unsigned char *lds, const WaveShape<G> &ws, const unsigned char *tr, unsigned char *rec, Walk<G> &w) {
+    const int lane = lane_id();
+    const int s = lane / G, c = lane % G;
+    double *tot = reinterpret_cast<double *>(lds + ws.off_tot);
+    unsigned long long *pool = reinterpret_cast<unsigned long long *>(lds + ws.off_pool);
+    const TaskRec *th = reinterpret_cast<const TaskRec *>(tr);
+    const RecHeader *H = reinterpret_cast<const RecHeader *>(rec);
+    const int nl = uni((int)H->nl);
+    const uint32_t ksumtot = (uint32_t)uni((int)H->ksumtot), T = (uint32_t)uni((int)H->T);
+    w.Sb = rec + rec_s_off<G>();
+    w.Pb = rec + rec_p_off<G>(ksumtot);
+    w.Rb = rec + rec_r_off<G>(ksumtot, T);
+    w.nl = nl;
+    w.hk = lane < nl ? (int)H->k[lane] : 0;
+    w.hks = lane <= nl ? (int)H->ksum[lane] : 0;
+    w.hrow = lane < nl ? (int)H->rowbase[lane] : 0;
+    const int nm0 = uni((int)th->nm), f0 = uni((int)th->f0);
+    if (lane < nm0) {
+        const int j = th->path[2 * lane], a = th->path[2 * lane + 1];
+        const int kj = H->k[j];
+        w.matRB = (int)H->rowbase[j] - kj * (int)H->ksum[j + 1];
+        w.matKA = kj | (a << 8) | (j << 16);
+    }
+    const unsigned long long *gbest = reinterpret_cast<const unsigned long long *>(rec + sizeof(RecHeader));
+    if (s == 0) {
+        tot[nm0 * G + c] = reinterpret_cast<const double *>(tr + sizeof(TaskRec))[c];
+        pool[c] = __hip_atomic_load(&gbest[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // maxima of the ligand's finished walkers
+    }
+    w.f = w.f0 = f0;
+    w.nm = nm0;
+    w.mask = uni64(th->mask);
+    w.flags = nm0 ? kMatched : 0u;
+    wave_sync();
+    if (!(p.flags & 4) && f0 < nl && nm0 >= 5) {
+        const double r = *reinterpret_cast<const double *>(w.Rb + ((size_t)f0 * G + c) * 8);
+        const double t = tot[nm0 * G + c];
+        return __ballot(((w.mask >> c) & 1ull) && (t + r) * kBoundSlack > __longlong_as_double((long long)pool[c])) != 0;
+    }
+    return true;
+}
+
+// The tree search of a prepared job and what follows it: the maxima go to the score (a ligand walked by this wave alone) or to
+// the ligand's record in the arena (a split ligand; finalize_kernel takes the mean). The walk is interrupted once, when it
+// runs over its budget: a ligand's tables then move to the arena (queued subtrees refer to them) and the walk resumes handing
+// subtrees with >= 5 matches to the queue.
+template <int G>
+__device__ __forceinline__ void run_job(const ScreenParams &p, unsigned char *lds, const WaveShape<G> &ws, Walk<G> &w, unsigned char *rec, uint32_t rec16,
+                                        const bool is_task, const uint32_t wave_id, WaveStats *stat) {
+    const int lane = lane_id();
+    const int s = lane / G, c = lane % G;
+    double *tot = reinterpret_cast<double *>(lds + ws.off_tot);
+    unsigned long long *pool = reinterpret_cast<unsigned long long *>(lds + ws.off_pool);
+    uint16_t *pathbuf = reinterpret_cast<uint16_t *>(lds + kOffPath);
+    const unsigned long long t_d = __builtin_amdgcn_s_memtime();
+    unsigned long long budget = ((p.flags & 2) || p.last_round) ? ~0ull : (unsigned long long)p.budget;
+    bool export_mode = false, split = is_task;
     for (;;) {
-        const int rc = walk<G>(w, p, tot, pool, rec16, export_mode, budget, wave_id);
+        const int rc = walk<G>(w, p, tot, pool, pathbuf, rec16, export_mode, budget, wave_id);
         if (rc != kOverBudget) break;
-        ++stat.over;
+        if (lane == 0) ++stat->over;
         budget = ~0ull;
-        if (!in_arena) {
-            const unsigned long long off = arena_alloc(p, (uint32_t)bytes64);
+        RecHeader *H = reinterpret_cast<RecHeader *>(rec);
+        if (rec16 == 0) { // tables in the wave's slice: move them to the arena
+            const uint32_t bytes = (uint32_t)uni((int)H->bytes);
+            const unsigned long long off = arena_alloc(p, bytes);
             if (off != ~0ull) {
                 const uint4 *src = reinterpret_cast<const uint4 *>(rec);
                 uint4 *dst = reinterpret_cast<uint4 *>(p.arena + off);
-                const uint32_t n16 = ((uint32_t)bytes64 + 15u) / 16u;
+                const uint32_t n16 = (bytes + 15u) / 16u;
                 for (uint32_t i = lane; i < n16; i += 64) dst[i] = src[i];
                 rec16 = (uint32_t)(off >> 4);
-                in_arena = true;
+                rec = p.arena + off;
+                // (the walker keeps reading the slice copy through w.Sb / Pb / Rb: same bytes)
             }
         }
-        if (in_arena) { // (arena full otherwise: the wave walks the tree alone - exact, only slower)
-            heavy = export_mode = true;
-            if (lane == 0) {
-                const uint32_t o = atomicAdd(&p.ctl->heavy_count, 1u);
-                if (o < p.list_cap) p.heavy_list[o] = rec16;
+        if (rec16 != 0) { // (arena full otherwise: the wave walks the tree alone - exact, only slower)
+            export_mode = true;
+            H = reinterpret_cast<RecHeader *>(rec);
+            if (!is_task && !split) { // first time: finalize_kernel has to score this ligand
+                if (lane == 0) {
+                    const uint32_t o = atomicAdd(&p.ctl->heavy_count, 1u);
+                    if (o < p.list_cap) p.heavy_list[o] = rec16;
+                }
             }
-            __threadfence(); // the arena copy is read by later kernels
+            split = true; // (the arena copy is read by later kernels: nothing to fence)
         }
     }
-    stat.frames += w.frames;
-    stat.passes += w.passes;
-    stat.items += n_items;
-    stat.exact += n_exact;
-    stat.longest = w.passes > stat.longest ? w.passes : stat.longest;
+    if (lane == 0) {
+        stat->cyc_walk += __builtin_amdgcn_s_memtime() - t_d;
+        stat->frames += w.frames;
+        stat->passes += w.passes;
+        stat->longest = w.passes > stat->longest ? w.passes : stat->longest;
+        stat->overflow += w.exported; // (records written to the queue)
+        stat->pad[0] += w.probe_passes;
+        stat->pad[1] += w.probes;
+        stat->passes += w.probe_passes;
+    }
     // ---- per-conformer maxima over the slots -> score
     if (w.best > 0.0) atomicMax(&pool[c], (unsigned long long)__double_as_longlong(w.best));
     wave_sync();
-    const double bc = __longlong_as_double((long long)pool[c]);
-    if (heavy) { // split ligand: the task waves add their maxima, finalize_kernel takes the mean
-        if (s == 0 && bc > 0.0) atomicMax(reinterpret_cast<unsigned long long *>(p.arena + (size_t)rec16 * 16 + sizeof(RecHeader)) + c,
-                                          (unsigned long long)__double_as_longlong(bc));
+    const unsigned long long bbits = pool[c];
+    const RecHeader *H = reinterpret_cast<const RecHeader *>(rec);
+    if (split) { // every walker of a split ligand adds its maxima, finalize_kernel takes the mean
+        unsigned long long *gbest = reinterpret_cast<unsigned long long *>(rec + sizeof(RecHeader));
+        if (s == 0 && bbits != 0ull) atomicMax(gbest + c, bbits);
     } else { // mean over conformers (graph_match.py:109); lanes beyond C hold 0
-        double sum = (s == 0 && c < r.C) ? bc : 0.0;
+        const int C = uni((int)H->C);
+        double sum = (s == 0 && c < C) ? __longlong_as_double((long long)bbits) : 0.0;
 #pragma unroll
         for (int d = 1; d < G; d <<= 1) sum += __shfl_xor(sum, d);
-        if (lane == 0) p.scores[li] = (float)(sum / (double)r.C);
+        if (lane == 0) p.scores[uni((int)H->lig)] = (float)(sum / (double)C);
     }
+    wave_sync();
 }
 
-// Persistent wavefronts (one per block): fetch a ligand, build its tables in the wave's slice (mode 0) or in the arena
-// (modes 1 / 2: ligands whose tables do not fit a slice), walk its tree, write its score.
+
+__device__ inline void flush_wave_stats(const ScreenParams &p, const WaveStats *stat, uint32_t wave_id, unsigned long long alive) {
+    unsigned long long *st = p.ctl->stats[wave_id & (kScreenStatShards - 1)];
+    atomicAdd(st + 0, stat->frames);
+    atomicAdd(st + 1, stat->passes);
+    atomicAdd(st + 2, stat->over);
+    atomicAdd(st + 3, stat->items);
+    atomicAdd(st + 4, stat->exact);
+    atomicMax(st + 5, stat->longest);
+    atomicAdd(st + 6, stat->tasks);
+    atomicAdd(st + 14, stat->overflow);
+    atomicAdd(st + 15, stat->pad[0]);
+    atomicAdd(st + 7, stat->pad[1] << 32);
+    atomicAdd(st + 8, stat->cyc_scan);
+    atomicAdd(st + 9, stat->cyc_tables);
+    atomicAdd(st + 10, stat->cyc_bounds);
+    atomicAdd(st + 11, stat->cyc_walk);
+    atomicAdd(st + 12, alive);
+    atomicAdd(st + 13, stat->cyc_idle);
+}
+
+// Persistent wavefronts (one per block) over the ligands of a pass: build a ligand's tables in the wave's slice (modes 0 / 1)
+// or in the arena (mode 2), walk its tree, write its score. A tree that runs over its budget hands its open subtrees to the
+// task queue, which task_kernel drains afterwards. (One kernel for ligands and queued subtrees together was built: the two
+// bodies in one loop cost 80-300 spilled registers, inside the walker's pass loop; apart they need none.)
 template <int G, bool EXACT>
 __global__ __launch_bounds__(64, PMX_SCREEN_WAVES) void ligand_kernel(const ScreenParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    const int lane = lane_id();
+    const int lane0 = lane_id();
     const uint32_t wave_id = blockIdx.x;
+    const WaveShape<G> ws = wave_shape<G>(p.M.K, (int)p.max_nodes);
     const uint32_t todo = p.mode == 0 ? p.hi - p.lo : (p.mode == 1 ? min(p.ctl->ovf_count, p.list_cap) : min(p.ctl->carry_count, p.list_cap));
     const uint32_t *list = p.mode == 1 ? p.ovf_list : p.carry_list;
-    WaveStats stat;
+    constexpr uint32_t kBatch = 4; // ligands claimed per atomic on the cursor
+    WaveStats *stat = reinterpret_cast<WaveStats *>(lds + ws.off_stat);
+    if (lane0 < 16) reinterpret_cast<unsigned long long *>(stat)[lane0] = 0ull;
+    wave_sync();
+    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+    uint32_t lig_next = 0, lig_end = 0;
     for (;;) {
-        uint32_t next = 0;
-        if (lane == 0) next = atomicAdd(&p.ctl->cursor[p.mode], 1u);
-        next = (uint32_t)uni((int)next);
-        if (next >= todo) break;
+        const int lane = lane_id();
+        if (lig_next == lig_end) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&p.ctl->cursor[p.mode], kBatch);
+            base = (uint32_t)uni((int)base);
+            lig_next = min(base, todo);
+            lig_end = min(base + kBatch, todo);
+            if (lig_next == lig_end) break;
+        }
+        const uint32_t next = lig_next++;
         const uint32_t li = p.mode == 0 ? p.lo + next : (uint32_t)uni((int)list[next]);
-        score_ligand<G, EXACT>(p, lds, li, wave_id, stat);
+        unsigned char *rec = prepare_ligand<G, EXACT>(p, lds, ws, li, wave_id, stat);
+        if (!rec) continue;
+        const unsigned char *root = lds + ws.off_task;
+        const uint32_t rec16 = (uint32_t)uni((int)reinterpret_cast<const TaskRec *>(root)->rec16);
+        Walk<G> w;
+        if (prepare_walk<G>(p, lds, ws, root, rec, w)) run_job<G>(p, lds, ws, w, rec, rec16, false, wave_id, stat);
     }
-    if (lane == 0) flush_stats(p.ctl, wave_id, stat.frames, stat.passes, stat.over, stat.items, stat.exact, stat.longest);
+    wave_sync();
+    if (lane0 == 0) flush_wave_stats(p, stat, wave_id, __builtin_amdgcn_s_memtime() - t_start);
 }
 
-// Snapshot of the task queue between rounds: the records appended since the last round are this round's tasks.
+// Snapshot of the task queue between rounds: the records reserved since the last round are this round's subtrees. (Rounds are
+// separate launches on purpose: what one wave queues has to be visible to waves on other XCDs, whose L2 is not coherent
+// with the writer's inside a kernel - a queue drained by the kernel that fills it needs an L2 write-back per hand-over,
+// measured at 15x the walk time.)
 __global__ void round_kernel(Ctl *ctl, uint32_t qcap) {
-    const int lane = lane_id();
-    const uint32_t lo = ctl->round_hi[lane], hi = min(ctl->qtail[lane], qcap);
+    const int lane = threadIdx.x & 63;
+    const uint32_t lo = ctl->round_hi[lane], hi = min(ctl->q_res[lane], qcap);
     uint32_t n = hi - lo;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) n += __shfl_xor(n, d);
@@ -1029,92 +1343,52 @@ __global__ void round_kernel(Ctl *ctl, uint32_t qcap) {
     if (lane == 0) {
         ctl->round_total = n;
         ctl->task_cursor = 0;
-        ctl->stats[0][6] += n; // tasks of the call (this kernel is alone on the stream)
+        ctl->stats[0][6] += n; // subtrees of the call (this kernel is alone on the stream)
     }
 }
 
-// Persistent wavefronts over the round's subtrees.
+// Persistent wavefronts over the round's subtrees; a subtree that runs over its budget queues its own open subtrees for the
+// next round (the last round's budget is unlimited).
+#ifndef PMX_TASK_WAVES
+#define PMX_TASK_WAVES 6
+#endif
 template <int G>
-__global__ __launch_bounds__(64, PMX_SCREEN_WAVES) void task_kernel(const ScreenParams p, int last_round) {
+__global__ __launch_bounds__(64, PMX_TASK_WAVES) void task_kernel(const ScreenParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    const int lane = lane_id();
-    const int s = lane / G, c = lane % G;
+    const int lane0 = lane_id();
     const uint32_t wave_id = blockIdx.x;
-    const WaveShape<G> ws = wave_shape<G>(p.M.K, (int)p.max_nodes);
-    double *tot = reinterpret_cast<double *>(lds + ws.off_tot);
-    unsigned long long *pool = reinterpret_cast<unsigned long long *>(lds + ws.off_pool);
     const uint32_t total = p.ctl->round_total;
-    // block nx -> (shard, record): inclusive scan of the shards' record counts over the lanes
-    const uint32_t lo_l = p.ctl->round_lo[lane], cnt_l = p.ctl->round_hi[lane] - lo_l;
+    if (total == 0) return;
+    const WaveShape<G> ws = wave_shape<G>(p.M.K, (int)p.max_nodes);
+    WaveStats *stat = reinterpret_cast<WaveStats *>(lds + ws.off_stat);
+    if (lane0 < 16) reinterpret_cast<unsigned long long *>(stat)[lane0] = 0ull;
+    wave_sync();
+    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+    // task number -> (shard, record): inclusive scan of the shards' record counts over the lanes
+    const uint32_t lo_l = p.ctl->round_lo[lane0], cnt_l = p.ctl->round_hi[lane0] - lo_l;
     uint32_t inc = cnt_l;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         const uint32_t t = __shfl_up(inc, d);
-        if (lane >= d) inc += t;
+        if (lane0 >= d) inc += t;
     }
-    unsigned long long st_frames = 0, st_passes = 0, st_longest = 0;
     for (;;) {
+        const int lane = lane_id();
         uint32_t nx = 0;
         if (lane == 0) nx = atomicAdd(&p.ctl->task_cursor, 1u);
         nx = (uint32_t)uni((int)nx);
         if (nx >= total) break;
         const int sh = __popcll(__ballot(nx >= inc)); // shards wholly before task nx (inc is non-decreasing)
-        const uint32_t before = sh ? (uint32_t)__shfl(inc, sh - 1) : 0u;
-        const uint32_t recno = (uint32_t)__shfl(lo_l, sh) + (nx - before);
-        const unsigned char *tr = uniptr(p.queue + ((size_t)sh * p.qcap + recno) * task_rec_bytes<G>());
-        const TaskRec *th = reinterpret_cast<const TaskRec *>(tr);
-        const uint32_t rec16 = (uint32_t)uni((int)th->rec16);
-        const unsigned char *rec = p.arena + (size_t)rec16 * 16;
-        const RecHeader *H = reinterpret_cast<const RecHeader *>(rec);
-        const int nl = uni((int)H->nl);
-        const uint32_t ksumtot = (uint32_t)uni((int)H->ksumtot), T = (uint32_t)uni((int)H->T);
+        const uint32_t before = sh ? (uint32_t)rl((int)inc, sh - 1) : 0u;
+        const uint32_t recno = (uint32_t)rl((int)lo_l, sh) + (nx - before);
+        const unsigned char *tr = p.queue + ((size_t)sh * p.qcap + recno) * task_rec_bytes<G>();
+        if (lane == 0) ++stat->tasks;
+        unsigned char *rec = p.arena + (size_t)(uint32_t)uni((int)reinterpret_cast<const TaskRec *>(tr)->rec16) * 16;
         Walk<G> w;
-        w.Sb = rec + rec_s_off<G>();
-        w.Pb = rec + rec_p_off<G>(ksumtot);
-        w.Rb = rec + rec_r_off<G>(ksumtot, T);
-        w.nl = nl;
-        w.hk = lane < nl ? (int)H->k[lane] : 0;
-        w.hks = lane <= nl ? (int)H->ksum[lane] : 0;
-        w.hrow = lane < nl ? (int)H->rowbase[lane] : 0;
-        const int nm0 = uni((int)th->nm), f0 = uni((int)th->f0);
-        if (lane < nm0) {
-            const int j = th->path[2 * lane], a = th->path[2 * lane + 1];
-            const int kj = H->k[j];
-            w.matRB = (int)H->rowbase[j] - kj * (int)H->ksum[j + 1];
-            w.matKA = kj | (a << 8) | (j << 16);
-        }
-        const unsigned long long *gbest = reinterpret_cast<const unsigned long long *>(rec + sizeof(RecHeader));
-        if (s == 0) {
-            tot[nm0 * G + c] = reinterpret_cast<const double *>(tr + sizeof(TaskRec))[c];
-            pool[c] = gbest[c]; // maxima of the ligand's finished walkers
-        }
-        w.f = w.f0 = f0;
-        w.nm = nm0;
-        w.mask = uni64(th->mask);
-        w.flags = kMatched;
-        wave_sync();
-        // a subtree that can no longer raise any maximum (the maxima may have grown since it was queued) is not walked
-        bool go = true;
-        if (!(p.flags & 4) && f0 < nl) {
-            const double r = *reinterpret_cast<const double *>(w.Rb + ((size_t)f0 * G + c) * 8);
-            const double t = tot[nm0 * G + c];
-            go = __ballot(((w.mask >> c) & 1ull) && (t + r) * kBoundSlack > __longlong_as_double((long long)pool[c])) != 0;
-        }
-        if (go) {
-            const unsigned long long budget = (last_round || (p.flags & 2)) ? ~0ull : (unsigned long long)p.budget;
-            bool export_mode = false;
-            while (walk<G>(w, p, tot, pool, rec16, export_mode, export_mode ? ~0ull : budget, wave_id) == kOverBudget) export_mode = true;
-            if (w.best > 0.0) atomicMax(&pool[c], (unsigned long long)__double_as_longlong(w.best));
-            wave_sync();
-            const unsigned long long bc = pool[c];
-            if (s == 0 && bc > gbest[c]) atomicMax(reinterpret_cast<unsigned long long *>(p.arena + (size_t)rec16 * 16 + sizeof(RecHeader)) + c, bc);
-        }
-        st_frames += w.frames;
-        st_passes += w.passes;
-        st_longest = w.passes > st_longest ? w.passes : st_longest;
-        wave_sync();
+        if (prepare_walk<G>(p, lds, ws, tr, rec, w)) run_job<G>(p, lds, ws, w, rec, (uint32_t)((rec - p.arena) >> 4), true, wave_id, stat);
     }
-    if (lane == 0) flush_stats(p.ctl, wave_id, st_frames, st_passes, 0, 0, 0, st_longest);
+    wave_sync();
+    if (lane0 == 0) flush_wave_stats(p, stat, wave_id, __builtin_amdgcn_s_memtime() - t_start);
 }
 
 // Scores of the ligands whose tree was split: mean over conformers of the combined maxima (graph_match.py:109).
@@ -1132,12 +1406,11 @@ __global__ void finalize_kernel(const ScreenParams p) {
 }
 
 // Start of a super-chunk: cursors, lists, arena and queue are empty again (the statistics survive unless asked).
-__global__ void ctl_clear_kernel(Ctl *ctl, int clear_stats, int keep_carry) {
+__global__ void ctl_clear_kernel(Ctl *ctl, int clear_stats) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t head_words = offsetof(Ctl, stats) / 4, all_words = sizeof(Ctl) / 4;
     uint32_t *w = reinterpret_cast<uint32_t *>(ctl);
     if (i < head_words) {
-        if (i == offsetof(Ctl, carry_count) / 4 && keep_carry) return;
         if (i != offsetof(Ctl, err) / 4 && i != offsetof(Ctl, qflag) / 4) w[i] = 0;
         else if (clear_stats) w[i] = 0;
     } else if (i < all_words && clear_stats) {
