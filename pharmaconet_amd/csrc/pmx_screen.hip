@@ -251,7 +251,7 @@ template <int G>
 struct WaveShape {
     uint32_t kp;     // candidates per level, padded
     uint32_t nc_cap; // node-candidate entries
-    uint32_t off_cand, off_lcnt, off_nc, off_tot, off_pool, off_stat, off_task, bytes;
+    uint32_t off_cand, off_lcnt, off_nc, off_tot, off_pool, off_stat, off_task, off_tch, bytes;
 };
 template <int G>
 __host__ __device__ inline WaveShape<G> wave_shape(int K, int max_nodes) {
@@ -275,6 +275,9 @@ __host__ __device__ inline WaveShape<G> wave_shape(int K, int max_nodes) {
     o += 128;
     w.off_task = o; // subtree record of the root of the ligand in work
     o += task_rec_bytes<G>();
+    o = (o + 15u) & ~15u;
+    w.off_tch = o; // totals of a frame's children (fused last two levels)
+    o += 64 * 8;
     w.bytes = o;
     return w;
 }
@@ -314,9 +317,9 @@ struct Walk {
     // stack: lane f holds frame f
     int stA = 0, stB = 0, stC = 0; // mask lo, mask hi, nb | mx << 8 | flags << 16 | nm << 24
     double best = 0.0, flushed = 0.0;
-    unsigned long long frames = 0, passes = 0;
+    uint32_t frames = 0, passes = 0;
     uint32_t exported = 0, probes = 0;
-    unsigned long long probe_passes = 0;
+    uint32_t probe_passes = 0;
     // current frame (kept here so that a walk can be interrupted and resumed, see kOverBudget)
     int f = 0, f0 = 0, nm = 0, nb = 0, mx = 0;
     unsigned flags = 0;
@@ -337,7 +340,7 @@ constexpr double kBoundSlack = 1.0 + 1e-9; // covers the float64 rounding of the
 // with >= 5 matches is reached whenever a valid assignment with >= 5 matches exists (see walk()). Uses the stack and path
 // lanes above the current frame, which the walker re-writes when it descends itself.
 template <int G>
-__device__ __forceinline__ bool probe(Walk<G> &w, int f, int nm, int cand, uint64_t cmask, unsigned long long &passes) {
+__device__ __forceinline__ bool probe(Walk<G> &w, int f, int nm, int cand, uint64_t cmask, uint32_t &passes) {
     constexpr int SLOTS = 64 / G;
     constexpr int PSH = G == 1 ? 2 : G == 2 ? 3 : G == 4 ? 4 : G == 8 ? 5 : G == 16 ? 6 : G == 32 ? 7 : 8;
     constexpr uint64_t GM = group_mask<G>();
@@ -427,7 +430,7 @@ __device__ __forceinline__ bool probe(Walk<G> &w, int f, int nm, int cand, uint6
 }
 
 template <int G>
-__device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *tot, unsigned long long *pool, uint16_t *pathbuf,
+__device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *tot, unsigned long long *pool, uint16_t *pathbuf, double *tch,
                                     uint32_t rec16 /* arena record of the job (exports refer to it) */, bool export_mode,
                                     unsigned long long budget, uint32_t wave_id) {
     constexpr int SLOTS = 64 / G;
@@ -440,23 +443,20 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
     const unsigned char *Sb = w.Sb, *Pb = w.Pb, *Rb = w.Rb;
     const bool no_bound = (p.flags & 4) != 0;
 
+    const uint32_t budget32 = budget > 0xfffffff0ull ? 0xffffffffu : (uint32_t)budget; // (a walk of 2^32 passes does not end in this life)
     const int f0 = w.f0;
     int f = w.f, nm = w.nm, nb = w.nb, mx = w.mx;
     unsigned flags = w.flags;
     uint64_t mask = w.mask;
     int ret = 0;
     for (;;) {
-        if (!export_mode && w.passes > budget) { // over budget: the caller moves the job's tables to the arena and resumes in export mode
+        if (!export_mode && w.passes > budget32) { // over budget: the caller moves the job's tables to the arena and resumes in export mode
             w.f = f, w.nm = nm, w.nb = nb, w.mx = mx, w.flags = flags, w.mask = mask;
             return kOverBudget;
         }
-        if (w.passes > p.max_passes) { // cannot happen for a finite tree; report instead of spinning
-            if (lane == 0) p.ctl->err = 1;
-            break;
-        }
         const int kf = rl(w.hk, f), ksf = rl(w.hks, f);
         const bool leaf_level = f == nl - 1;
-        bool descended = false;
+        bool descended = false, fused_any = false;
         const double tparent = tot[nm * G + c];
         // the bound row and the pooled maxima go out with the table loads (one memory round trip per pass, not two); frames
         // f < nl only, so row f + 1 exists
@@ -474,7 +474,7 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
                 const bool on = b < kf;
                 const uint32_t bo = on ? lane_off : (uint32_t)c * 4u; // idle slots read candidate nb (in bounds)
                 const float self = *reinterpret_cast<const float *>(Sb + (((uint32_t)(ksf + nb) << PSH) + bo));
-                bool valid = on && ((mask >> c) & 1ull);
+                float lo = 1.f; // smallest pair entry: the candidate is valid for this conformer iff every entry is > 0 (tree.py:81)
                 double sum = 0.0;
                 int q = 0;
                 for (; q + 4 <= nm; q += 4) {
@@ -483,15 +483,16 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
                     for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float *>(Pb + (((uint32_t)(rl(ebv, q + u) + nb) << PSH) + bo));
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        valid = valid && v[u] > 0.f;
+                        lo = fminf(lo, v[u]);
                         sum += (double)v[u];
                     }
                 }
                 for (; q < nm; ++q) {
                     const float v = *reinterpret_cast<const float *>(Pb + (((uint32_t)(rl(ebv, q) + nb) << PSH) + bo));
-                    valid = valid && v > 0.f;
+                    lo = fminf(lo, v);
                     sum += (double)v;
                 }
+                const bool valid = on && ((mask >> c) & 1ull) && lo > 0.f;
                 const double t = (tparent + (double)self) + sum; // parent + self + accumulated pair (tree.py:38-41)
                 const unsigned long long vb = __ballot(valid);
                 ++w.passes;
@@ -505,6 +506,52 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
                 if (bounded && vb) { // the children hold >= 5 matches: drop those that cannot raise a maximum
                     const double bp = pooled > w.best ? pooled : w.best;
                     ab = __ballot(valid && (t + rbound) * kBoundSlack > bp);
+                }
+                if (f == nl - 2 && rl(w.hk, f + 1) <= SLOTS && !(p.flags & 32)) {
+                    // The children of this frame are frames of the last level, whose children are leaves: finish all of them here.
+                    // Lane (s', c) takes leaf candidate s' of level f + 1; what a leaf's total and validity owe to the path above
+                    // this frame is computed once, then every surviving child b of this pass adds its own pair entry:
+                    //   total(b, b') = (total(b) + S[f + 1][b']) + (sum_q P[q -> (f + 1, b')] + P[(f, b) -> (f + 1, b')])   (tree.py:38-41)
+                    // in the reference's order (the child is the deepest ancestor, so its entry comes last).
+                    if (ab) {
+                        const int f1 = f + 1, k1 = rl(w.hk, f1), ks1 = rl(w.hks, f1);
+                        tch[lane] = t; // the children's totals, read back per child by every slot
+                        const int ebv1 = w.matRB + __mul24(w.matKA & 255, ks1) + __mul24((w.matKA >> 8) & 255, k1);
+                        const bool on1 = s < k1;
+                        const uint32_t bo1 = on1 ? lane_off : (uint32_t)c * 4u;
+                        const float self1 = *reinterpret_cast<const float *>(Sb + (((uint32_t)ks1 << PSH) + bo1));
+                        bool base_valid = on1;
+                        double base_sum = 0.0;
+                        for (int q = 0; q < nm; ++q) {
+                            const float v = *reinterpret_cast<const float *>(Pb + (((uint32_t)rl(ebv1, q)) << PSH) + bo1);
+                            base_valid = base_valid && v > 0.f;
+                            base_sum += (double)v;
+                        }
+                        // entry((f, b) -> (f + 1, b')) = rowbase[f] + b * k1 + b'
+                        const uint32_t row_f = (uint32_t)rl(w.hrow, f);
+                        lds_sync();
+                        unsigned long long left = ab;
+                        while (left) {
+                            const int sb = (__ffsll(left) - 1) / G;
+                            left &= ~(GM << (sb * G));
+                            const uint64_t cm = (vb >> (sb * G)) & GM;
+                            const double tb = tch[sb * G + c];
+                            const float pfb = *reinterpret_cast<const float *>(Pb + ((row_f + (uint32_t)(nb + sb) * (uint32_t)k1) << PSH) + bo1);
+                            const bool v1 = base_valid && pfb > 0.f && ((cm >> c) & 1ull);
+                            const double t1 = (tb + (double)self1) + (base_sum + (double)pfb);
+                            const bool any1 = __ballot(v1) != 0;
+                            if (v1 && t1 > w.best) w.best = t1;                                             // leaves (graph_match.py:105-108)
+                            if ((!any1 || nm < 3) && ((cm >> c) & 1ull) && tb > w.best) w.best = tb;        // the child's skip leaf (tree.py:98-101)
+                            const int r1 = 1 + (any1 ? 1 : 0);
+                            mx = mx > r1 ? mx : r1;
+                            ++w.frames;
+                        }
+                        w.passes += 1;
+                    }
+                    if (vb) mx = mx > 1 ? mx : 1; // (children dropped by the bound test return at least 1)
+                    nb += SLOTS;
+                    fused_any = true;
+                    continue;
                 }
                 if (ab) {
                     if (export_mode && nl - (f + 1) >= (int)p.min_levels) {
@@ -608,6 +655,8 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
             if (!(flags & kAny) || nm + mx < 5) { // skip leaf (tree.py:98-101, :42-43): this node's totals
                 if (((mask >> c) & 1ull) && tparent > w.best) w.best = tparent;
             }
+        }
+        if (leaf_level || fused_any) {
             // publish improved maxima to the other slots (the bound test reads them)
             const bool up = w.best > w.flushed;
             if (__ballot(up)) {
@@ -616,7 +665,8 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
                     w.flushed = w.best;
                 }
             }
-        } else if (!(flags & kSkipped) && (!(flags & kAny) || nm + mx < 5)) { // skip child (tree.py:98-101)
+        }
+        if (!leaf_level && !(flags & kSkipped) && (!(flags & kAny) || nm + mx < 5)) { // skip child (tree.py:98-101)
             flags |= kSkipped;
             w.stA = wl(w.stA, f, (int)(uint32_t)mask);
             if (G > 32) w.stB = wl(w.stB, f, (int)(uint32_t)(mask >> 32));
@@ -1204,11 +1254,12 @@ __device__ __forceinline__ void run_job(const ScreenParams &p, unsigned char *ld
     double *tot = reinterpret_cast<double *>(lds + ws.off_tot);
     unsigned long long *pool = reinterpret_cast<unsigned long long *>(lds + ws.off_pool);
     uint16_t *pathbuf = reinterpret_cast<uint16_t *>(lds + kOffPath);
+    double *tch = reinterpret_cast<double *>(lds + ws.off_tch);
     const unsigned long long t_d = __builtin_amdgcn_s_memtime();
     unsigned long long budget = ((p.flags & 2) || p.last_round) ? ~0ull : (unsigned long long)p.budget;
     bool export_mode = false, split = is_task;
     for (;;) {
-        const int rc = walk<G>(w, p, tot, pool, pathbuf, rec16, export_mode, budget, wave_id);
+        const int rc = walk<G>(w, p, tot, pool, pathbuf, tch, rec16, export_mode, budget, wave_id);
         if (rc != kOverBudget) break;
         if (lane == 0) ++stat->over;
         budget = ~0ull;
