@@ -3,11 +3,11 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One *step* = one pass of the hot path (`PharmacophoreModel.screen`: sizes -> pair-score tables ->
-tree search -> scores, then top-k) over this rank's resident library. Workload at N = 1 is
-BASELINE.json configs[1]: the 6OIM-like pharmacophore model against 1M synthetic ligands
-(<= 32 pharmacophore points, 8 conformers each). For N > 1 every rank holds its own 1M-ligand shard of
-the synthetic library (weak scaling) and each step ends with the all-gather of per-rank top-k over RCCL.
+One *step* = one pass of the hot path (`PharmacophoreModel.screen`: score tables -> tree search -> scores,
+then top-k) over this rank's resident library. Workload at N = 1 is BASELINE.json configs[1]: the 6OIM-like
+pharmacophore model against 1M synthetic ligands (<= 32 pharmacophore points, 8 conformers each). For N > 1
+every rank holds its own 12.5M-ligand shard of the synthetic library (configs[2]: 100M ligands on 8 GPUs, weak
+scaling) and each step ends with the all-gather of per-rank top-k over RCCL.
 
 Rank 0 prints ONE JSON line. `value` is measured with the library already resident in HBM.
 `roofline.achieved` prices the dominant kernel (the one with the largest HIP-event time per chunk) at the
@@ -31,13 +31,6 @@ REPO = Path(__file__).resolve().parent
 sys.path.insert(0, str(REPO))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s HBM3E spec
-# Plain (unpacked) fp32 VALU lane-operations per second: 256 CU x 4 SIMD-32 x 2.4 GHz (MI355X_MICROARCH.md: a wave64
-# instruction issues over 2 cycles; 157.3 TFLOP/s fp32 vector = 2 flops x this). tools/calib/valu_calib.hip measures
-# 6.84e13 with independent v_fma_f32 chains (87 %), v_pk_fma_f32 at half that instruction rate (no gain), and
-# v_exp_f32 at 3.6 plain slots: profiles/r2_valu_calibration.json. A Gaussian term (sub, mul, mul, exp, fma, cmp, addc)
-# is therefore priced at 6 + 3.6 ~ 10 slots.
-VALU_LANE_OPS = 256 * 4 * 32 * 2.4e9
-SLOTS_PER_TERM = 10.0
 
 
 def log(*a):
@@ -153,18 +146,20 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--ligands", type=int, default=1_000_000, help="ligands per GPU")
+    ap.add_argument("--ligands", type=int, default=0, help="ligands per GPU (default: 1M on one GPU = BASELINE configs[1]; 12.5M per GPU on several = configs[2])")
     ap.add_argument("--conformers", type=int, default=8)
     ap.add_argument("--topologies", type=int, default=4096, help="distinct synthetic molecules per GPU")
     ap.add_argument("--topk", type=int, default=1000)
     ap.add_argument("--pockets", type=int, default=1, help="score this many distinct pockets (1..16) against the shared library (BASELINE configs[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-serial-leg", action="store_true", help="skip the extra untimed pass that measures every kernel alone (profiling runs)")
+    ap.add_argument("--no-serial-leg", action="store_true", help="skip the end-to-end (pack + copy) side measurement")
     args = ap.parse_args()
 
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
+    if args.ligands <= 0:
+        args.ligands = 1_000_000 if int(os.environ.get("WORLD_SIZE", "1")) == 1 else 12_500_000
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
@@ -205,13 +200,12 @@ def main():
         for pocket in pockets:  # pocket-outer / ligand-inner: the library stays resident, every pocket makes one pass
             res = engine.screen(pocket, lib, topk=args.topk, index_base=index_base)
             if world > 1:
-                if exchange is not None:  # RCCL all-gather + merge on the device through libpmx's C ABI
-                    top_s, top_i = exchange.allgather(res.topk_scores, res.topk_indices, args.topk)
-                    top = (top_s.cpu().numpy(), top_i.cpu().numpy())
+                if exchange is not None:  # RCCL all-gather + merge on the device through libpmx's C ABI; the ranking stays on the device
+                    top = exchange.allgather(res.topk_scores, res.topk_indices, args.topk)
                 else:
                     top = allgather_topk(res.topk_scores.cpu(), res.topk_indices.cpu(), args.topk)
             else:
-                top = merge_topk(res.topk_scores.cpu().numpy(), res.topk_indices.cpu().numpy(), args.topk)
+                top = (res.topk_scores, res.topk_indices)
         return res, top
 
     def barrier():
@@ -221,54 +215,25 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    engine.set_profiling(True)  # HIP events around each kernel launch of the timed steps
-    ms_tree = ms_tables = ms_sizes = ms_tasks = 0.0
-    n_tasks = n_steps = n_iters = 0
-    launches = 0
-    table_bytes = 0
+    # the timed steps run the product as a user runs it: profiling off, nothing read back but the final ranking
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res, top = step()
-        st = engine.last_score_stats()
-        ms_tree += st["ms_tree"]
-        ms_tables += st["ms_tables"]
-        ms_sizes += st["ms_sizes"]
-        ms_tasks += st["ms_tasks"]
-        n_tasks += st["n_tasks"]
-        n_steps += st["n_steps"]
-        n_iters += st["n_iters"]
-        launches += st["n_chunks"]
-        table_bytes += st["table_bytes"]
-        log(f"[rank {rank}] step stats: {st}")
     barrier()
     elapsed = time.perf_counter() - t0
-    # One extra, untimed pass with the chunk pipelines serialised (one pipeline, table and tree phases on one stream): the
-    # duration of every kernel when it has the GPU to itself, quoted beside the co-running figures of the timed steps.
-    serial = None
-    if rank == 0 and world == 1 and not args.no_serial_leg and os.environ.get("PMX_ENGINE", "1") == "1":
-        saved = {k: os.environ.get(k) for k in ("PMX_PIPELINES", "PMX_OVERLAP")}
-        os.environ["PMX_PIPELINES"], os.environ["PMX_OVERLAP"] = "1", "0"
+    # One more, untimed pass with HIP events around the phases (pmx_set_profiling: event records only) and the device
+    # counters read back: the kernel durations behind the roofline block.
+    prof = None
+    if rank == 0:
+        engine.set_profiling(True)
         try:
             engine.screen(pockets[0], lib, topk=args.topk, index_base=index_base)
             torch.cuda.synchronize()
-            st1 = engine.last_score_stats()
-            nch = max(st1["n_chunks"], 1)
-            serial = {
-                "ligands_per_launch": n_lig / nch,
-                "sizes+scan": st1["ms_sizes"] / nch,
-                "tables_kernel_v2 + bounds_kernel": st1["ms_tables"] / nch,
-                "tree_kernel<G,false>": st1["ms_tree"] / nch,
-                "tree_kernel<G,true> (all rounds of a chunk)": st1["ms_tasks"] / nch,
-                "pass_ms": st1["ms_total"],
-            }
+            prof = engine.last_score_stats()
+            log(f"[rank 0] profiled pass: {prof}")
         finally:
-            for k, v in saved.items():
-                if v is None:
-                    os.environ.pop(k, None)
-                else:
-                    os.environ[k] = v
-    engine.set_profiling(False)
+            engine.set_profiling(False)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
     if world > 1:
@@ -280,23 +245,21 @@ def main():
         value = world * n_conf_total * len(pockets) * args.steps / elapsed
         # algorithmic bytes: records + 8 B offset in, 4 B score + 4 B status out, per ligand
         alg_bytes_per_ligand = lib.num_bytes / n_lig + 8 + 4 + 4
-        ligands_per_launch = n_lig * args.steps / max(launches, 1)
-        per_chunk = {
-            "tables_kernel_v2 (+ bounds_kernel; side stream, co-runs with the previous chunk's tree kernels)": ms_tables / max(launches, 1),
-            "tree_kernel<G,false> (one wavefront per ligand)": ms_tree / max(launches, 1),
-            "tree_kernel<G,true> (queued subtrees, all rounds of a chunk)": ms_tasks / max(launches, 1),
+        kernels = {
+            "ligand_kernel (score tables in per-wavefront slices + tree search within the pass budget; 3 launches: slices, large slices, arena)": prof["ms_ligand"],
+            "task_kernel (queued subtrees of over-budget trees; all rounds) + finalize": prof["ms_tasks"],
         }
-        dominant = max(per_chunk, key=per_chunk.get)
-        dom_ms = per_chunk[dominant]
+        dominant = max(kernels, key=kernels.get)
+        dom_ms = kernels[dominant]
+        ligands_per_launch = prof["ligands_last"]
         achieved = (alg_bytes_per_ligand * ligands_per_launch) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        # HBM traffic of the dominant kernel per launch, from the committed PMC passes (FETCH_SIZE / WRITE_SIZE,
-        # collected separately with rocprofv3 --pmc and corrected as MI355X_MICROARCH.md prescribes)
+        # HBM traffic per launch from the committed PMC passes (FETCH_SIZE / WRITE_SIZE, collected separately with
+        # rocprofv3 --pmc and corrected as MI355X_MICROARCH.md prescribes), scaled to this launch's ligands
         traffic = None
         try:
-            pmc = json.loads((REPO / "profiles" / "r2_hbm_traffic.json").read_text())
-            key = {"tables_kernel_v2": "pmx::tables_kernel_v2<8, false>", "tree_kernel<G,false>": "pmx::tree_kernel<8, false>",
-                   "tree_kernel<G,true>": "pmx::tree_kernel<8, true>"}[dominant.split(" ")[0]]
-            if args.conformers == 8:
+            pmc = json.loads((REPO / "profiles" / "r3_hbm_traffic.json").read_text())
+            key = "ligand_kernel" if dominant.startswith("ligand_kernel") else "task_kernel"
+            if args.conformers == 8 and len(pockets) == 1:
                 traffic = pmc["kernels"][key]["hbm_bytes_per_ligand"] * ligands_per_launch
         except Exception:
             traffic = None
@@ -332,45 +295,36 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "traffic_note": "HBM bytes per launch of that kernel from profiles/r2_hbm_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, read side doubled per MI355X_MICROARCH.md); null if unavailable",
+                "traffic_note": "HBM bytes per launch of that kernel from profiles/r3_hbm_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, read side doubled per MI355X_MICROARCH.md); null if unavailable",
                 "algorithmic_bytes_per_ligand": alg_bytes_per_ligand,
                 "ligands_per_launch": ligands_per_launch,
-                "kernel_ms_per_launch": {"sizes+scan": ms_sizes / max(launches, 1), **per_chunk},
-                "kernel_ms_per_launch_serialised": serial,
-                "tree_steps_per_ligand": n_steps / max(n_lig * args.steps, 1),
-                "busy_conformer_groups_per_wave": n_steps / max(n_iters, 1),
-                "subtree_tasks_per_ligand": n_tasks / max(n_lig * args.steps, 1),
-                "intermediate_table_bytes_per_ligand": table_bytes / max(n_lig * args.steps, 1),
-                "note": "kernel_ms_per_launch: HIP-event times on the stream each kernel runs on, inside the timed steps, where three "
-                        "chunk pipelines co-run (so they add up to more than ms_per_step / chunks); kernel_ms_per_launch_serialised: one "
-                        "extra untimed pass with PMX_PIPELINES=1 PMX_OVERLAP=0, every kernel alone on the GPU. The path is not "
-                        "HBM-bound: see roofline_valu and DESIGN.md section 4.",
+                "kernel_ms_per_launch": kernels,
+                "profiled_pass_ms": prof["ms_total"],
+                "note": "HIP-event times of one extra, untimed pass with pmx_set_profiling(1) (event records on the call's stream, no synchronisation); "
+                        "the timed steps run with profiling off. The path is not HBM-bound (SURVEY.md section 0, DESIGN.md section 4): what binds is "
+                        "instruction issue, see `issue`.",
+            },
+            # what the kernels do per ligand, and how that compares with the CU's issue rate (one VALU and one SALU wave-instruction
+            # per cycle and CU: MI355X_MICROARCH.md); instruction counts from profiles/r3_pmc_sq.json
+            "work": {
+                "tree_frames_per_ligand": prof["n_frames"] / max(n_lig, 1),
+                "walker_passes_per_ligand": prof["n_passes"] / max(n_lig, 1),
+                "table_items_per_ligand_conformer": prof["n_items"] * (64 // 8 if args.conformers == 8 else 1) / max(n_lig, 1),
+                "queued_subtrees_per_ligand": prof["n_tasks"] / max(n_lig, 1),
+                "walks_over_budget_per_ligand": prof["n_heavy"] / max(n_lig, 1),
+                "ligands_with_tables_beyond_a_slice": prof["n_slice_overflow"],
+                "longest_walk_passes": prof["max_passes"],
+                "wave_time_share": {k: prof["ticks_" + k] / max(prof["ticks_alive"], 1) for k in ("scan", "tables", "bounds", "walk")},
             },
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], work = cpu_baseline(model, offsets, data, args.conformers)
-            # The bound that matters for the table kernel: Gaussian terms per second (terms as the reference evaluates
-            # them, counted by the oracle on the same ligands) against the VALU issue rate at SLOTS_PER_TERM slots per term.
+            # Gaussian terms as the reference evaluates them (counted by the oracle on the same ligands) per second: the
+            # table phase replaces each group of |A||B| terms by one tabulated pair function, so this is an equivalent rate
             terms_per_conf = work["gaussian_terms_per_ligand_conformer"]
-            terms_per_s = terms_per_conf * value
-            peak_terms = VALU_LANE_OPS / SLOTS_PER_TERM
-            alone = None
-            if serial and serial["tables_kernel_v2 + bounds_kernel"] > 0:
-                alone = terms_per_conf * args.conformers * serial["ligands_per_launch"] / (serial["tables_kernel_v2 + bounds_kernel"] * 1e-3)
-            out["roofline_valu"] = {
-                "bound": "valu",
-                "kernel": "tables_kernel_v2",
-                "achieved": terms_per_s / 1e12,
-                "peak": peak_terms / 1e12,
-                "unit": "T Gaussian terms/s",
-                "frac": terms_per_s / peak_terms,
-                "table_kernel_alone": {"achieved": alone / 1e12, "frac": alone / peak_terms} if alone else None,
-                "valu_lane_ops_per_s": VALU_LANE_OPS,
-                "slots_per_term": SLOTS_PER_TERM,
-                **work,
-                "note": "frac = whole-pass rate (every kernel's time counted) / peak; table_kernel_alone = terms of one launch / its "
-                        "serialised duration. Peak and slots per term: profiles/r2_valu_calibration.json (tools/calib/valu_calib.hip).",
-            }
+            out["work"].update(work)
+            out["work"]["reference_equivalent_gaussian_terms_per_s"] = terms_per_conf * value
+            out["work"]["reference_terms_per_table_item"] = terms_per_conf / max(out["work"]["table_items_per_ligand_conformer"], 1e-9)
         else:
             out["cpu_baseline"] = None
         if world == 1 and not args.no_serial_leg:

@@ -9,9 +9,9 @@
  * Conventions: every function returns 0 on success and a non-zero pmx_status otherwise;
  * pmx_last_error() gives the calling thread's last message. No exceptions cross the boundary.
  * Handles are opaque; a handle is bound to the device it was created on. Every entry point may be called from
- * any thread. pmx_score / pmx_score_multi of the default engine share per-device workspaces and are serialised by
- * one process-wide lock (a second caller waits; each call already fills the GPU with its own concurrent pipelines);
- * creating, uploading, ranking, packing and the communicator calls do not take that lock. `stream` is a hipStream_t
+ * any thread. pmx_score / pmx_score_multi keep their work buffers per (device, stream): calls on different streams run
+ * concurrently, calls on the same stream are ordered by it (a second host thread enqueuing on the same stream waits for
+ * the first to finish enqueuing, not for the GPU). `stream` is a hipStream_t
  * passed as void* (NULL = the default stream). Pointers named *_dev are device pointers on that device.
  */
 #ifndef PMX_H
@@ -107,14 +107,15 @@ int pmx_library_destroy(pmx_library *lib);
  * (graph_match.py:32-40,81-83) in type-id order. scores_dev[count] receives the float32 value
  * of the float the reference returns (0 for ligands without clusters or candidates,
  * graph_match.py:95-99); status_dev[count] (may be NULL) receives PMX_LIGAND_*.
- * The range is cut into PMX_PIPELINES (default 3) parts scored concurrently by internal host threads and streams;
- * the results are ordered on `stream`. The call itself blocks on small device-to-host reads (one per chunk and task round).
+ * Everything is enqueued on `stream` and the call returns: no device-to-host read, no synchronisation, no helper thread
+ * (a synchronisation happens only when a cached work buffer has to grow). Per super-chunk of ligands (PMX_SUPER): the
+ * ligand kernel (score tables in per-wavefront slices + tree search within a pass budget), the same for ligands with
+ * larger tables, a fixed number of task rounds for the subtrees of over-budget trees, finalize.
  */
 int pmx_score(const pmx_model *model, const pmx_library *lib, const float weights[PMX_NUM_TYPES], uint64_t first,
               uint64_t count, float *scores_dev, int32_t *status_dev, void *stream);
 
-/* The same for several models over one library: one pocket after the other through one chunk pipeline (the table
- * kernels of the next pocket's first chunk overlap the tree kernels of the previous pocket's last);
+/* The same for several models over one library, one pocket after the other on `stream`;
  * scores_dev is [n_models][count], status_dev[count] is written once. */
 int pmx_score_multi(const pmx_model *const *models, int n_models, const pmx_library *lib,
                     const float weights[PMX_NUM_TYPES], uint64_t first, uint64_t count, float *scores_dev,
@@ -182,26 +183,29 @@ int pmx_pack_features(const pmx_feature_batch *batch, int threads, uint64_t *off
 /* Frees the scoring workspaces libpmx keeps between calls on `device` (synchronises the device first). */
 int pmx_release_workspaces(int device);
 
-/* Timing / diagnostics of the last pmx_score on this thread: kernel-time split measured with HIP events. */
+/* Diagnostics of the last pmx_score / pmx_score_multi on this thread. pmx_score_stats_get synchronises the stream the
+ * call ran on (the counters live on the device); the times are HIP-event times and are filled when profiling was on
+ * (pmx_set_profiling(1): three event records per super-chunk, nothing else changes). */
 typedef struct {
-    double ms_sizes, ms_tables, ms_tree, ms_tasks, ms_total; /* sizes+scan | tables_kernel | tree_kernel per ligand | task rounds */
-    uint64_t table_bytes;   /* bytes of intermediate pair-score tables written for the call */
-    uint64_t n_chunks;
-    uint64_t n_tasks;        /* subtrees handed to the task queue by over-budget tree walkers */
-    uint64_t n_rounds;       /* task-queue rounds (one tree-kernel launch each) */
-    uint64_t queue_overflow; /* 1 if the task queue filled up (results stay exact; raise PMX_TASKQ_MB) */
-    uint64_t n_steps;        /* tree-search steps (frame expansions, descents, leaf visits, returns) */
-    uint64_t n_iters;        /* wavefront iterations of the tree kernels (n_steps / n_iters = busy conformer groups per wave) */
-    uint64_t max_iters_ligand; /* wavefront iterations of the longest per-ligand job / task job (tail diagnostics) */
-    uint64_t max_iters_task;
-    uint64_t n_steps_first;  /* of which in the first (per-ligand) tree kernel of the first chunk with tasks */
-    uint64_t n_heavy;        /* ligands whose tree ran over its budget (their tables moved to the arena) */
-    uint64_t n_items;        /* (ligand node pair, table entry) items evaluated by the table phase, per conformer lane group */
-    uint64_t n_exact_cells;  /* items whose 2-sigma majority test was counted term by term (pass set not an interval) */
-    uint64_t n_overflow;     /* ligands whose tables did not fit a per-wavefront slice */
+    double ms_total;            /* the call's kernels, first to last */
+    double ms_ligand, ms_tasks; /* of the last super-chunk: ligand kernels (tables + tree search within budget) | task rounds + finalize */
+    uint64_t ligands_last;      /* ligands in that super-chunk */
+    uint64_t n_frames;          /* tree nodes entered (tree.py:15-53) */
+    uint64_t n_passes;          /* walker passes: evaluations of a frame's candidates (probes included) */
+    uint64_t n_items;           /* table phase: (table entry, ligand node pair) evaluations per wavefront, i.e. / (64 / G) slots */
+    uint64_t n_exact_cells;     /* items whose 2-sigma majority test was counted term by term (pass set not an interval), per lane */
+    uint64_t n_heavy;           /* walks that ran over their budget (ligands and queued subtrees) */
+    uint64_t n_tasks;           /* subtrees taken from the task queue */
+    uint64_t n_exported;        /* subtree records written to the task queue */
+    uint64_t n_slice_overflow;  /* ligands whose tables did not fit a per-wavefront slice */
+    uint64_t n_probes, n_probe_passes; /* reachability searches for handing over subtrees below 5 matches */
+    uint64_t max_passes;        /* longest single walk */
+    uint64_t queue_overflow;    /* 1 if a task queue shard filled up (results stay exact; raise PMX_TASKQ_MB) */
+    uint64_t arena_bytes;       /* table arena in use at the end of the last super-chunk */
+    uint64_t ticks_scan, ticks_tables, ticks_bounds, ticks_walk, ticks_alive; /* s_memtime ticks summed over wavefronts, by phase */
 } pmx_score_stats;
 int pmx_score_stats_get(pmx_score_stats *out);
-int pmx_set_profiling(int enabled); /* when enabled pmx_score records HIP events around each kernel (adds syncs) */
+int pmx_set_profiling(int enabled); /* when enabled pmx_score records HIP events around its phases (no synchronisation) */
 
 #ifdef __cplusplus
 }

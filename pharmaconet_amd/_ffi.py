@@ -73,27 +73,13 @@ class FeatureBatch(ctypes.Structure):
 
 
 class ScoreStats(ctypes.Structure):
-    _fields_ = [
-        ("ms_sizes", ctypes.c_double),
-        ("ms_tables", ctypes.c_double),
-        ("ms_tree", ctypes.c_double),
-        ("ms_tasks", ctypes.c_double),
-        ("ms_total", ctypes.c_double),
-        ("table_bytes", ctypes.c_uint64),
-        ("n_chunks", ctypes.c_uint64),
-        ("n_tasks", ctypes.c_uint64),
-        ("n_rounds", ctypes.c_uint64),
-        ("queue_overflow", ctypes.c_uint64),
-        ("n_steps", ctypes.c_uint64),
-        ("n_iters", ctypes.c_uint64),
-        ("max_iters_ligand", ctypes.c_uint64),
-        ("max_iters_task", ctypes.c_uint64),
-        ("n_steps_first", ctypes.c_uint64),
-        ("n_heavy", ctypes.c_uint64),
-        ("n_items", ctypes.c_uint64),
-        ("n_exact_cells", ctypes.c_uint64),
-        ("n_overflow", ctypes.c_uint64),
-    ]
+    _fields_ = (
+        [("ms_total", ctypes.c_double), ("ms_ligand", ctypes.c_double), ("ms_tasks", ctypes.c_double)]
+        + [(n, ctypes.c_uint64) for n in (
+            "ligands_last", "n_frames", "n_passes", "n_items", "n_exact_cells", "n_heavy", "n_tasks", "n_exported",
+            "n_slice_overflow", "n_probes", "n_probe_passes", "max_passes", "queue_overflow", "arena_bytes",
+            "ticks_scan", "ticks_tables", "ticks_bounds", "ticks_walk", "ticks_alive")]
+    )
 
 
 # name -> (restype, argtypes); every symbol include/pmx.h declares

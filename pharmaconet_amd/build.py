@@ -16,7 +16,7 @@ REPO = PKG.parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libpmx.so"
 SOURCES = ("pmx_api.hip", "pmx_topk.hip", "pmx_pack.cpp")
-DEPS = ("pmx_kernels.hip", "pmx_screen.hip", "pmx_device.h")
+DEPS = ("pmx_screen.hip", "pmx_device.h")
 FLAGS = (
     "--offload-arch=gfx950",
     "-O3",

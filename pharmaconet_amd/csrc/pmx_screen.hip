@@ -374,9 +374,9 @@ __device__ __forceinline__ bool probe(Walk<G> &w, int f, int nm, int cand, uint6
                 while (nb < kf) {
                     const bool on = nb + s < kf;
                     const uint32_t bo = on ? lane_off : (uint32_t)c * 4u;
-                    float lo = 1.f;
-                    for (int q = 0; q < nm; ++q) lo = fminf(lo, *reinterpret_cast<const float *>(Pb + (((uint32_t)(rl(ebv, q) + nb) << PSH) + bo)));
-                    const unsigned long long vb = __ballot(on && ((mask >> c) & 1ull) && lo > 0.f);
+                    bool ok = on && ((mask >> c) & 1ull);
+                    for (int q = 0; q < nm; ++q) ok = ok && *reinterpret_cast<const float *>(Pb + (((uint32_t)(rl(ebv, q) + nb) << PSH) + bo)) > 0.f;
+                    const unsigned long long vb = __ballot(ok);
                     ++passes;
                     if (!vb) {
                         nb += SLOTS;
@@ -492,7 +492,8 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
                     lo = fminf(lo, v);
                     sum += (double)v;
                 }
-                const bool valid = on && ((mask >> c) & 1ull) && lo > 0.f;
+                // (v_min_f32 skips a NaN entry - a zero-weight pair, match_utils.py:50-52 - but the sum does not: NaN is not > 0)
+                const bool valid = on && ((mask >> c) & 1ull) && lo > 0.f && sum == sum;
                 const double t = (tparent + (double)self) + sum; // parent + self + accumulated pair (tree.py:38-41)
                 const unsigned long long vb = __ballot(valid);
                 ++w.passes;
@@ -1466,6 +1467,81 @@ __global__ void ctl_clear_kernel(Ctl *ctl, int clear_stats) {
         else if (clear_stats) w[i] = 0;
     } else if (i < all_words && clear_stats) {
         w[i] = 0;
+    }
+}
+
+// Wave-wide reductions in front of statistics atomics: one atomic per wavefront instead of one per lane on the same
+// address (device-scope atomics on one address serialise at some 20 ns each on this part; inactive lanes contribute 0).
+__device__ inline unsigned long long wave_sum(unsigned long long v) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) v += __shfl_xor(v, d);
+    return v;
+}
+__device__ inline unsigned long long wave_max(unsigned long long v) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long o = __shfl_xor(v, d);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+
+// -------------------------------------------------------------------------------- library stats
+// Also validates every record (a truncated or corrupt library must not make the scoring kernels read out of bounds): the
+// header-implied size has to fit the record's byte range, cluster ends have to be monotonic and <= n_nodes, type masks
+// <= 127. A record that fails is neutralised in the device copy (header zeroed -> PMX_LIGAND_UNSUPPORTED, score NaN) and
+// counted; offsets that are not multiples of 16 or run backwards make the upload fail (out[5]).
+__global__ void library_stats_kernel(DevLibrary lib, uint8_t *data_rw, uint64_t nbytes,
+                                     unsigned long long *out /* [0] conformers [1] maxn [2] maxC [3] maxcl [4] unsupported [5] bad offsets [6] corrupt */) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long conf = 0, maxn = 0, maxc = 0, maxcl = 0, unsupported = 0, bad_offsets = 0, corrupt = 0;
+    if (i < lib.n) {
+        const uint64_t o0 = lib.offsets[i], o1 = lib.offsets[i + 1];
+        if ((o0 & 15) || o1 < o0 + 8 || o1 > nbytes) {
+            bad_offsets = 1;
+        } else {
+            Record r = parse_record(lib.data + o0);
+            const uint64_t need = ((8ull + (uint64_t)r.n + (uint64_t)r.ncl + 3ull) & ~3ull) + 12ull * (uint64_t)r.n * (uint64_t)r.C;
+            bool ok = need <= o1 - o0;
+            if (ok && record_supported(r)) {
+                int prev = 0;
+                for (int q = 0; q < r.ncl && ok; ++q) {
+                    const int e = r.cluster_end[q];
+                    ok = e >= prev && e <= r.n;
+                    prev = e;
+                }
+                for (int u = 0; u < r.n && ok; ++u) ok = r.typemask[u] < 128;
+            }
+            if (!ok) { // neutralise: 0 nodes, 0 conformers, 0 clusters
+                *reinterpret_cast<uint64_t *>(data_rw + o0) = 0ull;
+                corrupt = 1;
+                unsupported = 1;
+            } else {
+                conf = (unsigned long long)r.C;
+                maxn = (unsigned long long)r.n;
+                maxc = (unsigned long long)r.C;
+                maxcl = (unsigned long long)r.ncl;
+                if (!record_supported(r)) unsupported = 1;
+            }
+        }
+    }
+    // one set of atomics per wavefront, not per ligand
+    conf = wave_sum(conf);
+    maxn = wave_max(maxn);
+    maxc = wave_max(maxc);
+    maxcl = wave_max(maxcl);
+    unsupported = wave_sum(unsupported);
+    bad_offsets = wave_sum(bad_offsets);
+    corrupt = wave_sum(corrupt);
+    if ((threadIdx.x & 63) == 0) {
+        if (conf) atomicAdd(&out[0], conf);
+        if (maxn) atomicMax(&out[1], maxn);
+        if (maxc) atomicMax(&out[2], maxc);
+        if (maxcl) atomicMax(&out[3], maxcl);
+        if (unsupported) atomicAdd(&out[4], unsupported);
+        if (bad_offsets) atomicAdd(&out[5], bad_offsets);
+        if (corrupt) atomicAdd(&out[6], corrupt);
     }
 }
 

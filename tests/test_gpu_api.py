@@ -187,9 +187,10 @@ def test_sharded_screen_merges_to_the_global_ranking():
 
 
 def test_scores_do_not_depend_on_how_the_work_is_cut(monkeypatch):
-    """The same bits whatever the launch structure: several chunks through the two-slot pipelines, phases
-    serialised, one or five concurrent pipelines, subtrees exported early, no in-wave sharing, other shapes of the table kernel's persistent launch - and with the bound test of the tree search switched
-    off (every subtree walked, as the reference does): dropping subtrees never changes a score."""
+    """The same bits whatever the launch structure: small super-chunks, few or many wavefronts per CU, tables that do
+    not fit the slices (large-slice and arena passes), trees split into queued subtrees almost at once or never, one
+    task round only, subtrees handed over at any depth - and with the bound test of the tree search switched off
+    (every subtree walked, as the reference does): dropping or moving subtrees never changes a score."""
     import torch
 
     from pharmaconet_amd import engine
@@ -205,18 +206,19 @@ def test_scores_do_not_depend_on_how_the_work_is_cut(monkeypatch):
     offsets, data = expand_library_on_device(base, 120, "cuda")  # 30,720 ligands
     lib = DeviceLibrary.from_device_buffers(offsets, data)
     want = model.screen(lib).scores
-    steps_default = engine.last_score_stats()["n_steps"]
+    stats_default = engine.last_score_stats()
     assert torch.isfinite(want).all()
+    assert stats_default["n_tasks"] > 0  # the default run does split trees
     for env in (
-        {"PMX_CHUNK": "4001"},                      # >= 8 chunks, both buffer slots of every pipeline reused
-        {"PMX_CHUNK": "4001", "PMX_OVERLAP": "0"},  # the same with each pipeline on one stream
-        {"PMX_PIPELINES": "1"},                     # one chunk pipeline instead of three concurrent ones
-        {"PMX_PIPELINES": "5", "PMX_CHUNK": "2500"},
-        {"PMX_BUDGET": "64"},                       # trees are split across wavefronts much earlier
-        {"PMX_TREE_FLAGS": "1"},                    # no hand-over between the groups of a wave
-        {"PMX_TREE_FLAGS": "4"},                    # no bound test
-        {"PMX_V2_WAVES": "3", "PMX_V2_BLOCKS": "1"},  # table kernel: few, small persistent blocks - every wave builds many ligands
-        {"PMX_V2_BLOCKS": "64"},                    # more blocks than work: most find the cursor exhausted
+        {"PMX_SUPER": "4001"},                       # 8 super-chunks: control block, queue and arena restart eight times
+        {"PMX_WAVES_PER_CU": "2"},                   # few persistent wavefronts: each builds and walks many ligands
+        {"PMX_SLICE_KB": "8"},                       # most tables overflow the slices: large-slice pass
+        {"PMX_SLICE_KB": "8", "PMX_BIG_SLICE_MB": "1", "PMX_BIG_TOTAL_MB": "64"},
+        {"PMX_BUDGET": "16", "PMX_MIN_LEVELS": "0"},  # trees are split almost at once, subtrees handed over at any depth
+        {"PMX_BUDGET": "64", "PMX_ROUNDS": "1"},     # one task round: queued subtrees are walked to their end
+        {"PMX_TREE_FLAGS": "2"},                     # nothing is ever queued
+        {"PMX_TREE_FLAGS": "4"},                     # no bound test
+        {"PMX_TREE_FLAGS": "32"},                    # the last two levels walked frame by frame instead of fused into the parent's pass
     ):
         with monkeypatch.context() as mp:
             for k, v in env.items():
@@ -224,15 +226,17 @@ def test_scores_do_not_depend_on_how_the_work_is_cut(monkeypatch):
             got = model.screen(lib).scores
             stats = engine.last_score_stats()
         assert torch.equal(got, want), env
-        if env.get("PMX_CHUNK") == "4001":
-            assert stats["n_chunks"] >= 8
+        if env.get("PMX_SLICE_KB"):
+            assert stats["n_slice_overflow"] > 1000
+        if env.get("PMX_TREE_FLAGS") == "2":
+            assert stats["n_tasks"] == 0
         if env.get("PMX_TREE_FLAGS") == "4":
-            assert stats["n_steps"] > 2 * steps_default  # the bound test is what keeps the trees small
+            assert stats["n_frames"] > 2 * stats_default["n_frames"]  # the bound test is what keeps the trees small
 
 
 def test_concurrent_callers_are_serialised_not_corrupted():
-    """include/pmx.h: pmx_score may be called from any thread; calls of the default engine share per-device workspaces
-    and take one lock. Two threads screening different libraries at once get the scores they get alone."""
+    """include/pmx.h: pmx_score may be called from any thread; work buffers are kept per (device, stream). Two threads
+    screening different libraries on their own streams at once get the scores they get alone."""
     import threading
 
     import torch
@@ -285,8 +289,8 @@ def test_full_task_queue_changes_nothing_but_time(monkeypatch):
     try:
         with monkeypatch.context() as mp:
             mp.setenv("PMX_TASKQ_MB", "1")  # 128 records per shard
-            mp.setenv("PMX_BUDGET", "64")   # export early and often
-            mp.setenv("PMX_PIPELINES", "1")
+            mp.setenv("PMX_BUDGET", "16")   # export early and often
+            mp.setenv("PMX_MIN_LEVELS", "0")
             got = model.screen(lib).scores
             stats = engine.last_score_stats()
         assert stats["queue_overflow"] == 1  # otherwise this test shows nothing

@@ -153,7 +153,7 @@ def test_bench_size_library_properties_and_oracle_sample(oracle, monkeypatch):
     assert torch.isfinite(full).all() and (full >= 0).all()
     checksum = full.double().sum().item()
     with monkeypatch.context() as mp:
-        mp.setenv("PMX_CHUNK", "100000")
+        mp.setenv("PMX_SUPER", "100000")
         again = model.screen(lib).scores
     assert torch.equal(again, full)
     assert again.double().sum().item() == checksum

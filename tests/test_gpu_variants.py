@@ -1,5 +1,5 @@
 """GPU tests beyond the golden sets: both of the reference's kernel variants, zero weights, the alternative engines, the
-structural limits, corrupt libraries, the arena limit, the multi-pocket batch (BASELINE.json configs[3]) and the stress
+structural limits, corrupt libraries, the table arena, the multi-pocket batch (BASELINE.json configs[3]) and the stress
 configuration at full size (configs[4])."""
 
 import json
@@ -137,23 +137,43 @@ def test_corrupt_library_is_neutralised_not_followed():
     assert abs(scores[5] - d["score"][5]) <= RTOL * abs(d["score"][5]) + 1e-30
 
 
-def test_arena_limit_cuts_chunks_smaller(monkeypatch):
-    """A chunk whose score tables would exceed the arena limit (64 GB addressing / PMX_ARENA_MAX_MB) is cut into smaller
-    chunks instead of overflowing 32-bit table offsets or failing: same bits."""
+def test_small_arena_changes_nothing_but_time(monkeypatch):
+    """The arena holds the tables of ligands whose tree is split (and of ligands too large for any slice). When it is full
+    a tree that runs over its budget is walked by its own wavefront to the end instead of being split: same bits. A ligand
+    whose tables fit neither a slice nor the arena at all is reported, not mis-scored."""
     import torch
 
+    from pharmaconet_amd import engine
     from pharmaconet_amd.engine import DeviceLibrary
     from pharmaconet_amd.synthetic import expand_library_on_device, synthetic_library
 
     model, _, _, _ = load_golden("set_6oim_c8")
     base = synthetic_library(256, num_conformers=8, model_nodes=_model_nodes(model), conformer_noise=0.0, seed=777)
-    offsets, data = expand_library_on_device(base, 64, "cuda")  # 16,384 ligands, ~180 MB of tables
+    offsets, data = expand_library_on_device(base, 64, "cuda")  # 16,384 ligands
     lib = DeviceLibrary.from_device_buffers(offsets, data)
     want = model.screen(lib).scores
-    with monkeypatch.context() as mp:
-        mp.setenv("PMX_ARENA_MAX_MB", "64")
-        got = model.screen(lib).scores
-    assert torch.equal(got, want)
+    engine.release_workspaces()  # the arena is sized when a workspace is created
+    try:
+        with monkeypatch.context() as mp:
+            mp.setenv("PMX_ARENA_MB", "16")
+            mp.setenv("PMX_BUDGET", "64")
+            got = model.screen(lib).scores
+            stats = engine.last_score_stats()
+        assert stats["arena_bytes"] > 16 << 20  # more was asked for than there is: otherwise this test shows nothing
+        assert torch.equal(got, want)
+        engine.release_workspaces()
+        with monkeypatch.context() as mp:  # tables that fit nowhere: slices of 4 KB, no large slices to speak of, arena of 16 MB... still fit
+            mp.setenv("PMX_SLICE_KB", "4")
+            mp.setenv("PMX_BIG_SLICE_MB", "1")
+            mp.setenv("PMX_ARENA_MB", "16")
+            res = model.screen(lib)
+        st = res.status.cpu().numpy()
+        sc = res.scores.cpu().numpy()
+        ok = st == 0
+        assert np.array_equal(sc[ok], want.cpu().numpy()[ok])   # whatever was scored is right
+        assert np.all(np.isnan(sc[~ok])) and np.all(st[~ok] == 2)  # the rest says PMX_LIGAND_TOO_LARGE
+    finally:
+        engine.release_workspaces()
 
 
 def test_sixteen_pockets_one_library():
@@ -211,7 +231,7 @@ def test_stress_config_at_full_size(oracle, monkeypatch):
     assert torch.isfinite(full).all() and (full >= 0).all()
     checksum = full.double().sum().item()
     with monkeypatch.context() as mp:
-        mp.setenv("PMX_CHUNK", "17000")
+        mp.setenv("PMX_SUPER", "17000")
         again = model.screen(lib).scores
     assert torch.equal(again, full) and again.double().sum().item() == checksum
     off = offsets.cpu().numpy()
