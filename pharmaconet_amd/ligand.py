@@ -6,8 +6,12 @@ in the reference (`openbabel-wheel`, `pyproject.toml:34`); it is an optional dep
 module raises ImportError with instructions when it is absent. Everything after perception - the graph
 builder (`library.cluster_ligand`), packing and scoring - has no OpenBabel dependency.
 
-NOTE (parity): OpenBabel is not installed in the build image, so this file is exercised only up to its
-ImportError; the typed-feature interface below (`LigandFeatures`) is the tested parity boundary.
+Parity: OpenBabel is not installed in the build image, so real molecule files cannot be read here. The rule logic of
+this file IS pinned: `tests/golden/make_golden_perception.py` runs the reference's own `get_pharmacophore_nodes`,
+`Ligand.__init__`, `Ligand.load_from_file` and `scoring_pbmol` / `scoring_file` on 600 described molecules through a
+stand-in for the OpenBabel calls (`tests/fake_openbabel.py`), and `tests/test_perception.py` holds this file to those
+outputs (feature lists, packed records, scores). OpenBabel's own atom typing (`IsHbondAcceptor`, hybridisation, ring
+perception) is its business in both code bases and is not pinned.
 """
 
 from __future__ import annotations
