@@ -125,7 +125,9 @@ int pmx_score_multi(const pmx_model *const *models, int n_models, const pmx_libr
  * The ranking step of screening.py:70 (`result.sort(key=score, reverse=True)`, stable): the k best
  * of scores_dev[n] in descending score order, ties in ascending index order. index_dev may be
  * NULL (element i has index base_index + i) or give each element's global index.
- * out_scores_dev[k], out_index_dev[k]; if n < k the tail is filled with -inf / UINT64_MAX.
+ * out_scores_dev[k], out_index_dev[k]; if n < k the tail is filled with -inf / UINT64_MAX. A NaN score (an unsupported ligand)
+ * ranks after every real score and is reported as NaN with its index; input elements whose index is UINT64_MAX are padding
+ * (they rank last). k <= 65536, n < 2^31. A radix select on the device (csrc/pmx_topk.hip): no sort of all n, no library.
  */
 int pmx_topk(const float *scores_dev, const uint64_t *index_dev, uint64_t n, uint64_t base_index, int k,
              float *out_scores_dev, uint64_t *out_index_dev, int device, void *stream);
@@ -157,8 +159,10 @@ int pmx_topk_allgather(pmx_comm *comm, const float *scores_k_dev, const uint64_t
  * offsets_out[n_mols + 1] and data_out receive the library; *data_bytes the bytes written. Sizing: a call with data_out =
  * NULL packs nothing and returns in *data_bytes an upper bound (every feature a node) - allocate that, pack once, keep the
  * first *data_bytes bytes. With a data_cap that turns out too small the call fails and *data_bytes holds the exact need.
- * status_out (may be NULL): 1 for a molecule outside the
- * structural limits above, which becomes a header-only record that pmx_score reports as PMX_LIGAND_UNSUPPORTED.
+ * status_out (may be NULL): 1 for a molecule outside the structural limits above, 2 for malformed input (type id above 6, an atom /
+ * centre / neighbour index outside the molecule, a feature without atoms, too few positions) or a feature graph on which the
+ * reference's builder raises (a dependent node whose ring has no cluster); either becomes a header-only record that pmx_score
+ * reports as PMX_LIGAND_UNSUPPORTED. Offsets that run backwards fail the whole call.
  */
 typedef struct {
     uint64_t n_mols;

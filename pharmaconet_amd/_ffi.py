@@ -152,6 +152,26 @@ def load(need_torch: bool = True) -> ctypes.CDLL:
     return _lib
 
 
+_pack_lib: ctypes.CDLL | None = None
+
+
+def load_packer() -> ctypes.CDLL:
+    """libpmx_pack.so: `pmx_pack_features` alone, for host processes that pack libraries (no torch, no HIP runtime)."""
+    global _pack_lib
+    if _pack_lib is None:
+        path = LIB_PATH.with_name("libpmx_pack.so")
+        if not path.exists():
+            raise PmxError(f"{path} is missing: build with `python -m pharmaconet_amd.build`")
+        lib = ctypes.CDLL(str(path))
+        for name in ("pmx_pack_features", "pmx_last_error", "pmx_version"):
+            restype, argtypes = SIGNATURES[name]
+            fn = getattr(lib, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _pack_lib = lib
+    return _pack_lib
+
+
 def check(rc: int) -> None:
     if rc != 0:
         msg = load().pmx_last_error()

@@ -15,6 +15,7 @@ PKG = Path(__file__).resolve().parent
 REPO = PKG.parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libpmx.so"
+PACK_LIB = PKG / "libpmx_pack.so"  # the packer alone, host-only (no HIP / RCCL runtime)
 SOURCES = ("pmx_api.hip", "pmx_topk.hip", "pmx_pack.cpp")
 DEPS = ("pmx_screen.hip", "pmx_device.h")
 FLAGS = (
@@ -37,9 +38,9 @@ def hipcc() -> str:
 
 
 def _stale() -> bool:
-    if not LIB.exists():
+    if not LIB.exists() or not PACK_LIB.exists():
         return True
-    built = LIB.stat().st_mtime
+    built = min(LIB.stat().st_mtime, PACK_LIB.stat().st_mtime)
     inputs = [CSRC / s for s in SOURCES + DEPS] + [REPO / "include" / "pmx.h"]
     return any(p.stat().st_mtime > built for p in inputs)
 
@@ -72,11 +73,22 @@ def _build(verbose: bool) -> Path:
         subprocess.run(cmd, check=True)
         objs.append(str(obj))
     tmp = LIB.with_suffix(".so.tmp")
-    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", str(tmp), "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    # librccl is linked without an rpath: a process that has imported torch already holds torch's bundled RCCL / HIP runtime
+    # (see _ffi.load), and one that has not finds ROCm's through the loader's usual search path
+    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", str(tmp), f"-L{rocm}/lib", "-lrccl"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
     os.replace(tmp, LIB)
+    # the host-only packer library
+    tmp = PACK_LIB.with_suffix(".so.tmp")
+    cmd = [os.environ.get("CXX", "g++"), "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread", "-DPMX_PACK_STANDALONE", f"-I{REPO / 'include'}",
+           str(CSRC / "pmx_pack.cpp"), "-o", str(tmp)]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    os.replace(tmp, PACK_LIB)
     return LIB
 
 

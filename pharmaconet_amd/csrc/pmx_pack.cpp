@@ -19,7 +19,20 @@
 
 #include "pmx.h"
 
+#ifdef PMX_PACK_STANDALONE
+// libpmx_pack.so: this file alone, for host processes that pack libraries and never touch a GPU (no HIP / RCCL runtime is
+// loaded with it). It brings its own error string.
+#include <cstdio>
+static thread_local char g_pack_err[256] = "";
+static int pmx_topk_fail(int code, const char *msg) {
+    std::snprintf(g_pack_err, sizeof(g_pack_err), "%s", msg);
+    return code;
+}
+extern "C" const char *pmx_last_error(void) { return g_pack_err; }
+extern "C" int pmx_version(void) { return 100; }
+#else
 int pmx_topk_fail(int code, const char *msg); // error hook in pmx_api.hip
+#endif
 
 namespace {
 
@@ -216,7 +229,9 @@ int64_t pack_one(const Mol &m, uint8_t *out, uint64_t cap) {
             if (nd.min_dependence >= 0 && founder[nd.min_dependence] >= 0) { // (the reference would raise KeyError otherwise)
                 clusters[founder[nd.min_dependence]].push_back(ni);
                 add_new = false;
-            } else if (nd.min_dependence < 0) {
+            } else if (nd.min_dependence >= 0) {
+                return -2; // a node that depends on a node without a cluster: the reference's builder raises KeyError (ligand.py:238-241)
+            } else {
                 for (int g : nd.group)
                     if (founder[g] >= 0) {
                         clusters[founder[g]].push_back(ni);
@@ -283,9 +298,48 @@ int64_t pack_one(const Mol &m, uint8_t *out, uint64_t cap) {
 
 } // namespace
 
+// The raw arrays of one molecule, checked before the graph builder indexes with them: type ids, atom / centre / neighbour
+// indices inside the molecule, features with at least one atom, monotonic offsets, a sane conformer count.
+static bool valid_molecule(const pmx_feature_batch *b, uint64_t i, const Mol &m) {
+    if (m.n_atoms < 0 || m.n_feat < 0 || m.n_conf < 1 || m.n_conf > 1 << 16) return false;
+    const uint64_t need_pos = (uint64_t)m.n_atoms * (uint64_t)m.n_conf * 3;
+    if (b->pos_off[i + 1] - b->pos_off[i] < need_pos) return false;
+    for (int a = 0; a < m.n_atoms; ++a) {
+        if (m.nbr_off[a + 1] < m.nbr_off[a]) return false;
+        for (uint64_t q = m.nbr_off[a]; q < m.nbr_off[a + 1]; ++q)
+            if (m.nbr[q] < 0 || m.nbr[q] >= m.n_atoms) return false;
+    }
+    for (int f = 0; f < m.n_feat; ++f) {
+        if (m.ftype[f] >= PMX_NUM_TYPES) return false;
+        if (m.fatom_off[f + 1] <= m.fatom_off[f] || m.fcenter_off[f + 1] <= m.fcenter_off[f]) return false; // at least one atom / centre
+        for (uint64_t q = m.fatom_off[f]; q < m.fatom_off[f + 1]; ++q)
+            if (m.fatoms[q] < 0 || m.fatoms[q] >= m.n_atoms) return false;
+        for (uint64_t q = m.fcenter_off[f]; q < m.fcenter_off[f + 1]; ++q)
+            if (m.fcenters[q] < 0 || m.fcenters[q] >= m.n_atoms) return false;
+    }
+    return true;
+}
+
+static int pack_features_impl(const pmx_feature_batch *b, int threads, uint64_t *offsets_out, uint8_t *data_out, uint64_t data_cap,
+                              uint64_t *data_bytes, int32_t *status_out);
+
 extern "C" int pmx_pack_features(const pmx_feature_batch *b, int threads, uint64_t *offsets_out, uint8_t *data_out, uint64_t data_cap,
                                  uint64_t *data_bytes, int32_t *status_out) {
+    try { // no exception crosses the C boundary
+        return pack_features_impl(b, threads, offsets_out, data_out, data_cap, data_bytes, status_out);
+    } catch (const std::bad_alloc &) {
+        return pmx_topk_fail(PMX_ERR_OOM, "pmx_pack_features: out of host memory");
+    } catch (...) {
+        return pmx_topk_fail(PMX_ERR_INVALID, "pmx_pack_features: internal error");
+    }
+}
+
+static int pack_features_impl(const pmx_feature_batch *b, int threads, uint64_t *offsets_out, uint8_t *data_out, uint64_t data_cap,
+                              uint64_t *data_bytes, int32_t *status_out) {
     if (!b || !offsets_out || (!data_out && data_cap) || !data_bytes) return pmx_topk_fail(PMX_ERR_INVALID, "null argument");
+    for (uint64_t i = 0; i < b->n_mols; ++i) // offset arrays must not run backwards (everything else is checked per molecule)
+        if (b->atom_off[i + 1] < b->atom_off[i] || b->feat_off[i + 1] < b->feat_off[i] || b->pos_off[i + 1] < b->pos_off[i])
+            return pmx_topk_fail(PMX_ERR_INVALID, "pmx_pack_features: offsets run backwards");
     const uint64_t n = b->n_mols;
     // every record gets the worst-case room of its molecule first (features x conformers), then the records are compacted
     std::vector<uint64_t> room(n + 1, 0);
@@ -298,10 +352,11 @@ extern "C" int pmx_pack_features(const pmx_feature_batch *b, int threads, uint64
         *data_bytes = room[n];
         return PMX_OK;
     }
-    std::unique_ptr<uint8_t[]> scratch_mem(new uint8_t[room[n] + 16]); // not zero-filled: pack_one clears what it writes
+    std::unique_ptr<uint8_t[]> scratch_mem(new (std::nothrow) uint8_t[room[n] + 16]); // not zero-filled: pack_one clears what it writes
+    if (!scratch_mem) return pmx_topk_fail(PMX_ERR_OOM, "pmx_pack_features: out of host memory");
     uint8_t *scratch = scratch_mem.get();
     std::vector<int64_t> sizes(n, 0);
-    std::atomic<uint64_t> next{0};
+    std::atomic<uint64_t> next{0}, bad_input{0};
     auto work = [&]() {
         for (;;) {
             const uint64_t i0 = next.fetch_add(256);
@@ -322,11 +377,17 @@ extern "C" int pmx_pack_features(const pmx_feature_batch *b, int threads, uint64
                 m.fatoms = b->feat_atoms;
                 m.fcenters = b->feat_centers;
                 m.pos = b->positions + b->pos_off[i];
-                int64_t sz = pack_one(m, scratch + room[i], room[i + 1] - room[i]);
-                if (sz <= 0) { // outside the structural limits: header-only record, reported per ligand (PMX_LIGAND_UNSUPPORTED)
+                int64_t sz = -2;
+                try {
+                    if (valid_molecule(b, i, m)) sz = pack_one(m, scratch + room[i], room[i + 1] - room[i]);
+                } catch (...) { // (allocation failure inside the graph builder: report the molecule, never unwind a thread)
+                    sz = -2;
+                }
+                if (sz <= 0) { // outside the structural limits, or malformed input: header-only record, reported per ligand
                     std::memset(scratch + room[i], 0, 16);
+                    if (status_out) status_out[i] = sz == -2 ? 2 : 1;
+                    if (sz == -2) bad_input.fetch_add(1);
                     sz = 16;
-                    if (status_out) status_out[i] = 1;
                 } else if (status_out) {
                     status_out[i] = 0;
                 }

@@ -70,8 +70,9 @@ class TopkExchange:
         if self.rank == 0:
             _ffi.check(self._lib.pmx_comm_unique_id(ident))
         payload = [ident.raw]
-        if self.world > 1:
-            dist.broadcast_object_list(payload, src=0, group=group)
+        if self.world > 1:  # (src is a global rank: the group's rank 0 need not be the world's)
+            src = dist.get_global_rank(group, 0) if group is not None else 0
+            dist.broadcast_object_list(payload, src=src, group=group)
         self._handle = ctypes.c_void_p()
         _ffi.check(self._lib.pmx_comm_create(payload[0], self.rank, self.world, self.device.index or 0, ctypes.byref(self._handle)))
 

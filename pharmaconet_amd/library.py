@@ -338,7 +338,7 @@ def pack_features_native(mols: Sequence[LigandFeatures] | dict[str, np.ndarray],
     from . import _ffi
 
     flat = mols if isinstance(mols, dict) else flatten_features(mols)
-    lib = _ffi.load(need_torch=False)
+    lib = _ffi.load_packer()  # host-only library: packing workers load no GPU runtime
     n = int(flat["atom_off"].shape[0]) - 1
     batch = _ffi.FeatureBatch(n, *(flat[k].ctypes.data for k in (
         "atom_off", "atomic_num", "nbr_off", "nbr", "feat_off", "feat_type", "feat_flags", "feat_atom_off", "feat_atoms",
@@ -346,10 +346,14 @@ def pack_features_native(mols: Sequence[LigandFeatures] | dict[str, np.ndarray],
     offsets = np.zeros(n + 1, dtype=np.uint64)
     status = np.zeros(n, dtype=np.int32)
     nbytes = ctypes.c_uint64(0)
-    _ffi.check(lib.pmx_pack_features(ctypes.byref(batch), int(threads), offsets.ctypes.data, None, 0, ctypes.byref(nbytes), status.ctypes.data))
+    def check(rc):
+        if rc != 0:
+            raise _ffi.PmxError(f"libpmx_pack error {rc}: {lib.pmx_last_error().decode()}")
+
+    check(lib.pmx_pack_features(ctypes.byref(batch), int(threads), offsets.ctypes.data, None, 0, ctypes.byref(nbytes), status.ctypes.data))
     data = np.empty(int(nbytes.value), dtype=np.uint8)  # the sizing call returns an upper bound; the molecules are packed once
-    _ffi.check(lib.pmx_pack_features(ctypes.byref(batch), int(threads), offsets.ctypes.data, data.ctypes.data, data.size, ctypes.byref(nbytes),
-                                     status.ctypes.data))
+    check(lib.pmx_pack_features(ctypes.byref(batch), int(threads), offsets.ctypes.data, data.ctypes.data, data.size, ctypes.byref(nbytes),
+                                status.ctypes.data))
     return PackedLibrary(offsets, data[: int(nbytes.value)]), status
 
 

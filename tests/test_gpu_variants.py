@@ -306,3 +306,60 @@ def test_release_workspaces_and_score_again():
     engine.release_workspaces()
     b = model.screen(lib, weights=weights, topk=5)
     assert torch.equal(a.scores, b.scores) and torch.equal(a.topk_indices, b.topk_indices)
+
+
+def _exchange_rank(rank, world, port, k, n_per_rank, out_dir):
+    """One rank of test_topk_exchange_over_rccl_on_every_gpu (a spawned process: one per GPU)."""
+    import torch
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.cuda.set_device(rank)
+    device = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    try:
+        from pharmaconet_amd.distributed import TopkExchange
+        from pharmaconet_amd.engine import topk
+
+        rng = np.random.default_rng(1234 + rank)
+        scores = rng.integers(0, 40, size=n_per_rank).astype(np.float32)  # many ties across ranks
+        scores[rng.integers(0, n_per_rank, size=5)] = np.nan               # unsupported ligands
+        if rank == world - 1:
+            scores = scores[: n_per_rank // 2]                             # a short last shard
+        t = torch.from_numpy(scores).to(device)
+        ls, li = topk(t, k, base_index=rank * n_per_rank)
+        ex = TopkExchange(device)
+        gs, gi = ex.allgather(ls, li, k)
+        torch.cuda.synchronize()
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), scores=scores, gs=gs.cpu().numpy(), gi=gi.cpu().numpy())
+        ex.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_topk_exchange_over_rccl_on_every_gpu(tmp_path):
+    """The shipped multi-GPU exchange (`pmx_topk_allgather`: RCCL all-gather + merge on the device) with one process per
+    visible GPU (at most 8): every rank ends with the ranking a single-process stable sort of all shards gives - descending
+    score, ties by ascending global index, NaN after every real score. Skipped on a box with one GPU."""
+    import socket
+
+    import torch
+    import torch.multiprocessing as mp
+
+    world = min(torch.cuda.device_count(), 8)
+    if world < 2:
+        pytest.skip("needs at least two GPUs")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    k, n_per_rank = 500, 20_000
+    mp.spawn(_exchange_rank, args=(world, port, k, n_per_rank, str(tmp_path)), nprocs=world, join=True)
+    shards = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    all_scores = np.concatenate([np.pad(sh["scores"], (0, 0)) for sh in shards])
+    all_index = np.concatenate([r * n_per_rank + np.arange(len(sh["scores"])) for r, sh in enumerate(shards)])
+    key = np.where(np.isnan(all_scores), -np.inf, all_scores.astype(np.float64))
+    nan_last = np.isnan(all_scores).astype(np.int64)
+    order = np.lexsort((all_index, -key, nan_last))[:k]
+    for sh in shards:
+        assert sh["gi"].tolist() == all_index[order].tolist()
+        np.testing.assert_array_equal(sh["gs"], all_scores[order])

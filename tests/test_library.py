@@ -138,7 +138,7 @@ def test_native_packer_sizing_protocol():
     mols = list(golden_molecules("set_6oim_c8"))
     want = PackedLibrary.load(GOLDEN / "set_6oim_c8.pmxlib")
     flat = flatten_features(mols)
-    lib = _ffi.load(need_torch=False)
+    lib = _ffi.load_packer()
     n = len(mols)
     batch = _ffi.FeatureBatch(n, *(flat[k].ctypes.data for k in (
         "atom_off", "atomic_num", "nbr_off", "nbr", "feat_off", "feat_type", "feat_flags", "feat_atom_off", "feat_atoms",
@@ -156,3 +156,55 @@ def test_native_packer_sizing_protocol():
     assert int(nbytes.value) == want.data.size
     assert data[: want.data.size].tobytes() == want.data.tobytes()
     np.testing.assert_array_equal(offsets, want.offsets)
+
+
+def test_native_packer_rejects_malformed_input_per_molecule():
+    """pmx_pack_features trusts nothing in the raw arrays: a type id above 6, an atom index outside the molecule, a feature
+    without atoms or too few positions make THAT molecule a header-only record with status 2; the rest of the batch is
+    packed as usual. Offsets that run backwards fail the call."""
+    import ctypes
+
+    from pharmaconet_amd import _ffi
+    from pharmaconet_amd.library import flatten_features, pack_ligand
+
+    mols = list(golden_molecules("set_6oim_c8"))[:6]
+    good = [bytes(pack_ligand(m)) for m in mols]
+    lib = _ffi.load_packer()
+
+    def run(flat):
+        n = len(mols)
+        batch = _ffi.FeatureBatch(n, *(flat[k].ctypes.data for k in (
+            "atom_off", "atomic_num", "nbr_off", "nbr", "feat_off", "feat_type", "feat_flags", "feat_atom_off", "feat_atoms",
+            "feat_center_off", "feat_centers", "n_conf", "pos_off", "positions")))
+        offsets = np.zeros(n + 1, dtype=np.uint64)
+        status = np.zeros(n, dtype=np.int32)
+        nbytes = ctypes.c_uint64(0)
+        rc = lib.pmx_pack_features(ctypes.byref(batch), 2, offsets.ctypes.data, None, 0, ctypes.byref(nbytes), None)
+        if rc != 0:
+            return rc, None, None, None
+        data = np.zeros(int(nbytes.value), dtype=np.uint8)
+        rc = lib.pmx_pack_features(ctypes.byref(batch), 2, offsets.ctypes.data, data.ctypes.data, data.size, ctypes.byref(nbytes), status.ctypes.data)
+        return rc, offsets, data, status
+
+    def corrupt(fn):
+        flat = {k: np.array(v, copy=True) for k, v in flatten_features(mols).items()}
+        fn(flat)
+        return flat
+
+    f0 = int(flatten_features(mols)["feat_off"][2])  # first feature of molecule 2
+    cases = {
+        "type id": lambda f: f["feat_type"].__setitem__(f0, 9),
+        "atom index": lambda f: f["feat_atoms"].__setitem__(int(f["feat_atom_off"][f0]), 10_000),
+        "negative centre": lambda f: f["feat_centers"].__setitem__(int(f["feat_center_off"][f0]), -1),
+        "neighbour index": lambda f: f["nbr"].__setitem__(int(f["nbr_off"][int(f["atom_off"][2])]), 777),
+        "no conformers": lambda f: f["n_conf"].__setitem__(2, 0),
+    }
+    for name, fn in cases.items():
+        rc, offsets, data, status = run(corrupt(fn))
+        assert rc == 0, name
+        assert status.tolist() == [0, 0, 2, 0, 0, 0], name
+        for i in (0, 1, 3, 4, 5):
+            assert data[int(offsets[i]):int(offsets[i + 1])].tobytes() == good[i], name
+        assert int(offsets[3] - offsets[2]) == 16
+    rc, _, _, _ = run(corrupt(lambda f: f["feat_off"].__setitem__(3, int(f["feat_off"][2]) - 1)))
+    assert rc != 0 and b"backwards" in lib.pmx_last_error()
