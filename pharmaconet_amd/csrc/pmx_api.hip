@@ -556,16 +556,16 @@ static int score_screen(const pmx_model *model, const pmx_library *lib, const We
         const uint64_t nlmax = (uint64_t)std::min<int>(PMX_MAX_LEVELS, std::max(1, lib->info.max_clusters));
         const uint64_t K = (uint64_t)std::max(1, model->dm.K);
         const uint64_t worst = rec_bytes<G>((uint32_t)(nlmax * K), (uint32_t)(nlmax * (nlmax - 1) / 2 * K * K), (uint32_t)nlmax);
-        const uint64_t cap = (uint64_t)std::max<long>(1, env_long("PMX_BIG_SLICE_MB", 32)) << 20;
+        const uint64_t cap = (uint64_t)std::max<long>(1, env_long("PMX_BIG_SLICE_MB", G >= 32 ? 4 : 32)) << 20;
         big_bytes = (uint32_t)std::max<uint64_t>(slice_bytes, (std::min(worst, cap) + 4095) & ~4095ull);
-        const uint64_t total = (uint64_t)std::max<long>(64, env_long("PMX_BIG_TOTAL_MB", 4096)) << 20;
+        const uint64_t total = (uint64_t)std::max<long>(64, env_long("PMX_BIG_TOTAL_MB", G >= 32 ? 16384 : 4096)) << 20;
         big_grid = (uint32_t)std::max<uint64_t>(16, std::min<uint64_t>(grid, total / big_bytes));
     }
     rc = grow(&ws.big, &ws.big_bytes, (size_t)big_grid * big_bytes, stream);
     if (rc) return rc;
-    rc = grow(&ws.arena, &ws.arena_bytes, (size_t)std::max<long>(16, env_long("PMX_ARENA_MB", 6144)) << 20, stream);
+    rc = grow(&ws.arena, &ws.arena_bytes, (size_t)std::max<long>(16, env_long("PMX_ARENA_MB", G >= 32 ? 24576 : 6144)) << 20, stream);
     if (rc) return rc;
-    rc = grow(&ws.queue, &ws.queue_bytes, (size_t)std::max<long>(1, env_long("PMX_TASKQ_MB", 2048)) << 20, stream);
+    rc = grow(&ws.queue, &ws.queue_bytes, (size_t)std::max<long>(1, env_long("PMX_TASKQ_MB", 2048L * std::max(1, G / 8))) << 20, stream);
     if (rc) return rc;
     // super-chunk: the arena holds the tables of the ligands whose tree is split, until the chunk's subtrees are done
     const uint32_t super = (uint32_t)std::max<long>(1024, std::min<long>(env_long("PMX_SUPER", (1L << 20) * 8 / std::max(G, 8)), 1 << 24));
