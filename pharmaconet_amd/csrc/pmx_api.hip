@@ -546,7 +546,9 @@ static int score_screen(const pmx_model *model, const pmx_library *lib, const We
     const uint32_t waves_per_cu = (uint32_t)std::max<long>(1, std::min<long>({(long)(kLdsPerCu / shape.bytes), 4L * PMX_SCREEN_WAVES, env_long("PMX_WAVES_PER_CU", 32)}));
     const uint32_t grid = (uint32_t)ws.num_cu * waves_per_cu;
     // per-wavefront slice: 48 KB at 8 conformer lanes (99.7 % of the bench library's ligands fit), scaled with the lanes
-    const uint32_t slice_bytes = (uint32_t)std::max<long>(4, env_long("PMX_SLICE_KB", 48L * std::max(1, G / 8))) * 1024u;
+    // (table bytes grow with the square of the model's cluster count: the 11-cluster 6OIM-like model is the reference point)
+    const long k_scale = std::max(1L, std::min(16L, ((long)model->dm.K * model->dm.K + 60) / 121));
+    const uint32_t slice_bytes = (uint32_t)std::max<long>(4, env_long("PMX_SLICE_KB", 48L * std::max(1, G / 8) * k_scale)) * 1024u;
     rc = grow(&ws.slices, &ws.slices_bytes, (size_t)grid * slice_bytes, stream);
     if (rc) return rc;
     // large slices for the ligands whose tables exceed a slice: as large as a table of this model and library can get, at most
@@ -563,12 +565,12 @@ static int score_screen(const pmx_model *model, const pmx_library *lib, const We
     }
     rc = grow(&ws.big, &ws.big_bytes, (size_t)big_grid * big_bytes, stream);
     if (rc) return rc;
-    rc = grow(&ws.arena, &ws.arena_bytes, (size_t)std::max<long>(16, env_long("PMX_ARENA_MB", G >= 32 ? 24576 : 6144)) << 20, stream);
+    rc = grow(&ws.arena, &ws.arena_bytes, (size_t)std::max<long>(16, env_long("PMX_ARENA_MB", 32768)) << 20, stream);
     if (rc) return rc;
     rc = grow(&ws.queue, &ws.queue_bytes, (size_t)std::max<long>(1, env_long("PMX_TASKQ_MB", 2048L * std::max(1, G / 8))) << 20, stream);
     if (rc) return rc;
     // super-chunk: the arena holds the tables of the ligands whose tree is split, until the chunk's subtrees are done
-    const uint32_t super = (uint32_t)std::max<long>(1024, std::min<long>(env_long("PMX_SUPER", (1L << 20) * 8 / std::max(G, 8)), 1 << 24));
+    const uint32_t super = (uint32_t)std::max<long>(1024, std::min<long>(env_long("PMX_SUPER", std::max(16384L, (1L << 20) * 8 / std::max(G, 8) / k_scale)), 1 << 24));
     {
         size_t have = (size_t)ws.list_cap * 12;
         rc = grow(&ws.lists, &have, (size_t)super * 12, stream);
@@ -588,7 +590,7 @@ static int score_screen(const pmx_model *model, const pmx_library *lib, const We
     p.max_passes = (unsigned long long)std::max<long>(1, env_long("PMX_MAXITERS", 1L << 40));
     p.scores = scores_dev;
     p.status = status_dev;
-    const int rounds = (int)std::max<long>(1, env_long("PMX_ROUNDS", 8));
+    const int rounds = (int)std::max<long>(1, env_long("PMX_ROUNDS", 12));
     p.last_round = 0;
     p.pad_ = 0;
     const bool exact = (p.flags & 8) != 0;
@@ -605,6 +607,7 @@ static int score_screen(const pmx_model *model, const pmx_library *lib, const We
         if (g_profiling) HIPCHECK(hipEventRecord(ws.ev[1], stream));
         ws.ligands_last = p.hi - p.lo;
         ctl_clear_kernel<<<dim3((sizeof(Ctl) / 4 + 255) / 256), dim3(256), 0, stream>>>(ws.ctl, (lo == 0 && first_model) ? 1 : 0);
+        p.last_round = 0;
         // every ligand whose tables fit a slice
         p.slices = ws.slices;
         p.slice_bytes = slice_bytes;
