@@ -232,7 +232,9 @@ def score_one(model, ligand, weights: dict[str, float] | None = None, device=Non
     packed = as_packed_library(ligand)
     if len(packed) != 1:
         raise ValueError("_scoring takes exactly one ligand")
-    n, c, _ = packed.header(0)
+    n, c, ncl = packed.header(0)
+    if ncl == 0 and n == 0 and c > 0:
+        return 0  # `GraphMatcher.run()` returns the int 0 for a ligand without clusters (graph_match.py:95-96)
     result = screen(model, packed, weights=weights, device=device)
     if int(result.status.cpu()[0]) != 0:
         raise ValueError(

@@ -181,6 +181,7 @@ class PharmacophoreModel:
         self._state = state
         self._flat = _flatten_state(state)
         self._engine_handle = None
+        self._object_graph = None
 
     @classmethod
     def create(cls, pdbblock, center, hotspot_infos, resolution: float = 0.5, size: int = 64):
@@ -207,6 +208,45 @@ class PharmacophoreModel:
     @property
     def num_nodes(self) -> int:
         return self.flat.num_nodes
+
+    # The reference's object graph (`pharmacophore_model.py:191-204,207-365`), built on first use from the state dict: code
+    # written against `model.nodes / .edges / .node_dict / .node_cluster_dict / .node_clusters` keeps working. Read-only views -
+    # scoring never touches them (the device tables come from `flat`).
+    def _graph(self):
+        g = getattr(self, "_object_graph", None)
+        if g is None:
+            assert self._state is not None, "empty model"
+            st = self._state
+            nodes = [ModelNode(self, **kw) for kw in st["nodes"]]
+            g = dict(nodes=nodes)
+            self._object_graph = g  # (ModelEdge / ModelNodeCluster look the nodes up through the model)
+            g["edges"] = [ModelEdge(self, **kw) for kw in st["edges"]]
+            for node in nodes:
+                node.setup()
+            g["node_dict"] = {typ: [nodes[i] for i in indices] for typ, indices in st["node_dict"].items()}
+            g["node_cluster_dict"] = {typ: [ModelNodeCluster(self, **kw) for kw in lst] for typ, lst in st["node_cluster_dict"].items()}
+            g["node_clusters"] = [c for lst in g["node_cluster_dict"].values() for c in lst]
+        return g
+
+    @property
+    def nodes(self) -> list["ModelNode"]:
+        return self._graph()["nodes"]
+
+    @property
+    def edges(self) -> list["ModelEdge"]:
+        return self._graph()["edges"]
+
+    @property
+    def node_dict(self) -> dict[str, list["ModelNode"]]:
+        return self._graph()["node_dict"]
+
+    @property
+    def node_cluster_dict(self) -> dict[str, list["ModelNodeCluster"]]:
+        return self._graph()["node_cluster_dict"]
+
+    @property
+    def node_clusters(self) -> list["ModelNodeCluster"]:
+        return self._graph()["node_clusters"]
 
     @property
     def num_clusters(self) -> int:
@@ -268,3 +308,82 @@ class PharmacophoreModel:
         from .engine import screen
 
         return screen(self, library, weights=weights, topk=topk, **kwargs)
+
+
+class ModelNodeCluster:
+    """`pharmacophore_model.py:207-246` (a view; `get_kwargs()` gives back the state entry)."""
+
+    def __init__(self, graph, cluster_type, node_indices, node_types, center, size):
+        self.type = cluster_type
+        self.nodes = {graph.nodes[int(i)] for i in node_indices}
+        self.node_indices = {int(i) for i in node_indices}
+        self.node_types = set(node_types)
+        self.center = tuple(center)
+        self.size = size
+
+    def __repr__(self):
+        return f"ModelCluster({self.type})[{self.nodes}]"
+
+    def get_kwargs(self):
+        return dict(cluster_type=self.type, node_indices=tuple(self.node_indices), node_types=tuple(self.node_types), center=self.center, size=self.size)
+
+
+class ModelNode:
+    """`pharmacophore_model.py:249-320`."""
+
+    def __init__(self, graph, index, type, interaction_type, hotspot_position, score, center, radius, neighbor_edge_dict, overlapped_nodes):
+        self.graph = graph
+        self.index = int(index)
+        self.type = type
+        self.interaction_type = interaction_type
+        self.hotspot_position = tuple(hotspot_position)
+        self.score = score
+        self.center = tuple(center)
+        self.radius = radius
+        self._neighbor_edge_dict = {int(k): int(v) for k, v in neighbor_edge_dict.items()}  # (.json keys are strings, :279)
+        self._overlapped_nodes = [int(i) for i in overlapped_nodes]
+        self.neighbor_edge_dict = {}
+        self.overlapped_nodes = []
+
+    def setup(self):
+        self.neighbor_edge_dict = {self.graph.nodes[n]: self.graph.edges[e] for n, e in self._neighbor_edge_dict.items()}
+        self.overlapped_nodes = [self.graph.nodes[i] for i in self._overlapped_nodes]
+
+    def __hash__(self):
+        return self.index
+
+    def __eq__(self, other):
+        return self is other
+
+    def __repr__(self):
+        return f"ModelNode({self.index})[{self.interaction_type}]"
+
+    def get_kwargs(self):
+        return dict(index=self.index, type=self.type, interaction_type=self.interaction_type, hotspot_position=self.hotspot_position,
+                    score=self.score, center=self.center, radius=self.radius, neighbor_edge_dict=dict(self._neighbor_edge_dict),
+                    overlapped_nodes=list(self._overlapped_nodes))
+
+
+class ModelEdge:
+    """`pharmacophore_model.py:323-365`."""
+
+    def __init__(self, graph, index, node_indices, edge_type, distance_mean, distance_std):
+        self.graph = graph
+        self.index = int(index)
+        self.node_indices = (int(node_indices[0]), int(node_indices[1]))
+        self.nodes = (graph.nodes[self.node_indices[0]], graph.nodes[self.node_indices[1]])
+        self.type = tuple(edge_type)
+        self.distance_mean = distance_mean
+        self.distance_std = distance_std
+
+    def __hash__(self):
+        return self.index
+
+    def __eq__(self, other):
+        return self is other
+
+    def __repr__(self):
+        return f"ModelEdge({self.node_indices[0]},{self.node_indices[1]})[{self.type[0]},{self.type[1]}]"
+
+    def get_kwargs(self):
+        return dict(index=self.index, node_indices=self.node_indices, edge_type=self.type, distance_mean=self.distance_mean, distance_std=self.distance_std)

@@ -206,6 +206,56 @@ def test_sixteen_pockets_one_library():
     assert np.count_nonzero(ref) > ref.size // 2
 
 
+def test_sixteen_pockets_at_shard_size(oracle):
+    """BASELINE.json configs[3] at the size one GPU of eight holds: 16 distinct pockets x a 1.25 M-ligand shard of the shared
+    library (10 M / 8) through pmx_score_multi - 20 M (pocket, ligand) scores. Size-independent properties (finite,
+    non-negative, every pocket's row equal to scoring that pocket alone on a window of the library) and a sample of every
+    pocket's scores against the CPU oracle."""
+    import ctypes
+
+    import torch
+
+    from pharmaconet_amd import PackedLibrary, PharmacophoreModel, _ffi
+    from pharmaconet_amd.constants import weights_vector
+    from pharmaconet_amd.engine import DeviceLibrary, device_model
+    from pharmaconet_amd.synthetic import BASE_SEED, expand_library_on_device, synthetic_library
+
+    model6, _, _, _ = load_golden("set_6oim_c8")
+    base = synthetic_library(4096, num_conformers=8, model_nodes=_model_nodes(model6), active_fraction=0.1, seed=BASE_SEED, max_nodes=32,
+                             conformer_noise=0.0)
+    offsets, data = expand_library_on_device(base, 306, "cuda", seed=BASE_SEED + 3)
+    lib = DeviceLibrary.from_device_buffers(offsets, data)
+    n = len(lib)
+    assert n == 1_253_376
+    models = [PharmacophoreModel.load(GOLDEN / "pockets16" / f"model_{k:02d}.pm") for k in range(16)]
+    handles = (ctypes.c_void_p * 16)(*[device_model(m).handle for m in models])
+    out = torch.empty(16 * n, dtype=torch.float32, device="cuda")
+    status = torch.empty(n, dtype=torch.int32, device="cuda")
+    w = (ctypes.c_float * 7)(*weights_vector(None))
+    _ffi.check(_ffi.load().pmx_score_multi(handles, 16, lib.handle, w, 0, n, out.data_ptr(), status.data_ptr(), None))
+    torch.cuda.synchronize()
+    scores = out.view(16, n)
+    assert torch.isfinite(scores).all() and (scores >= 0).all() and (status == 0).all()
+    off = offsets.cpu().numpy()
+    dat = data.cpu().numpy()
+    rng = np.random.default_rng(316)
+    worst = 0.0
+    for k, m in enumerate(models):
+        first = int(rng.integers(0, n - 20_000))
+        alone = m.screen(lib, first=first, count=20_000).scores
+        assert torch.equal(alone, scores[k, first:first + 20_000]), f"pocket {k}"
+        pick = np.sort(rng.choice(n, size=48, replace=False))
+        sample = PackedLibrary.from_records([dat[off[i]:off[i + 1]].tobytes() for i in pick])
+        ref = oracle.oracle_score(m.flat, sample, weights_vector(None), num_threads=os.cpu_count() or 8)
+        got = scores[k, torch.from_numpy(pick).cuda()].cpu().numpy().astype(np.float64)
+        zero = ref == 0
+        assert np.all(got[zero] == 0.0)
+        if (~zero).any():
+            worst = max(worst, rel_err(got[~zero], ref[~zero]).max())
+    assert worst < RTOL + 6e-8
+    print(f"16 pockets x {n} ligands: max rel err vs oracle on 16 x 48 samples {worst:.2e}")
+
+
 def test_stress_config_at_full_size(oracle, monkeypatch):
     """BASELINE.json configs[4] at its stated size: the 64-node model, 100 352 ligands x 64 conformers. Size-independent
     properties (finite, non-negative, chunk-invariant, reproducible) and a 512-ligand sample against the CPU oracle; then

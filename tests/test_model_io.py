@@ -96,3 +96,29 @@ def test_too_many_nodes_rejected():
     st["nodes"].append(dict(st["nodes"][0], index=64))
     with pytest.raises(ValueError):
         PharmacophoreModel().__setstate__(st)
+
+
+def test_object_graph_accessors_mirror_the_state():
+    """`model.nodes / .edges / .node_dict / .node_cluster_dict / .node_clusters` (pharmacophore_model.py:191-204,207-365):
+    code written against the reference's object graph keeps working on the drop-in class; `get_kwargs()` of every object
+    gives back its state entry, for `.pm` and `.json` alike (the latter stores dict keys as strings, :279)."""
+    from pharmaconet_amd import PharmacophoreModel
+
+    for name in ("model_6oim_like.pm", "model_6oim_like.json"):
+        m = PharmacophoreModel.load(GOLDEN / name)
+        st = m.__getstate__()
+        assert [n.index for n in m.nodes] == list(range(len(st["nodes"])))
+        assert len(m.edges) == len(st["edges"]) and all(e.nodes == (m.nodes[e.node_indices[0]], m.nodes[e.node_indices[1]]) for e in m.edges)
+        for node, kw in zip(m.nodes, st["nodes"]):
+            assert node.type == kw["type"] and node.interaction_type == kw["interaction_type"]
+            assert {n.index: e.index for n, e in node.neighbor_edge_dict.items()} == {int(k): int(v) for k, v in kw["neighbor_edge_dict"].items()}
+            assert [n.index for n in node.overlapped_nodes] == [int(i) for i in kw["overlapped_nodes"]]
+            for nb, edge in node.neighbor_edge_dict.items():
+                assert set(edge.node_indices) == {node.index, nb.index}
+        assert list(m.node_cluster_dict) == list(st["node_cluster_dict"])
+        flat = [c for lst in m.node_cluster_dict.values() for c in lst]
+        assert m.node_clusters == flat and len(flat) == m.num_clusters
+        for c, kw in zip(flat, [kw for lst in st["node_cluster_dict"].values() for kw in lst]):
+            assert c.type == kw["cluster_type"] and c.node_indices == {int(i) for i in kw["node_indices"]}
+            assert {n.index for n in c.nodes} == c.node_indices and c.node_types == set(kw["node_types"])
+        assert {t: [n.index for n in lst] for t, lst in m.node_dict.items()} == {t: [int(i) for i in v] for t, v in st["node_dict"].items()}

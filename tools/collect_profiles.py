@@ -18,7 +18,7 @@ import os
 
 REPO = Path(__file__).resolve().parents[1]
 PROF = REPO / "profiles"
-TAG = os.environ.get("PMX_PROFILE_TAG", "r2")  # file name prefix: the round the profiles belong to
+TAG = os.environ.get("PMX_PROFILE_TAG", "r3")  # file name prefix: the round the profiles belong to
 
 
 def short(name):
@@ -52,7 +52,7 @@ def main():
         "note": "FETCH_SIZE / WRITE_SIZE in KiB; hbm_bytes_per_ligand = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 / ligands, the read "
                 "side doubled per MI355X_MICROARCH.md (gfx950 reports half of wide coalesced reads; narrow accesses are "
                 "uncalibrated, so the read figure is an upper estimate). The counters see L2 <-> fabric traffic, i.e. they "
-                "include what the 256 MB Infinity Cache serves (the walkers' private totals).",
+                "include what the 256 MB Infinity Cache serves (the per-wavefront table slices).",
         "ligands": n_lig,
         "kernels": {},
     }
@@ -64,11 +64,14 @@ def main():
             "fetch_kib_raw": f, "write_kib": w, "hbm_bytes_per_ligand": (2 * f + w) * 1024 / n_lig,
             "launches": res["FETCH_SIZE"][1][k],
         }
+        for short_name in ("ligand_kernel", "task_kernel"):  # the keys bench.py looks up
+            if short_name in k:
+                out["kernels"][short_name] = out["kernels"][k]
     json.dump(out, open(PROF / f"{TAG}_hbm_traffic.json", "w"), indent=1)
     sq = collections.defaultdict(lambda: collections.defaultdict(float))
     for row in csv.DictReader(open(next(sq_dir.glob("*counter_collection.csv")))):
         k = row["Kernel_Name"]
-        if "pmx::" in k and ("tree_kernel" in k or "tables_kernel" in k or "bounds_kernel" in k or "match_kernel" in k or "coop_kernel" in k):
+        if "pmx::" in k and ("ligand_kernel" in k or "task_kernel" in k):
             sq[short(k).replace("pmx::", "")][row["Counter_Name"]] += float(row["Counter_Value"])
     json.dump({"source": "rocprofv3 --pmc SQ_* (one pass) of bench.py --ligands 200000 --steps 1 --warmup 0; SQ_WAVE_CYCLES, "
                          "SQ_WAIT_* and SQ_ACTIVE_* count quad-cycles", "counters": sq},
