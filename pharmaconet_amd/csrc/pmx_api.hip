@@ -75,7 +75,7 @@ struct pmx_model {
     void *blob;
     uint8_t node_type[PMX_MAX_MODEL_NODES]; // host copy
     // node subsets and tabulated pair functions (pmx_screen.hip)
-    uint32_t NS = 0, ncell = 0;
+    uint32_t NS = 0, NF = 0, ncell = 0;
     float h = 0.f;
     uint16_t *sidtab = nullptr;  // device [K * 128]
     uint64_t *subnodes = nullptr; // device [NS]
@@ -146,30 +146,34 @@ static int build_pair_functions(pmx_model *m, const pmx_model_desc *d, const std
             sidtab[(size_t)a * 128 + mask] = (uint16_t)id;
         }
     const uint32_t NS = (uint32_t)subs.size();
-    // grid: h = the largest power of two <= std_min / 5 (quintic Hermite error < 3e-8 of the peak, measured), range to mean + 7.5 std
+    // grid: h = the largest power of two <= std_min / 4 (quintic Hermite error < 6e-8 of the peak, measured), range to mean + 7 std
     float std_min = 1e30f, dmax = 1.f;
     for (int i = 0; i < Nm * Nm; ++i) {
         std_min = std::min(std_min, d->edge_std[i]);
-        dmax = std::max(dmax, d->edge_mean[i] + 7.5f * d->edge_std[i]);
+        dmax = std::max(dmax, d->edge_mean[i] + 7.0f * d->edge_std[i]);
     }
     if (Nm == 0) std_min = 1.f;
     float h = 0.5f;
-    while (h > std_min / 5.f && h > 1.f / 64.f) h *= 0.5f;
+    while (h > std_min / 4.f && h > 1.f / 64.f) h *= 0.5f;
     const uint32_t ncell = (uint32_t)std::ceil((double)dmax / (double)h) + 1;
-    if (ncell > 16384 || (uint64_t)NS * NS * ncell * sizeof(FnCell) > (2ull << 30))
+    if (ncell > 16384 || (uint64_t)NS * NS * ncell * sizeof(FnCell) > (4ull << 30))
         return fail(PMX_ERR_INVALID, "pair-function tables of this model would take %llu cells x %u x %u subsets", (unsigned long long)ncell, NS, NS);
     // exact pass window of every model edge
     std::vector<float> wlo((size_t)Nm * Nm), whi((size_t)Nm * Nm);
     std::vector<uint8_t> wok((size_t)Nm * Nm);
     for (int i = 0; i < Nm * Nm; ++i) wok[i] = edge_window(d->edge_mean[i], pass_threshold(d->edge_std[i]), wlo[i], whi[i]) ? 1 : 0;
     const float INF = INFINITY;
-    std::vector<float2> win((size_t)NS * NS * ncell);
+    // a symmetric model (edge[m][n] == edge[n][m]: distances are) has F_(A,B) == F_(B,A): the pair (lo, hi) is stored once
+    const bool tri = m->dm.symmetric != 0;
+    const uint32_t NF = tri ? NS * (NS + 1) / 2 : NS * NS;
+    std::vector<float2> win((size_t)NF * ncell);
     uint64_t n_complex = 0;
     std::vector<std::pair<float, int>> ev;
     std::vector<std::pair<float, float>> pass;
     for (uint32_t sa = 0; sa < NS; ++sa)
         for (uint32_t sb = 0; sb < NS; ++sb) {
-            float2 *out = win.data() + ((size_t)sa * NS + sb) * ncell;
+            if (tri && sb > sa) continue;
+            float2 *out = win.data() + (size_t)(tri ? sa * (sa + 1) / 2 + sb : sa * NS + sb) * ncell;
             const uint64_t A = subs[sa], B = subs[sb];
             if (!A || !B) { // no item: never a fail
                 for (uint32_t i = 0; i < ncell; ++i) out[i] = make_float2(-INF, INF);
@@ -220,6 +224,7 @@ static int build_pair_functions(pmx_model *m, const pmx_model_desc *d, const std
     HIPCHECK(hipMemcpy(m->subnodes, subs.data(), (size_t)NS * 8, hipMemcpyHostToDevice));
     HIPCHECK(hipMemcpy(m->win, win.data(), win.size() * sizeof(float2), hipMemcpyHostToDevice));
     m->NS = NS;
+    m->NF = NF;
     m->ncell = ncell;
     m->h = h;
     m->n_complex_cells = n_complex;
@@ -236,7 +241,7 @@ static int pair_functions(pmx_model *m, const Weights &W, hipStream_t stream, Fn
         if (m->fn.size() < 4) {
             m->fn.emplace_back();
             hit = &m->fn.back();
-            HIPCHECK(hipMalloc((void **)&hit->cells, (size_t)m->NS * m->NS * m->ncell * sizeof(FnCell)));
+            HIPCHECK(hipMalloc((void **)&hit->cells, (size_t)m->NF * m->ncell * sizeof(FnCell)));
             HIPCHECK(hipEventCreateWithFlags(&hit->ready, hipEventDisableTiming));
         } else { // recycle the least recently used entry once nothing queued still reads it
             hit = &m->fn[0];
@@ -245,7 +250,7 @@ static int pair_functions(pmx_model *m, const Weights &W, hipStream_t stream, Fn
             HIPCHECK(hipDeviceSynchronize());
         }
         hit->W = W;
-        fn_build_kernel<<<dim3(m->NS * m->NS), dim3(128), 0, stream>>>(m->dm, W, m->subnodes, m->NS, m->ncell, m->h, m->win, hit->cells);
+        fn_build_kernel<<<dim3(m->NF), dim3(128), 0, stream>>>(m->dm, W, m->subnodes, m->NS, m->ncell, m->h, m->win, hit->cells);
         HIPCHECK(hipGetLastError());
         HIPCHECK(hipEventRecord(hit->ready, stream));
     } else {
@@ -254,9 +259,9 @@ static int pair_functions(pmx_model *m, const Weights &W, hipStream_t stream, Fn
     hit->stamp = ++m->fn_stamp;
     out->cells = hit->cells;
     out->NS = m->NS;
+    out->tri = m->dm.symmetric != 0 ? 1u : 0u;
     out->ncell = m->ncell;
     out->inv_h = 1.0f / m->h;
-    out->pad = 0;
     return PMX_OK;
 }
 

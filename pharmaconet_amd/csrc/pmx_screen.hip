@@ -49,7 +49,7 @@ struct FnTable {
     uint32_t NS;         // node subsets (0 = empty)
     uint32_t ncell;
     float inv_h;
-    uint32_t pad;
+    uint32_t tri;        // the functions of a symmetric model are stored once per unordered subset pair
 };
 
 // Header of one ligand's tables, in a wave's slice or in the arena:
@@ -196,7 +196,15 @@ __device__ inline float norm3f(float dx, float dy, float dz) { // np.linalg.norm
 __global__ void fn_build_kernel(DevModel M, Weights W, const uint64_t *subnodes, uint32_t NS, uint32_t ncell, float h,
                                 const float2 *win, FnCell *cells) {
     const uint32_t fid = blockIdx.x;
-    const uint32_t sa = fid / NS, sb = fid - sa * NS;
+    uint32_t sa, sb;
+    if (M.symmetric) { // triangular: fid = sa (sa + 1) / 2 + sb, sb <= sa
+        sa = (uint32_t)((sqrtf(8.f * (float)fid + 1.f) - 1.f) * 0.5f);
+        while ((sa + 1) * (sa + 2) / 2 <= fid) ++sa;
+        while (sa * (sa + 1) / 2 > fid) --sa;
+        sb = fid - sa * (sa + 1) / 2;
+    } else {
+        sa = fid / NS, sb = fid - sa * NS;
+    }
     const uint64_t A = subnodes[sa], B = subnodes[sb];
     const int Nm = M.Nm;
     bool a_nz = false, b_nz = false;
@@ -699,6 +707,14 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
 
 
 // ------------------------------------------------------------------------------------------ table phase
+__device__ __forceinline__ uint32_t fn_index(const FnTable &F, uint32_t sidu, uint32_t sidv) {
+    if (F.tri) {
+        const uint32_t hi = max(sidu, sidv), lo = min(sidu, sidv);
+        return (hi * (hi + 1u) >> 1) + lo;
+    }
+    return sidu * F.NS + sidv;
+}
+
 // One (ligand node, ligand node) item of match_utils.py:26-69 for the subset pair `fid` at distance d: the tabulated sum
 // (already divided by |A||B|) and whether the item fails the majority test of :56-61.
 template <bool EXACT>
@@ -708,7 +724,7 @@ __device__ __forceinline__ void item(const ScreenParams &p, uint32_t sidu, uint3
         const float x = d * p.F.inv_h; // exact: inv_h is a power of two
         const int ci = min((int)x, (int)p.F.ncell - 1);
         const float t = fminf(x - (float)ci, 1.0f);
-        const float4 *cell = reinterpret_cast<const float4 *>(p.F.cells + ((sidu * p.F.NS + sidv) * p.F.ncell + (uint32_t)ci));
+        const float4 *cell = reinterpret_cast<const float4 *>(p.F.cells + (fn_index(p.F, sidu, sidv) * p.F.ncell + (uint32_t)ci));
         const float4 a = cell[0], b = cell[1];
         float v = __builtin_fmaf(t, b.y, b.x);
         v = __builtin_fmaf(t, v, a.w);
@@ -768,7 +784,7 @@ __device__ __forceinline__ ItemLoad item_load(const ScreenParams &p, uint32_t si
     L.t = fminf(x - (float)ci, 1.0f);
     L.d = d;
     L.sidu = sidu, L.sidv = sidv;
-    const float4 *cell = reinterpret_cast<const float4 *>(p.F.cells + ((sidu * p.F.NS + sidv) * p.F.ncell + (uint32_t)ci));
+    const float4 *cell = reinterpret_cast<const float4 *>(p.F.cells + (fn_index(p.F, sidu, sidv) * p.F.ncell + (uint32_t)ci));
     L.a = cell[0];
     L.b = cell[1];
     return L;
