@@ -255,11 +255,14 @@ __global__ void fn_build_kernel(DevModel M, Weights W, const uint64_t *subnodes,
 }
 
 // ------------------------------------------------------------------------------------------- LDS of a wave
+// Frames nl - 3 .. nl - 2 - kTcLevels keep their children's totals in LDS: when the walker comes back to such a frame the
+// remaining candidates are taken from there instead of being evaluated again (a third of all passes were re-evaluations).
+constexpr int kTcLevels = 4;
 template <int G>
 struct WaveShape {
     uint32_t kp;     // candidates per level, padded
     uint32_t nc_cap; // node-candidate entries
-    uint32_t off_cand, off_lcnt, off_nc, off_tot, off_pool, off_stat, off_task, off_tch, bytes;
+    uint32_t off_cand, off_lcnt, off_nc, off_tot, off_pool, off_stat, off_task, off_tch, off_tc, bytes;
 };
 template <int G>
 __host__ __device__ inline WaveShape<G> wave_shape(int K, int max_nodes) {
@@ -286,6 +289,8 @@ __host__ __device__ inline WaveShape<G> wave_shape(int K, int max_nodes) {
     o = (o + 15u) & ~15u;
     w.off_tch = o; // totals of a frame's children (fused last two levels)
     o += 64 * 8;
+    w.off_tc = o; // the children's totals of the kTcLevels deepest unfused frames + their validity ballots
+    o += kTcLevels * (64 * 8 + 8);
     w.bytes = o;
     return w;
 }
@@ -339,7 +344,7 @@ __host__ __device__ constexpr uint64_t group_mask() {
     return G >= 64 ? ~0ull : ((1ull << (G & 63)) - 1ull);
 }
 
-constexpr unsigned kMatched = 1, kAny = 2, kSkipped = 4;
+constexpr unsigned kMatched = 1, kAny = 2, kSkipped = 4, kCached = 8;
 constexpr double kBoundSlack = 1.0 + 1e-9; // covers the float64 rounding of the sums the bound is compared with
 
 // Can the child (frame f, candidate `cand`, conformer mask `cmask`) of the current frame, which holds nm matches, still
@@ -438,7 +443,7 @@ __device__ __forceinline__ bool probe(Walk<G> &w, int f, int nm, int cand, uint6
 }
 
 template <int G>
-__device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *tot, unsigned long long *pool, uint16_t *pathbuf, double *tch,
+__device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *tot, unsigned long long *pool, uint16_t *pathbuf, double *tch, double *tc,
                                     uint32_t rec16 /* arena record of the job (exports refer to it) */, bool export_mode,
                                     unsigned long long budget, uint32_t wave_id) {
     constexpr int SLOTS = 64 / G;
@@ -480,29 +485,47 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
             while (nb < kf) {
                 const int b = nb + s;
                 const bool on = b < kf;
-                const uint32_t bo = on ? lane_off : (uint32_t)c * 4u; // idle slots read candidate nb (in bounds)
-                const float self = *reinterpret_cast<const float *>(Sb + (((uint32_t)(ksf + nb) << PSH) + bo));
-                float lo = 1.f; // smallest pair entry: the candidate is valid for this conformer iff every entry is > 0 (tree.py:81)
-                double sum = 0.0;
-                int q = 0;
-                for (; q + 4 <= nm; q += 4) {
-                    float v[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float *>(Pb + (((uint32_t)(rl(ebv, q + u) + nb) << PSH) + bo));
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        lo = fminf(lo, v[u]);
-                        sum += (double)v[u];
+                double t;
+                bool valid;
+                // cache slot of this frame: the kTcLevels frames above the fused one, one pass wide
+                const int tci = nl - 3 - f;
+                const bool cacheable = tci >= 0 && tci < kTcLevels && kf <= SLOTS && !(p.flags & 64);
+                if (cacheable && (flags & kCached)) { // back from a child: the remaining candidates as evaluated on the way in
+                    const unsigned long long vb0 = *reinterpret_cast<const unsigned long long *>(tc + kTcLevels * 64 + tci);
+                    const int src = lane + nb * G;
+                    t = tc[tci * 64 + (on ? src : lane)];
+                    valid = on && ((uni64(vb0) >> src) & 1ull);
+                } else {
+                    const uint32_t bo = on ? lane_off : (uint32_t)c * 4u; // idle slots read candidate nb (in bounds)
+                    const float self = *reinterpret_cast<const float *>(Sb + (((uint32_t)(ksf + nb) << PSH) + bo));
+                    float lo = 1.f; // smallest pair entry: the candidate is valid for this conformer iff every entry is > 0 (tree.py:81)
+                    double sum = 0.0;
+                    int q = 0;
+                    for (; q + 4 <= nm; q += 4) {
+                        float v[4];
+    #pragma unroll
+                        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float *>(Pb + (((uint32_t)(rl(ebv, q + u) + nb) << PSH) + bo));
+    #pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            lo = fminf(lo, v[u]);
+                            sum += (double)v[u];
+                        }
+                    }
+                    for (; q < nm; ++q) {
+                        const float v = *reinterpret_cast<const float *>(Pb + (((uint32_t)(rl(ebv, q) + nb) << PSH) + bo));
+                        lo = fminf(lo, v);
+                        sum += (double)v;
+                    }
+                    // (v_min_f32 skips a NaN entry - a zero-weight pair, match_utils.py:50-52 - but the sum does not: NaN is not > 0)
+                    valid = on && ((mask >> c) & 1ull) && lo > 0.f && sum == sum;
+                    t = (tparent + (double)self) + sum; // parent + self + accumulated pair (tree.py:38-41)
+                    if (cacheable && nb == 0) { // first pass of the frame
+                        tc[tci * 64 + lane] = t;
+                        const unsigned long long vb0 = __ballot(valid);
+                        if (lane == 0) *reinterpret_cast<unsigned long long *>(tc + kTcLevels * 64 + tci) = vb0;
+                        flags |= kCached;
                     }
                 }
-                for (; q < nm; ++q) {
-                    const float v = *reinterpret_cast<const float *>(Pb + (((uint32_t)(rl(ebv, q) + nb) << PSH) + bo));
-                    lo = fminf(lo, v);
-                    sum += (double)v;
-                }
-                // (v_min_f32 skips a NaN entry - a zero-weight pair, match_utils.py:50-52 - but the sum does not: NaN is not > 0)
-                const bool valid = on && ((mask >> c) & 1ull) && lo > 0.f && sum == sum;
-                const double t = (tparent + (double)self) + sum; // parent + self + accumulated pair (tree.py:38-41)
                 const unsigned long long vb = __ballot(valid);
                 ++w.passes;
                 if (vb) flags |= kAny;
@@ -1272,11 +1295,12 @@ __device__ __forceinline__ void run_job(const ScreenParams &p, unsigned char *ld
     unsigned long long *pool = reinterpret_cast<unsigned long long *>(lds + ws.off_pool);
     uint16_t *pathbuf = reinterpret_cast<uint16_t *>(lds + kOffPath);
     double *tch = reinterpret_cast<double *>(lds + ws.off_tch);
+    double *tc = reinterpret_cast<double *>(lds + ws.off_tc);
     const unsigned long long t_d = __builtin_amdgcn_s_memtime();
     unsigned long long budget = ((p.flags & 2) || p.last_round) ? ~0ull : (unsigned long long)p.budget;
     bool export_mode = false, split = is_task;
     for (;;) {
-        const int rc = walk<G>(w, p, tot, pool, pathbuf, tch, rec16, export_mode, budget, wave_id);
+        const int rc = walk<G>(w, p, tot, pool, pathbuf, tch, tc, rec16, export_mode, budget, wave_id);
         if (rc != kOverBudget) break;
         if (lane == 0) ++stat->over;
         budget = ~0ull;
