@@ -122,6 +122,8 @@ struct Ctl {
     uint32_t round_lo[kShards], round_hi[kShards]; // the records of the current round (round_kernel)
     uint32_t round_total, task_cursor;
     uint32_t pad[2];
+    uint32_t xcd_cursor[8][16];   // task cursors of the round, one per group of 8 shards (one 64-byte line each)
+    uint32_t round_inc[kShards];  // records of the round in shards 0 .. s (task number -> shard)
     unsigned long long stats[kScreenStatShards][kStatWords]; // sharded: [0] frames [1] passes [2] walks over budget [3] items [4] exact-count cells [5] longest walk [6] tasks [7] slice overflows [8..12] phase ticks
 };
 
@@ -598,20 +600,25 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
                         if (!deep) slot_alive = slot_alive && s == first_ss;
                         const unsigned long long heads = __ballot(slot_alive && c == 0);
                         const uint32_t n = (uint32_t)__popcll(heads);
-                        const uint32_t sh = (wave_id + (uint32_t)(w.passes >> 4)) & (kShards - 1);
-                        uint32_t base = 0xffffffffu;
-                        if (lane == 0) {
-                            uint32_t r = p.ctl->q_res[sh];
-                            while (r + n <= p.qcap) {
-                                const uint32_t old = atomicCAS(&p.ctl->q_res[sh], r, r + n);
-                                if (old == r) {
-                                    base = r;
-                                    break;
-                                }
-                                r = old;
-                            }
-                        }
+                        // all subtrees of a ligand go to one shard, and the task wavefronts of one XCD drain one group of
+                        // shards (task_kernel): the walkers that share a ligand's tables run side by side under one L2
+                        const uint32_t sh = (p.flags & 256) ? ((wave_id + (uint32_t)(w.passes >> 4)) & (kShards - 1)) : ((rec16 * 2654435761u) >> 26);
+                        static_assert(kShards == 64, "shard hash");
+                        // one atomic add reserves the records (no retry loop: the walkers of one ligand export to one shard at
+                        // the same time); a reservation that crosses the end of the shard fills its part below the end
+                        // with empty subtrees of this ligand (no conformer: prepare_walk drops them)
+                        uint32_t base = 0;
+                        if (lane == 0) base = atomicAdd(&p.ctl->q_res[sh], n);
                         base = (uint32_t)uni((int)base);
+                        if (base + n > p.qcap) {
+                            for (uint32_t i = base + (uint32_t)lane; i < p.qcap; i += 64u) {
+                                uint32_t *nr = reinterpret_cast<uint32_t *>(p.queue + ((size_t)sh * p.qcap + i) * task_rec_bytes<G>());
+                                for (uint32_t wd = 0; wd < task_rec_bytes<G>() / 4; ++wd) nr[wd] = 0u;
+                                nr[0] = rec16;
+                                nr[1] = (uint32_t)(f + 1) | (5u << 8); // f0, nm
+                            }
+                            base = 0xffffffffu;
+                        }
                         if (base != 0xffffffffu) {
                             if (lane < nm) pathbuf[lane] = (uint16_t)(((w.matKA >> 16) & 255) | (((w.matKA >> 8) & 255) << 8));
                             lds_sync();
@@ -1427,14 +1434,21 @@ __global__ __launch_bounds__(64, PMX_SCREEN_WAVES) void ligand_kernel(const Scre
 __global__ void round_kernel(Ctl *ctl, uint32_t qcap) {
     const int lane = threadIdx.x & 63;
     const uint32_t lo = ctl->round_hi[lane], hi = min(ctl->q_res[lane], qcap);
-    uint32_t n = hi - lo;
+    uint32_t n = hi - lo, inc = n;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(inc, d);
+        if (lane >= d) inc += t;
+    }
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) n += __shfl_xor(n, d);
     ctl->round_lo[lane] = lo;
     ctl->round_hi[lane] = hi;
+    ctl->round_inc[lane] = inc;
     if (lane == 0) {
         ctl->round_total = n;
         ctl->task_cursor = 0;
+        for (int x = 0; x < 8; ++x) ctl->xcd_cursor[x][0] = 0;
         ctl->stats[0][6] += n; // subtrees of the call (this kernel is alone on the stream)
     }
 }
@@ -1456,23 +1470,32 @@ __global__ __launch_bounds__(64, PMX_TASK_WAVES) void task_kernel(const ScreenPa
     if (lane0 < 16) reinterpret_cast<unsigned long long *>(stat)[lane0] = 0ull;
     wave_sync();
     const unsigned long long t_start = __builtin_amdgcn_s_memtime();
-    // task number -> (shard, record): inclusive scan of the shards' record counts over the lanes
-    const uint32_t lo_l = p.ctl->round_lo[lane0], cnt_l = p.ctl->round_hi[lane0] - lo_l;
-    uint32_t inc = cnt_l;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t t = __shfl_up(inc, d);
-        if (lane0 >= d) inc += t;
-    }
+    // Task number -> (shard, record) through the inclusive counts round_kernel left. Shards 8x .. 8x + 7 (a contiguous range
+    // of task numbers) belong to XCD x - block b runs on XCD b % 8 on this part, which only matters for speed: a wavefront
+    // takes from its own group until it is empty, then from the next ones. (Nothing of this stays in registers over a walk.)
+    uint32_t skip = 0;
     for (;;) {
         const int lane = lane_id();
-        uint32_t nx = 0;
-        if (lane == 0) nx = atomicAdd(&p.ctl->task_cursor, 1u);
-        nx = (uint32_t)uni((int)nx);
-        if (nx >= total) break;
+        const uint32_t inc = p.ctl->round_inc[lane];
+        uint32_t nx = 0xffffffffu;
+        while (skip < 8) {
+            const int xx = (int)((blockIdx.x + skip) & 7u);
+            const uint32_t st = xx ? (uint32_t)rl((int)inc, 8 * xx - 1) : 0u, en = (uint32_t)rl((int)inc, 8 * xx + 7);
+            if (st < en) {
+                uint32_t cur = 0;
+                if (lane == 0) cur = atomicAdd(&p.ctl->xcd_cursor[xx][0], 1u);
+                cur = (uint32_t)uni((int)cur);
+                if (cur < en - st) {
+                    nx = st + cur;
+                    break;
+                }
+            }
+            ++skip;
+        }
+        if (nx == 0xffffffffu) break;
         const int sh = __popcll(__ballot(nx >= inc)); // shards wholly before task nx (inc is non-decreasing)
         const uint32_t before = sh ? (uint32_t)rl((int)inc, sh - 1) : 0u;
-        const uint32_t recno = (uint32_t)rl((int)lo_l, sh) + (nx - before);
+        const uint32_t recno = (uint32_t)uni((int)p.ctl->round_lo[sh]) + (nx - before);
         const unsigned char *tr = p.queue + ((size_t)sh * p.qcap + recno) * task_rec_bytes<G>();
         if (lane == 0) ++stat->tasks;
         unsigned char *rec = p.arena + (size_t)(uint32_t)uni((int)reinterpret_cast<const TaskRec *>(tr)->rec16) * 16;
