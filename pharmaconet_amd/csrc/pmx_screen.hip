@@ -259,7 +259,10 @@ __global__ void fn_build_kernel(DevModel M, Weights W, const uint64_t *subnodes,
 // ------------------------------------------------------------------------------------------- LDS of a wave
 // Frames nl - 3 .. nl - 2 - kTcLevels keep their children's totals in LDS: when the walker comes back to such a frame the
 // remaining candidates are taken from there instead of being evaluated again (a third of all passes were re-evaluations).
-constexpr int kTcLevels = 4;
+#ifndef PMX_TC_LEVELS
+#define PMX_TC_LEVELS 4
+#endif
+constexpr int kTcLevels = PMX_TC_LEVELS;
 template <int G>
 struct WaveShape {
     uint32_t kp;     // candidates per level, padded
