@@ -338,10 +338,8 @@ struct Walk {
     uint32_t frames = 0, passes = 0;
     uint32_t exported = 0, probes = 0;
     uint32_t probe_passes = 0;
-    // current frame (kept here so that a walk can be interrupted and resumed, see kOverBudget)
-    int f = 0, f0 = 0, nm = 0, nb = 0, mx = 0;
-    unsigned flags = 0;
-    uint64_t mask = 0;
+    // current frame (its state is in lane f of the stack like every other frame's; a walk can be interrupted and resumed, see kOverBudget)
+    int f = 0, f0 = 0;
 };
 constexpr int kOverBudget = -1;
 template <int G>
@@ -349,7 +347,7 @@ __host__ __device__ constexpr uint64_t group_mask() {
     return G >= 64 ? ~0ull : ((1ull << (G & 63)) - 1ull);
 }
 
-constexpr unsigned kMatched = 1, kAny = 2, kSkipped = 4, kCached = 8;
+constexpr unsigned kMatched = 1, kAny = 2, kSkipped = 4, kCached = 8, kFused = 16;
 constexpr double kBoundSlack = 1.0 + 1e-9; // covers the float64 rounding of the sums the bound is compared with
 
 // Can the child (frame f, candidate `cand`, conformer mask `cmask`) of the current frame, which holds nm matches, still
@@ -463,202 +461,214 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
 
     const uint32_t budget32 = budget > 0xfffffff0ull ? 0xffffffffu : (uint32_t)budget; // (a walk of 2^32 passes does not end in this life)
     const int f0 = w.f0;
-    int f = w.f, nm = w.nm, nb = w.nb, mx = w.mx;
-    unsigned flags = w.flags;
-    uint64_t mask = w.mask;
+    // The only scalar carried from one iteration to the next is the frame number: every frame's state - the current one's
+    // too - lives in lane f of stA / stB / stC and is read at the top of an iteration and written back at its end. (With the
+    // current frame in scalars of its own, a third of the walker's instructions were copies between registers where the many
+    // paths of the loop meet.) One iteration = one pass over the frame's next candidates, or the end of the frame.
+    int f = w.f;
     int ret = 0;
     for (;;) {
         if (!export_mode && w.passes > budget32) { // over budget: the caller moves the job's tables to the arena and resumes in export mode
-            w.f = f, w.nm = nm, w.nb = nb, w.mx = mx, w.flags = flags, w.mask = mask;
+            w.f = f;
             return kOverBudget;
         }
+        const int sc = rl(w.stC, f);
+        int nb = sc & 255, mx = (sc >> 8) & 255;
+        unsigned flags = (unsigned)(sc >> 16) & 255u;
+        const int nm = (sc >> 24) & 255;
+        uint64_t mask = (uint64_t)(uint32_t)rl(w.stA, f);
+        if (G > 32) mask |= (uint64_t)(uint32_t)rl(w.stB, f) << 32;
         const int kf = rl(w.hk, f), ksf = rl(w.hks, f);
         const bool leaf_level = f == nl - 1;
-        bool descended = false, fused_any = false;
-        const double tparent = tot[nm * G + c];
-        // the bound row and the pooled maxima go out with the table loads (one memory round trip per pass, not two); frames
-        // f < nl only, so row f + 1 exists
-        const bool bounded = nm >= 4 && !leaf_level && !no_bound;
-        double rbound = 0.0, pooled = 0.0;
-        if (bounded) {
-            rbound = *reinterpret_cast<const double *>(Rb + (((uint32_t)(f + 1) << (PSH + 1)) + 8u * (uint32_t)c));
-            pooled = __longlong_as_double((long long)pool[c]);
-        }
         if (nb < kf) {
+            // ---------------------------------------------------------------- one pass over candidates nb .. nb + SLOTS - 1
+            const double tparent = tot[nm * G + c];
+            // the bound row and the pooled maxima go out with the table loads (one memory round trip per pass, not two); frames
+            // f < nl only, so row f + 1 exists
+            const bool bounded = nm >= 4 && !leaf_level && !no_bound;
+            double rbound = 0.0, pooled = 0.0;
+            if (bounded) {
+                rbound = *reinterpret_cast<const double *>(Rb + (((uint32_t)(f + 1) << (PSH + 1)) + 8u * (uint32_t)c));
+                pooled = __longlong_as_double((long long)pool[c]);
+            }
             // pair-table rows of the matched ancestors against level f: lane q
             const int ebv = w.matRB + __mul24(w.matKA & 255, ksf) + __mul24((w.matKA >> 8) & 255, kf);
-            while (nb < kf) {
-                const int b = nb + s;
-                const bool on = b < kf;
-                double t;
-                bool valid;
-                // cache slot of this frame: the kTcLevels frames above the fused one, one pass wide
-                const int tci = nl - 3 - f;
-                const bool cacheable = tci >= 0 && tci < kTcLevels && kf <= SLOTS && !(p.flags & 64);
-                if (cacheable && (flags & kCached)) { // back from a child: the remaining candidates as evaluated on the way in
-                    const unsigned long long vb0 = *reinterpret_cast<const unsigned long long *>(tc + kTcLevels * 64 + tci);
-                    const int src = lane + nb * G;
-                    t = tc[tci * 64 + (on ? src : lane)];
-                    valid = on && ((uni64(vb0) >> src) & 1ull);
-                } else {
-                    const uint32_t bo = on ? lane_off : (uint32_t)c * 4u; // idle slots read candidate nb (in bounds)
-                    const float self = *reinterpret_cast<const float *>(Sb + (((uint32_t)(ksf + nb) << PSH) + bo));
-                    float lo = 1.f; // smallest pair entry: the candidate is valid for this conformer iff every entry is > 0 (tree.py:81)
-                    double sum = 0.0;
-                    int q = 0;
-                    for (; q + 4 <= nm; q += 4) {
-                        float v[4];
-    #pragma unroll
-                        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float *>(Pb + (((uint32_t)(rl(ebv, q + u) + nb) << PSH) + bo));
-    #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            lo = fminf(lo, v[u]);
-                            sum += (double)v[u];
-                        }
-                    }
-                    for (; q < nm; ++q) {
-                        const float v = *reinterpret_cast<const float *>(Pb + (((uint32_t)(rl(ebv, q) + nb) << PSH) + bo));
-                        lo = fminf(lo, v);
-                        sum += (double)v;
-                    }
-                    // (v_min_f32 skips a NaN entry - a zero-weight pair, match_utils.py:50-52 - but the sum does not: NaN is not > 0)
-                    valid = on && ((mask >> c) & 1ull) && lo > 0.f && sum == sum;
-                    t = (tparent + (double)self) + sum; // parent + self + accumulated pair (tree.py:38-41)
-                    if (cacheable && nb == 0) { // first pass of the frame
-                        tc[tci * 64 + lane] = t;
-                        const unsigned long long vb0 = __ballot(valid);
-                        if (lane == 0) *reinterpret_cast<unsigned long long *>(tc + kTcLevels * 64 + tci) = vb0;
-                        flags |= kCached;
+            const int b = nb + s;
+            const bool on = b < kf;
+            double t;
+            bool valid;
+            // cache slot of this frame: the kTcLevels frames above the fused one, one pass wide
+            const int tci = nl - 3 - f;
+            const bool cacheable = tci >= 0 && tci < kTcLevels && kf <= SLOTS && !(p.flags & 64);
+            if (cacheable && (flags & kCached)) { // back from a child: the remaining candidates as evaluated on the way in
+                const unsigned long long vb0 = *reinterpret_cast<const unsigned long long *>(tc + kTcLevels * 64 + tci);
+                const int src = lane + nb * G;
+                t = tc[tci * 64 + (on ? src : lane)];
+                valid = on && ((uni64(vb0) >> src) & 1ull);
+            } else {
+                const uint32_t bo = on ? lane_off : (uint32_t)c * 4u; // idle slots read candidate nb (in bounds)
+                const float self = *reinterpret_cast<const float *>(Sb + (((uint32_t)(ksf + nb) << PSH) + bo));
+                float lo = 1.f; // smallest pair entry: the candidate is valid for this conformer iff every entry is > 0 (tree.py:81)
+                double sum = 0.0;
+                int q = 0;
+                for (; q + 4 <= nm; q += 4) {
+                    float v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float *>(Pb + (((uint32_t)(rl(ebv, q + u) + nb) << PSH) + bo));
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        lo = fminf(lo, v[u]);
+                        sum += (double)v[u];
                     }
                 }
-                const unsigned long long vb = __ballot(valid);
-                ++w.passes;
-                if (vb) flags |= kAny;
-                if (leaf_level) {
-                    if (valid && t > w.best) w.best = t; // graph_match.py:105-108
-                    nb += SLOTS;
-                    continue;
+                for (; q < nm; ++q) {
+                    const float v = *reinterpret_cast<const float *>(Pb + (((uint32_t)(rl(ebv, q) + nb) << PSH) + bo));
+                    lo = fminf(lo, v);
+                    sum += (double)v;
                 }
-                unsigned long long ab = vb;
-                if (bounded && vb) { // the children hold >= 5 matches: drop those that cannot raise a maximum
-                    const double bp = pooled > w.best ? pooled : w.best;
-                    ab = __ballot(valid && (t + rbound) * kBoundSlack > bp);
+                // (v_min_f32 skips a NaN entry - a zero-weight pair, match_utils.py:50-52 - but the sum does not: NaN is not > 0)
+                valid = on && ((mask >> c) & 1ull) && lo > 0.f && sum == sum;
+                t = (tparent + (double)self) + sum; // parent + self + accumulated pair (tree.py:38-41)
+                if (cacheable && nb == 0) { // first pass of the frame
+                    tc[tci * 64 + lane] = t;
+                    const unsigned long long vb0 = __ballot(valid);
+                    if (lane == 0) *reinterpret_cast<unsigned long long *>(tc + kTcLevels * 64 + tci) = vb0;
+                    flags |= kCached;
                 }
-                if (f == nl - 2 && rl(w.hk, f + 1) <= SLOTS && !(p.flags & 32)) {
-                    // The children of this frame are frames of the last level, whose children are leaves: finish all of them here.
-                    // Lane (s', c) takes leaf candidate s' of level f + 1; what a leaf's total and validity owe to the path above
-                    // this frame is computed once, then every surviving child b of this pass adds its own pair entry:
-                    //   total(b, b') = (total(b) + S[f + 1][b']) + (sum_q P[q -> (f + 1, b')] + P[(f, b) -> (f + 1, b')])   (tree.py:38-41)
-                    // in the reference's order (the child is the deepest ancestor, so its entry comes last).
-                    if (ab) {
-                        const int f1 = f + 1, k1 = rl(w.hk, f1), ks1 = rl(w.hks, f1);
-                        tch[lane] = t; // the children's totals, read back per child by every slot
-                        const int ebv1 = w.matRB + __mul24(w.matKA & 255, ks1) + __mul24((w.matKA >> 8) & 255, k1);
-                        const bool on1 = s < k1;
-                        const uint32_t bo1 = on1 ? lane_off : (uint32_t)c * 4u;
-                        const float self1 = *reinterpret_cast<const float *>(Sb + (((uint32_t)ks1 << PSH) + bo1));
-                        bool base_valid = on1;
-                        double base_sum = 0.0;
-                        for (int q = 0; q < nm; ++q) {
-                            const float v = *reinterpret_cast<const float *>(Pb + (((uint32_t)rl(ebv1, q)) << PSH) + bo1);
-                            base_valid = base_valid && v > 0.f;
-                            base_sum += (double)v;
-                        }
-                        // entry((f, b) -> (f + 1, b')) = rowbase[f] + b * k1 + b'
-                        const uint32_t row_f = (uint32_t)rl(w.hrow, f);
-                        lds_sync();
-                        unsigned long long left = ab;
-                        while (left) {
-                            const int sb = (__ffsll(left) - 1) / G;
-                            left &= ~(GM << (sb * G));
-                            const uint64_t cm = (vb >> (sb * G)) & GM;
-                            const double tb = tch[sb * G + c];
-                            const float pfb = *reinterpret_cast<const float *>(Pb + ((row_f + (uint32_t)(nb + sb) * (uint32_t)k1) << PSH) + bo1);
-                            const bool v1 = base_valid && pfb > 0.f && ((cm >> c) & 1ull);
-                            const double t1 = (tb + (double)self1) + (base_sum + (double)pfb);
-                            const bool any1 = __ballot(v1) != 0;
-                            if (v1 && t1 > w.best) w.best = t1;                                             // leaves (graph_match.py:105-108)
-                            if ((!any1 || nm < 3) && ((cm >> c) & 1ull) && tb > w.best) w.best = tb;        // the child's skip leaf (tree.py:98-101)
-                            const int r1 = 1 + (any1 ? 1 : 0);
-                            mx = mx > r1 ? mx : r1;
-                            ++w.frames;
-                        }
-                        w.passes += 1;
-                    }
-                    if (vb) mx = mx > 1 ? mx : 1; // (children dropped by the bound test return at least 1)
-                    nb += SLOTS;
-                    fused_any = true;
-                    continue;
-                }
+            }
+            const unsigned long long vb = __ballot(valid);
+            ++w.passes;
+            if (vb) flags |= kAny;
+            bool done = false; // the pass is over and the walker stays in this frame
+            if (leaf_level) {
+                if (valid && t > w.best) w.best = t; // graph_match.py:105-108
+                nb += SLOTS;
+                done = true;
+            }
+            unsigned long long ab = vb;
+            if (!done && bounded && vb) { // the children hold >= 5 matches: drop those that cannot raise a maximum
+                const double bp = pooled > w.best ? pooled : w.best;
+                ab = __ballot(valid && (t + rbound) * kBoundSlack > bp);
+            }
+            if (!done && f == nl - 2 && rl(w.hk, f + 1) <= SLOTS && !(p.flags & 32)) {
+                // The children of this frame are frames of the last level, whose children are leaves: finish all of them here.
+                // Lane (s', c) takes leaf candidate s' of level f + 1; what a leaf's total and validity owe to the path above
+                // this frame is computed once, then every surviving child b of this pass adds its own pair entry:
+                //   total(b, b') = (total(b) + S[f + 1][b']) + (sum_q P[q -> (f + 1, b')] + P[(f, b) -> (f + 1, b')])   (tree.py:38-41)
+                // in the reference's order (the child is the deepest ancestor, so its entry comes last).
                 if (ab) {
-                    if (export_mode && nl - (f + 1) >= (int)p.min_levels) {
-                        // Over budget: hand the surviving children of this pass to the task queue - one reservation, one record
-                        // per slot. Children with >= 5 matches count as "returned >= 1" (see above). Below that the frame needs
-                        // to know whether a child reaches 5 matches (tree.py:98), which probe() answers: only the first
-                        // surviving child is handed over then, and this frame's max_num_matches is raised to 5 - nm if
-                        // the child can get there (what it returns beyond that changes no decision anywhere).
-                        const bool deep = nm >= 4;
-                        const int first_ss = (__ffsll(ab) - 1) / G;
-                        bool slot_alive = ((ab >> (s * G)) & GM) != 0;
-                        if (!deep) slot_alive = slot_alive && s == first_ss;
-                        const unsigned long long heads = __ballot(slot_alive && c == 0);
-                        const uint32_t n = (uint32_t)__popcll(heads);
-                        // all subtrees of a ligand go to one shard, and the task wavefronts of one XCD drain one group of
-                        // shards (task_kernel): the walkers that share a ligand's tables run side by side under one L2
-                        const uint32_t sh = (p.flags & 256) ? ((wave_id + (uint32_t)(w.passes >> 4)) & (kShards - 1)) : ((rec16 * 2654435761u) >> 26);
-                        static_assert(kShards == 64, "shard hash");
-                        // one atomic add reserves the records (no retry loop: the walkers of one ligand export to one shard at
-                        // the same time); a reservation that crosses the end of the shard fills its part below the end
-                        // with empty subtrees of this ligand (no conformer: prepare_walk drops them)
-                        uint32_t base = 0;
-                        if (lane == 0) base = atomicAdd(&p.ctl->q_res[sh], n);
-                        base = (uint32_t)uni((int)base);
-                        if (base + n > p.qcap) {
-                            for (uint32_t i = base + (uint32_t)lane; i < p.qcap; i += 64u) {
-                                uint32_t *nr = reinterpret_cast<uint32_t *>(p.queue + ((size_t)sh * p.qcap + i) * task_rec_bytes<G>());
-                                for (uint32_t wd = 0; wd < task_rec_bytes<G>() / 4; ++wd) nr[wd] = 0u;
-                                nr[0] = rec16;
-                                nr[1] = (uint32_t)(f + 1) | (5u << 8); // f0, nm
-                            }
-                            base = 0xffffffffu;
-                        }
-                        if (base != 0xffffffffu) {
-                            if (lane < nm) pathbuf[lane] = (uint16_t)(((w.matKA >> 16) & 255) | (((w.matKA >> 8) & 255) << 8));
-                            lds_sync();
-                            if (slot_alive) {
-                                const uint32_t rank = (uint32_t)__popcll(heads & ((1ull << (s * G)) - 1ull));
-                                unsigned char *tr = p.queue + ((size_t)sh * p.qcap + base + rank) * task_rec_bytes<G>();
-                                TaskRec *th = reinterpret_cast<TaskRec *>(tr);
-                                if (c == 0) {
-                                    th->rec16 = rec16;
-                                    th->f0 = (uint8_t)(f + 1);
-                                    th->nm = (uint8_t)(nm + 1);
-                                    th->pad = 0;
-                                    th->mask = (vb >> (s * G)) & GM;
-                                }
-                                const uint32_t mine = (uint32_t)f | ((uint32_t)(nb + s) << 8); // this slot's own match, entry nm
-                                for (int wd = c; wd < PMX_MAX_LEVELS / 2; wd += G) { // two path entries per 32-bit word
-                                    const int q0 = 2 * wd, q1 = 2 * wd + 1;
-                                    const uint32_t e0 = q0 < nm ? pathbuf[q0] : (q0 == nm ? mine : 0u);
-                                    const uint32_t e1 = q1 < nm ? pathbuf[q1] : (q1 == nm ? mine : 0u);
-                                    reinterpret_cast<uint32_t *>(th->path)[wd] = e0 | (e1 << 16);
-                                }
-                                reinterpret_cast<double *>(tr + sizeof(TaskRec))[c] = t;
-                            }
-                            w.exported += n;
-                            if (deep) {
-                                mx = mx > 1 ? mx : 1; // children given away (or dropped) return at least 1
-                                nb += SLOTS;
-                            } else {
-                                const bool reach = probe<G>(w, f, nm, nb + first_ss, (vb >> (first_ss * G)) & GM, w.probe_passes);
-                                ++w.probes;
-                                if (reach) mx = mx > 5 - nm ? mx : 5 - nm;
-                                nb = nb + first_ss + 1;
-                            }
-                            continue;
-                        }
-                        if (lane == 0) p.ctl->qflag = 1; // shard full: walk the subtree here
+                    const int f1 = f + 1, k1 = rl(w.hk, f1), ks1 = rl(w.hks, f1);
+                    tch[lane] = t; // the children's totals, read back per child by every slot
+                    const int ebv1 = w.matRB + __mul24(w.matKA & 255, ks1) + __mul24((w.matKA >> 8) & 255, k1);
+                    const bool on1 = s < k1;
+                    const uint32_t bo1 = on1 ? lane_off : (uint32_t)c * 4u;
+                    const float self1 = *reinterpret_cast<const float *>(Sb + (((uint32_t)ks1 << PSH) + bo1));
+                    bool base_valid = on1;
+                    double base_sum = 0.0;
+                    for (int q = 0; q < nm; ++q) {
+                        const float v = *reinterpret_cast<const float *>(Pb + (((uint32_t)rl(ebv1, q)) << PSH) + bo1);
+                        base_valid = base_valid && v > 0.f;
+                        base_sum += (double)v;
                     }
+                    // entry((f, b) -> (f + 1, b')) = rowbase[f] + b * k1 + b'
+                    const uint32_t row_f = (uint32_t)rl(w.hrow, f);
+                    lds_sync();
+                    unsigned long long left = ab;
+                    while (left) {
+                        const int sb = (__ffsll(left) - 1) / G;
+                        left &= ~(GM << (sb * G));
+                        const uint64_t cm = (vb >> (sb * G)) & GM;
+                        const double tb = tch[sb * G + c];
+                        const float pfb = *reinterpret_cast<const float *>(Pb + ((row_f + (uint32_t)(nb + sb) * (uint32_t)k1) << PSH) + bo1);
+                        const bool v1 = base_valid && pfb > 0.f && ((cm >> c) & 1ull);
+                        const double t1 = (tb + (double)self1) + (base_sum + (double)pfb);
+                        const bool any1 = __ballot(v1) != 0;
+                        if (v1 && t1 > w.best) w.best = t1;                                             // leaves (graph_match.py:105-108)
+                        if ((!any1 || nm < 3) && ((cm >> c) & 1ull) && tb > w.best) w.best = tb;        // the child's skip leaf (tree.py:98-101)
+                        const int r1 = 1 + (any1 ? 1 : 0);
+                        mx = mx > r1 ? mx : r1;
+                        ++w.frames;
+                    }
+                    w.passes += 1;
+                }
+                if (vb) mx = mx > 1 ? mx : 1; // (children dropped by the bound test return at least 1)
+                nb += SLOTS;
+                flags |= kFused;
+                done = true;
+            }
+            if (!done && ab) {
+                bool keep = true; // the walker descends itself
+                if (export_mode && nl - (f + 1) >= (int)p.min_levels) {
+                    // Over budget: hand the surviving children of this pass to the task queue - one reservation, one record
+                    // per slot. Children with >= 5 matches count as "returned >= 1" (see above). Below that the frame needs
+                    // to know whether a child reaches 5 matches (tree.py:98), which probe() answers: only the first
+                    // surviving child is handed over then, and this frame's max_num_matches is raised to 5 - nm if
+                    // the child can get there (what it returns beyond that changes no decision anywhere).
+                    const bool deep = nm >= 4;
+                    const int first_ss = (__ffsll(ab) - 1) / G;
+                    bool slot_alive = ((ab >> (s * G)) & GM) != 0;
+                    if (!deep) slot_alive = slot_alive && s == first_ss;
+                    const unsigned long long heads = __ballot(slot_alive && c == 0);
+                    const uint32_t n = (uint32_t)__popcll(heads);
+                    // all subtrees of a ligand go to one shard, and the task wavefronts of one XCD drain one group of
+                    // shards (task_kernel): the walkers that share a ligand's tables run side by side under one L2
+                    const uint32_t sh = (p.flags & 256) ? ((wave_id + (uint32_t)(w.passes >> 4)) & (kShards - 1)) : ((rec16 * 2654435761u) >> 26);
+                    static_assert(kShards == 64, "shard hash");
+                    // one atomic add reserves the records (no retry loop: the walkers of one ligand export to one shard at
+                    // the same time); a reservation that crosses the end of the shard fills its part below the end
+                    // with empty subtrees of this ligand (no conformer: prepare_walk drops them)
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(&p.ctl->q_res[sh], n);
+                    base = (uint32_t)uni((int)base);
+                    if (base + n > p.qcap) {
+                        for (uint32_t i = base + (uint32_t)lane; i < p.qcap; i += 64u) {
+                            uint32_t *nr = reinterpret_cast<uint32_t *>(p.queue + ((size_t)sh * p.qcap + i) * task_rec_bytes<G>());
+                            for (uint32_t wd = 0; wd < task_rec_bytes<G>() / 4; ++wd) nr[wd] = 0u;
+                            nr[0] = rec16;
+                            nr[1] = (uint32_t)(f + 1) | (5u << 8); // f0, nm
+                        }
+                        base = 0xffffffffu;
+                    }
+                    if (base != 0xffffffffu) {
+                        if (lane < nm) pathbuf[lane] = (uint16_t)(((w.matKA >> 16) & 255) | (((w.matKA >> 8) & 255) << 8));
+                        lds_sync();
+                        if (slot_alive) {
+                            const uint32_t rank = (uint32_t)__popcll(heads & ((1ull << (s * G)) - 1ull));
+                            unsigned char *tr = p.queue + ((size_t)sh * p.qcap + base + rank) * task_rec_bytes<G>();
+                            TaskRec *th = reinterpret_cast<TaskRec *>(tr);
+                            if (c == 0) {
+                                th->rec16 = rec16;
+                                th->f0 = (uint8_t)(f + 1);
+                                th->nm = (uint8_t)(nm + 1);
+                                th->pad = 0;
+                                th->mask = (vb >> (s * G)) & GM;
+                            }
+                            const uint32_t mine = (uint32_t)f | ((uint32_t)(nb + s) << 8); // this slot's own match, entry nm
+                            for (int wd = c; wd < PMX_MAX_LEVELS / 2; wd += G) { // two path entries per 32-bit word
+                                const int q0 = 2 * wd, q1 = 2 * wd + 1;
+                                const uint32_t e0 = q0 < nm ? pathbuf[q0] : (q0 == nm ? mine : 0u);
+                                const uint32_t e1 = q1 < nm ? pathbuf[q1] : (q1 == nm ? mine : 0u);
+                                reinterpret_cast<uint32_t *>(th->path)[wd] = e0 | (e1 << 16);
+                            }
+                            reinterpret_cast<double *>(tr + sizeof(TaskRec))[c] = t;
+                        }
+                        w.exported += n;
+                        if (deep) {
+                            mx = mx > 1 ? mx : 1; // children given away (or dropped) return at least 1
+                            nb += SLOTS;
+                        } else {
+                            const bool reach = probe<G>(w, f, nm, nb + first_ss, (vb >> (first_ss * G)) & GM, w.probe_passes);
+                            ++w.probes;
+                            if (reach) mx = mx > 5 - nm ? mx : 5 - nm;
+                            nb = nb + first_ss + 1;
+                        }
+                        keep = false;
+                        done = true;
+                    } else if (lane == 0) {
+                        p.ctl->qflag = 1; // shard full: walk the subtree here
+                    }
+                }
+                if (keep) {
                     // descend into the first surviving child (tree.py:94-97)
                     const int ss = (__ffsll(ab) - 1) / G;
                     const unsigned long long before = ss == 0 ? 0ull : (vb & ((1ull << (ss * G)) - 1ull));
@@ -667,38 +677,35 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
                     nb = bsel + 1;
                     const uint64_t cmask = (vb >> (ss * G)) & GM;
                     if (s == ss) tot[(nm + 1) * G + c] = t;
-                    w.stA = wl(w.stA, f, (int)(uint32_t)mask);
-                    if (G > 32) w.stB = wl(w.stB, f, (int)(uint32_t)(mask >> 32));
-                    w.stC = wl(w.stC, f, nb | (mx << 8) | ((int)flags << 16) | (nm << 24));
+                    // this frame's state, then the child's: lane f + 1
+                    w.stC = wl(wl(w.stC, f, nb | (mx << 8) | ((int)flags << 16) | (nm << 24)), f + 1, ((int)kMatched << 16) | ((nm + 1) << 24));
+                    w.stA = wl(w.stA, f + 1, (int)(uint32_t)cmask);
+                    if (G > 32) w.stB = wl(w.stB, f + 1, (int)(uint32_t)(cmask >> 32));
                     // entry(this match, level f', b') = rowbase[f] + k_f * (ksum[f'] - ksum[f + 1]) + b * k_f' + b'
                     w.matRB = wl(w.matRB, nm, rl(w.hrow, f) - kf * rl(w.hks, f + 1));
                     w.matKA = wl(w.matKA, nm, kf | (bsel << 8) | (f << 16));
                     ++f;
-                    ++nm;
-                    mask = cmask;
-                    flags = kMatched;
-                    nb = 0;
-                    mx = 0;
                     ++w.frames;
-                    descended = true;
-                    break;
+                    lds_sync(); // the child's total is read by all slots
+                    continue;
                 }
-                if (vb) mx = mx > 1 ? mx : 1; // every existing child of this pass was dropped
+            }
+            if (!done) { // every existing child of this pass was dropped (or none existed)
+                if (vb) mx = mx > 1 ? mx : 1;
                 nb += SLOTS;
             }
-            if (descended) {
-                lds_sync(); // the child's total is read by all slots
-                continue;
-            }
+            w.stC = wl(w.stC, f, nb | (mx << 8) | ((int)flags << 16) | (nm << 24));
+            continue;
         }
-        // the candidates of this frame are done
+        // -------------------------------------------------------------------- the candidates of this frame are done
         if (leaf_level) {
             mx = (flags & kAny) ? 1 : 0;
             if (!(flags & kAny) || nm + mx < 5) { // skip leaf (tree.py:98-101, :42-43): this node's totals
+                const double tparent = tot[nm * G + c];
                 if (((mask >> c) & 1ull) && tparent > w.best) w.best = tparent;
             }
         }
-        if (leaf_level || fused_any) {
+        if (leaf_level || (flags & kFused)) {
             // publish improved maxima to the other slots (the bound test reads them)
             const bool up = w.best > w.flushed;
             if (__ballot(up)) {
@@ -710,29 +717,21 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
         }
         if (!leaf_level && !(flags & kSkipped) && (!(flags & kAny) || nm + mx < 5)) { // skip child (tree.py:98-101)
             flags |= kSkipped;
-            w.stA = wl(w.stA, f, (int)(uint32_t)mask);
-            if (G > 32) w.stB = wl(w.stB, f, (int)(uint32_t)(mask >> 32));
-            w.stC = wl(w.stC, f, nb | (mx << 8) | ((int)flags << 16) | (nm << 24));
+            w.stC = wl(wl(w.stC, f, nb | (mx << 8) | ((int)flags << 16) | (nm << 24)), f + 1, nm << 24);
+            w.stA = wl(w.stA, f + 1, (int)(uint32_t)mask);
+            if (G > 32) w.stB = wl(w.stB, f + 1, (int)(uint32_t)(mask >> 32));
             ++f;
-            flags = 0;
-            nb = 0;
-            mx = 0;
             ++w.frames;
             continue;
         }
-        // return max_num_matches + matched (tree.py:102)
+        // return max_num_matches + matched (tree.py:102) to the parent frame
         ret = mx + ((flags & kMatched) ? 1 : 0);
         --f;
         if (f < f0) break;
         {
-            const int sc = rl(w.stC, f);
-            mask = (uint64_t)(uint32_t)rl(w.stA, f);
-            if (G > 32) mask |= (uint64_t)(uint32_t)rl(w.stB, f) << 32;
-            nb = sc & 255;
-            mx = (sc >> 8) & 255;
-            flags = (unsigned)(sc >> 16) & 255u;
-            nm = (sc >> 24) & 255;
-            mx = mx > ret ? mx : ret;
+            const int pc = rl(w.stC, f);
+            const int pmx = (pc >> 8) & 255;
+            if (ret > pmx) w.stC = wl(w.stC, f, (pc & ~0xff00) | (ret << 8));
         }
     }
     return ret;
@@ -1280,14 +1279,15 @@ __device__ __forceinline__ bool prepare_walk(const ScreenParams &p, unsigned cha
         pool[c] = __hip_atomic_load(&gbest[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // maxima of the ligand's finished walkers
     }
     w.f = w.f0 = f0;
-    w.nm = nm0;
-    w.mask = uni64(th->mask);
-    w.flags = nm0 ? kMatched : 0u;
+    const uint64_t mask0 = uni64(th->mask);
+    w.stA = wl(w.stA, f0, (int)(uint32_t)mask0);
+    if (G > 32) w.stB = wl(w.stB, f0, (int)(uint32_t)(mask0 >> 32));
+    w.stC = wl(w.stC, f0, ((nm0 ? (int)kMatched : 0) << 16) | (nm0 << 24));
     wave_sync();
     if (!(p.flags & 4) && f0 < nl && nm0 >= 5) {
         const double r = *reinterpret_cast<const double *>(w.Rb + ((size_t)f0 * G + c) * 8);
         const double t = tot[nm0 * G + c];
-        return __ballot(((w.mask >> c) & 1ull) && (t + r) * kBoundSlack > __longlong_as_double((long long)pool[c])) != 0;
+        return __ballot(((mask0 >> c) & 1ull) && (t + r) * kBoundSlack > __longlong_as_double((long long)pool[c])) != 0;
     }
     return true;
 }
