@@ -324,6 +324,12 @@ static_assert(kOffBits + 8 * PMX_MAX_LEVELS + 8 <= kOffPath && kOffPath + 2 * PM
 // per-conformer maximum. So Y may be (i) dropped when no leaf below it can exceed the maxima found so far - leaf totals
 // are bounded by total(Y) + R[f + 1] (build_bounds) - and (ii) walked by another wavefront (task queue); both count as
 // "returned >= 1" for the parent. Scores and every skip decision stay what the reference computes.
+struct WaveStats { // lives in LDS, updated by lane 0
+    unsigned long long frames, passes, over, items, exact, longest, tasks, overflow;
+    unsigned long long cyc_scan, cyc_tables, cyc_bounds, cyc_walk, cyc_busy, cyc_idle, pad[2]; // s_memtime ticks per phase
+};
+static_assert(sizeof(WaveStats) == 128, "WaveStats layout");
+
 template <int G>
 struct Walk {
     // tables of the job
@@ -336,8 +342,6 @@ struct Walk {
     int stA = 0, stB = 0, stC = 0; // mask lo, mask hi, nb | mx << 8 | flags << 16 | nm << 24
     double best = 0.0, flushed = 0.0;
     uint32_t frames = 0, passes = 0;
-    uint32_t exported = 0, probes = 0;
-    uint32_t probe_passes = 0;
     // current frame (its state is in lane f of the stack like every other frame's; a walk can be interrupted and resumed, see kOverBudget)
     int f = 0, f0 = 0;
 };
@@ -448,7 +452,7 @@ __device__ __forceinline__ bool probe(Walk<G> &w, int f, int nm, int cand, uint6
 template <int G>
 __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *tot, unsigned long long *pool, uint16_t *pathbuf, double *tch, double *tc,
                                     uint32_t rec16 /* arena record of the job (exports refer to it) */, bool export_mode,
-                                    unsigned long long budget, uint32_t wave_id) {
+                                    unsigned long long budget, uint32_t wave_id, WaveStats *stat) {
     constexpr int SLOTS = 64 / G;
     constexpr int PSH = G == 1 ? 2 : G == 2 ? 3 : G == 4 ? 4 : G == 8 ? 5 : G == 16 ? 6 : G == 32 ? 7 : 8; // log2 bytes of an entry
     constexpr uint64_t GM = group_mask<G>();
@@ -459,7 +463,7 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
     const unsigned char *Sb = w.Sb, *Pb = w.Pb, *Rb = w.Rb;
     const bool no_bound = (p.flags & 4) != 0;
 
-    const uint32_t budget32 = budget > 0xfffffff0ull ? 0xffffffffu : (uint32_t)budget; // (a walk of 2^32 passes does not end in this life)
+    const uint32_t budget32 = (export_mode || budget > 0xfffffff0ull) ? 0xffffffffu : (uint32_t)budget; // (a walk of 2^32 passes does not end in this life)
     const int f0 = w.f0;
     // The only scalar carried from one iteration to the next is the frame number: every frame's state - the current one's
     // too - lives in lane f of stA / stB / stC and is read at the top of an iteration and written back at its end. (With the
@@ -468,7 +472,7 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
     int f = w.f;
     int ret = 0;
     for (;;) {
-        if (!export_mode && w.passes > budget32) { // over budget: the caller moves the job's tables to the arena and resumes in export mode
+        if (w.passes > budget32) { // over budget: the caller moves the job's tables to the arena and resumes in export mode
             w.f = f;
             return kOverBudget;
         }
@@ -652,13 +656,18 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
                             }
                             reinterpret_cast<double *>(tr + sizeof(TaskRec))[c] = t;
                         }
-                        w.exported += n;
+                        if (lane == 0) stat->overflow += n; // (records written to the queue)
                         if (deep) {
                             mx = mx > 1 ? mx : 1; // children given away (or dropped) return at least 1
                             nb += SLOTS;
                         } else {
-                            const bool reach = probe<G>(w, f, nm, nb + first_ss, (vb >> (first_ss * G)) & GM, w.probe_passes);
-                            ++w.probes;
+                            uint32_t pp = 0;
+                            const bool reach = probe<G>(w, f, nm, nb + first_ss, (vb >> (first_ss * G)) & GM, pp);
+                            if (lane == 0) {
+                                stat->pad[0] += pp;
+                                stat->pad[1] += 1;
+                                stat->passes += pp;
+                            }
                             if (reach) mx = mx > 5 - nm ? mx : 5 - nm;
                             nb = nb + first_ss + 1;
                         }
@@ -1134,11 +1143,6 @@ __device__ inline unsigned long long arena_alloc(const ScreenParams &p, uint32_t
 #define PMX_SCREEN_WAVES 6 // waves per SIMD the register budget is set for (<= 80 VGPRs: nothing spilled to memory)
 #endif
 
-struct WaveStats { // lives in LDS, updated by lane 0
-    unsigned long long frames, passes, over, items, exact, longest, tasks, overflow;
-    unsigned long long cyc_scan, cyc_tables, cyc_bounds, cyc_walk, cyc_busy, cyc_idle, pad[2]; // s_memtime ticks per phase
-};
-static_assert(sizeof(WaveStats) == 128, "WaveStats layout");
 
 // A job of a wavefront is a subtree record: one taken from the queue (the ligand's tables are in the arena), or the root of
 // a ligand whose tables this wave has just built (record in the wave's LDS, tables in its slice or in the arena).
@@ -1310,7 +1314,7 @@ __device__ __forceinline__ void run_job(const ScreenParams &p, unsigned char *ld
     unsigned long long budget = ((p.flags & 2) || p.last_round) ? ~0ull : (unsigned long long)p.budget;
     bool export_mode = false, split = is_task;
     for (;;) {
-        const int rc = walk<G>(w, p, tot, pool, pathbuf, tch, tc, rec16, export_mode, budget, wave_id);
+        const int rc = walk<G>(w, p, tot, pool, pathbuf, tch, tc, rec16, export_mode, budget, wave_id, stat);
         if (rc != kOverBudget) break;
         if (lane == 0) ++stat->over;
         budget = ~0ull;
@@ -1345,10 +1349,6 @@ __device__ __forceinline__ void run_job(const ScreenParams &p, unsigned char *ld
         stat->frames += w.frames;
         stat->passes += w.passes;
         stat->longest = w.passes > stat->longest ? w.passes : stat->longest;
-        stat->overflow += w.exported; // (records written to the queue)
-        stat->pad[0] += w.probe_passes;
-        stat->pad[1] += w.probes;
-        stat->passes += w.probe_passes;
     }
     // ---- per-conformer maxima over the slots -> score
     if (w.best > 0.0) atomicMax(&pool[c], (unsigned long long)__double_as_longlong(w.best));
