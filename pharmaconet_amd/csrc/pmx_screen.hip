@@ -703,8 +703,10 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
                 if (vb) mx = mx > 1 ? mx : 1;
                 nb += SLOTS;
             }
-            w.stC = wl(w.stC, f, nb | (mx << 8) | ((int)flags << 16) | (nm << 24));
-            continue;
+            if (nb < kf) { // more candidates: another pass
+                w.stC = wl(w.stC, f, nb | (mx << 8) | ((int)flags << 16) | (nm << 24));
+                continue;
+            }
         }
         // -------------------------------------------------------------------- the candidates of this frame are done
         if (leaf_level) {
