@@ -53,7 +53,9 @@ struct FnTable {
 };
 
 // Header of one ligand's tables, in a wave's slice or in the arena:
-//   [RecHeader][best u64[G]][S float[ksumtot][G]][P float[T][G]][R double[nl + 1][G]]
+//   [RecHeader][best u64[G]][S float[ksumtot][G]][P float[T][G]][R double[nl + 1][G]][V mask[T]]
+// V[e] = the conformers c with P[e][c] > 0 (one bit per conformer, max(G, 8) / 8 bytes per entry): what decides which
+// children of a tree node exist (tree.py:78-84), read with the lanes spread over candidates.
 // Pair entry ((i, a), (j, b)), i < j: rowbase[i] + k[i] * (ksum[j] - ksum[i + 1]) + a * k[j] + b.
 struct RecHeader {
     uint32_t lig; // ligand index relative to the call's `first`
@@ -82,8 +84,17 @@ __host__ __device__ inline uint32_t rec_r_off(uint32_t ksumtot, uint32_t T) {
     return rec_p_off<G>(ksumtot) + (uint32_t)round16((uint64_t)T * G * 4);
 }
 template <int G>
+__host__ __device__ constexpr uint32_t vmask_bytes() {
+    return G < 8 ? 1u : (uint32_t)G / 8u;
+}
+template <int G>
+__host__ __device__ inline uint32_t rec_v_off(uint32_t ksumtot, uint32_t T, uint32_t nl) {
+    return rec_r_off<G>(ksumtot, T) + (nl + 1u) * G * 8u;
+}
+template <int G>
 __host__ __device__ inline uint64_t rec_bytes(uint32_t ksumtot, uint32_t T, uint32_t nl) {
-    return (uint64_t)rec_s_off<G>() + round16((uint64_t)ksumtot * G * 4) + round16((uint64_t)T * G * 4) + (uint64_t)(nl + 1) * G * 8;
+    return (uint64_t)rec_s_off<G>() + round16((uint64_t)ksumtot * G * 4) + round16((uint64_t)T * G * 4) + (uint64_t)(nl + 1) * G * 8 +
+           round16((uint64_t)T * vmask_bytes<G>());
 }
 
 // A subtree handed to the task queue: its root has >= 5 matches (see walk()).
@@ -267,7 +278,7 @@ template <int G>
 struct WaveShape {
     uint32_t kp;     // candidates per level, padded
     uint32_t nc_cap; // node-candidate entries
-    uint32_t off_cand, off_lcnt, off_nc, off_tot, off_pool, off_stat, off_task, off_tch, off_tc, bytes;
+    uint32_t off_cand, off_lcnt, off_nc, off_tot, off_pool, off_stat, off_task, off_tch, off_tc, off_cb, bytes;
 };
 template <int G>
 __host__ __device__ inline WaveShape<G> wave_shape(int K, int max_nodes) {
@@ -296,6 +307,8 @@ __host__ __device__ inline WaveShape<G> wave_shape(int K, int max_nodes) {
     o += 64 * 8;
     w.off_tc = o; // the children's totals of the kTcLevels deepest unfused frames + their validity ballots
     o += kTcLevels * (64 * 8 + 8);
+    w.off_cb = o; // candidates of a filtered frame that are still to visit, one 64-bit set per level
+    o += PMX_MAX_LEVELS * 8;
     w.bytes = o;
     return w;
 }
@@ -333,7 +346,7 @@ static_assert(sizeof(WaveStats) == 128, "WaveStats layout");
 template <int G>
 struct Walk {
     // tables of the job
-    const unsigned char *Sb, *Pb, *Rb;
+    const unsigned char *Sb, *Pb, *Rb, *Vb;
     int nl;
     int hk, hks, hrow; // lane l: k[l], ksum[l], rowbase[l]
     // path: lane q holds match q
@@ -351,7 +364,7 @@ __host__ __device__ constexpr uint64_t group_mask() {
     return G >= 64 ? ~0ull : ((1ull << (G & 63)) - 1ull);
 }
 
-constexpr unsigned kMatched = 1, kAny = 2, kSkipped = 4, kCached = 8, kFused = 16;
+constexpr unsigned kMatched = 1, kAny = 2, kSkipped = 4, kCached = 8, kFused = 16, kFiltered = 32;
 constexpr double kBoundSlack = 1.0 + 1e-9; // covers the float64 rounding of the sums the bound is compared with
 
 // Can the child (frame f, candidate `cand`, conformer mask `cmask`) of the current frame, which holds nm matches, still
@@ -451,7 +464,7 @@ __device__ __forceinline__ bool probe(Walk<G> &w, int f, int nm, int cand, uint6
 
 template <int G>
 __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *tot, unsigned long long *pool, uint16_t *pathbuf, double *tch, double *tc,
-                                    uint32_t rec16 /* arena record of the job (exports refer to it) */, bool export_mode,
+                                    unsigned long long *cbl, uint32_t rec16 /* arena record of the job (exports refer to it) */, bool export_mode,
                                     unsigned long long budget, uint32_t wave_id, WaveStats *stat) {
     constexpr int SLOTS = 64 / G;
     constexpr int PSH = G == 1 ? 2 : G == 2 ? 3 : G == 4 ? 4 : G == 8 ? 5 : G == 16 ? 6 : G == 32 ? 7 : 8; // log2 bytes of an entry
@@ -460,8 +473,9 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
     const int s = lane / G, c = lane % G;
     const uint32_t lane_off = (uint32_t)lane * 4u; // (s * G + c) floats: candidate nb + s, conformer c
     const int nl = w.nl;
-    const unsigned char *Sb = w.Sb, *Pb = w.Pb, *Rb = w.Rb;
+    const unsigned char *Sb = w.Sb, *Pb = w.Pb, *Rb = w.Rb, *Vb = w.Vb;
     const bool no_bound = (p.flags & 4) != 0;
+    const bool no_filter = (p.flags & 128) != 0;
 
     const uint32_t budget32 = (export_mode || budget > 0xfffffff0ull) ? 0xffffffffu : (uint32_t)budget; // (a walk of 2^32 passes does not end in this life)
     const int f0 = w.f0;
@@ -497,8 +511,53 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
             }
             // pair-table rows of the matched ancestors against level f: lane q
             const int ebv = w.matRB + __mul24(w.matKA & 255, ksf) + __mul24((w.matKA >> 8) & 255, kf);
-            const int b = nb + s;
-            const bool on = b < kf;
+            // A frame with more candidates than slots is *filtered* first: which candidates exist as children - some conformer of
+            // the frame has every pair entry > 0 - is read off the V masks with the lanes spread over candidates, and the passes
+            // then take the existing candidates only, SLOTS at a time (most candidates do not exist: without this a frame of a
+            // large model, or of a 64-conformer library with one slot per pass, spends its passes on them).
+            bool filt = false;
+            unsigned long long cb = 0, cb_rest = 0;
+            int bvec = nb + s; // the candidate of this lane's slot
+            if constexpr (SLOTS <= 2) { // (with 8 slots - the 8-conformer shape - the filter's own pass costs more than it saves: measured)
+                filt = kf > SLOTS && nm > 0 && !no_filter;
+                if (filt) {
+                    if (!(flags & kFiltered)) {
+                        constexpr uint32_t VB = vmask_bytes<G>();
+                        const bool in = lane < kf;
+                        const uint32_t lo_ = (uint32_t)(in ? lane : 0) * VB;
+                        unsigned long long m = mask;
+                        for (int q = 0; q < nm; ++q) {
+                            const unsigned char *ve = Vb + (uint32_t)rl(ebv, q) * VB + lo_;
+                            unsigned long long v;
+                            if (G <= 8) v = *ve;
+                            else if (G == 16) v = *reinterpret_cast<const uint16_t *>(ve);
+                            else if (G == 32) v = *reinterpret_cast<const uint32_t *>(ve);
+                            else v = *reinterpret_cast<const unsigned long long *>(ve);
+                            m &= v;
+                        }
+                        cb = __ballot(in && m != 0ull);
+                        flags |= kFiltered;
+                        ++w.passes;
+                        if (cb == 0ull) { // no child exists: the frame's candidates are done
+                            w.stC = wl(w.stC, f, 255 | (mx << 8) | ((int)flags << 16) | (nm << 24));
+                            continue;
+                        }
+                    } else {
+                        cb = uni64(cbl[f]);
+                    }
+                    unsigned long long x = cb;
+                    bvec = 255;
+#pragma unroll
+                    for (int ss = 0; ss < SLOTS; ++ss) {
+                        const int bb = x ? __ffsll(x) - 1 : 255;
+                        x &= x - 1ull;
+                        bvec = s == ss ? bb : bvec;
+                    }
+                    cb_rest = x;
+                }
+            }
+            const bool on = bvec < kf;
+            const int b_first = filt ? (cb ? __ffsll(cb) - 1 : 0) : nb; // a candidate idle slots may read (in bounds)
             double t;
             bool valid;
             // cache slot of this frame: the kTcLevels frames above the fused one, one pass wide
@@ -510,15 +569,15 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
                 t = tc[tci * 64 + (on ? src : lane)];
                 valid = on && ((uni64(vb0) >> src) & 1ull);
             } else {
-                const uint32_t bo = on ? lane_off : (uint32_t)c * 4u; // idle slots read candidate nb (in bounds)
-                const float self = *reinterpret_cast<const float *>(Sb + (((uint32_t)(ksf + nb) << PSH) + bo));
+                const uint32_t bo = ((uint32_t)(on ? bvec : b_first) << PSH) + (uint32_t)c * 4u; // idle slots read an existing candidate
+                const float self = *reinterpret_cast<const float *>(Sb + (((uint32_t)ksf << PSH) + bo));
                 float lo = 1.f; // smallest pair entry: the candidate is valid for this conformer iff every entry is > 0 (tree.py:81)
                 double sum = 0.0;
                 int q = 0;
                 for (; q + 4 <= nm; q += 4) {
                     float v[4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float *>(Pb + (((uint32_t)(rl(ebv, q + u) + nb) << PSH) + bo));
+                    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float *>(Pb + (((uint32_t)rl(ebv, q + u) << PSH) + bo));
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         lo = fminf(lo, v[u]);
@@ -526,7 +585,7 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
                     }
                 }
                 for (; q < nm; ++q) {
-                    const float v = *reinterpret_cast<const float *>(Pb + (((uint32_t)(rl(ebv, q) + nb) << PSH) + bo));
+                    const float v = *reinterpret_cast<const float *>(Pb + (((uint32_t)rl(ebv, q) << PSH) + bo));
                     lo = fminf(lo, v);
                     sum += (double)v;
                 }
@@ -547,6 +606,7 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
             if (leaf_level) {
                 if (valid && t > w.best) w.best = t; // graph_match.py:105-108
                 nb += SLOTS;
+                cb = cb_rest;
                 done = true;
             }
             unsigned long long ab = vb;
@@ -583,7 +643,7 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
                         left &= ~(GM << (sb * G));
                         const uint64_t cm = (vb >> (sb * G)) & GM;
                         const double tb = tch[sb * G + c];
-                        const float pfb = *reinterpret_cast<const float *>(Pb + ((row_f + (uint32_t)(nb + sb) * (uint32_t)k1) << PSH) + bo1);
+                        const float pfb = *reinterpret_cast<const float *>(Pb + ((row_f + (uint32_t)rl(bvec, sb * G) * (uint32_t)k1) << PSH) + bo1);
                         const bool v1 = base_valid && pfb > 0.f && ((cm >> c) & 1ull);
                         const double t1 = (tb + (double)self1) + (base_sum + (double)pfb);
                         const bool any1 = __ballot(v1) != 0;
@@ -597,6 +657,7 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
                 }
                 if (vb) mx = mx > 1 ? mx : 1; // (children dropped by the bound test return at least 1)
                 nb += SLOTS;
+                cb = cb_rest;
                 flags |= kFused;
                 done = true;
             }
@@ -647,7 +708,7 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
                                 th->pad = 0;
                                 th->mask = (vb >> (s * G)) & GM;
                             }
-                            const uint32_t mine = (uint32_t)f | ((uint32_t)(nb + s) << 8); // this slot's own match, entry nm
+                            const uint32_t mine = (uint32_t)f | ((uint32_t)bvec << 8); // this slot's own match, entry nm
                             for (int wd = c; wd < PMX_MAX_LEVELS / 2; wd += G) { // two path entries per 32-bit word
                                 const int q0 = 2 * wd, q1 = 2 * wd + 1;
                                 const uint32_t e0 = q0 < nm ? pathbuf[q0] : (q0 == nm ? mine : 0u);
@@ -660,16 +721,19 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
                         if (deep) {
                             mx = mx > 1 ? mx : 1; // children given away (or dropped) return at least 1
                             nb += SLOTS;
+                            cb = cb_rest;
                         } else {
                             uint32_t pp = 0;
-                            const bool reach = probe<G>(w, f, nm, nb + first_ss, (vb >> (first_ss * G)) & GM, pp);
+                            const int bfirst = rl(bvec, first_ss * G);
+                            const bool reach = probe<G>(w, f, nm, bfirst, (vb >> (first_ss * G)) & GM, pp);
                             if (lane == 0) {
                                 stat->pad[0] += pp;
                                 stat->pad[1] += 1;
                                 stat->passes += pp;
                             }
                             if (reach) mx = mx > 5 - nm ? mx : 5 - nm;
-                            nb = nb + first_ss + 1;
+                            nb = bfirst + 1;
+                            cb &= ~((2ull << bfirst) - 1ull);
                         }
                         keep = false;
                         done = true;
@@ -682,8 +746,13 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
                     const int ss = (__ffsll(ab) - 1) / G;
                     const unsigned long long before = ss == 0 ? 0ull : (vb & ((1ull << (ss * G)) - 1ull));
                     if (before) mx = mx > 1 ? mx : 1; // existing children dropped by the bound test return at least 1
-                    const int bsel = nb + ss;
+                    const int bsel = rl(bvec, ss * G);
                     nb = bsel + 1;
+                    if (filt) { // what is left of the frame's candidates (the slots below ss were dropped)
+                        cb &= ~((2ull << bsel) - 1ull);
+                        if (lane == 0) cbl[f] = cb;
+                        nb = cb ? 0 : 255;
+                    }
                     const uint64_t cmask = (vb >> (ss * G)) & GM;
                     if (s == ss) tot[(nm + 1) * G + c] = t;
                     // this frame's state, then the child's: lane f + 1
@@ -702,6 +771,11 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
             if (!done) { // every existing child of this pass was dropped (or none existed)
                 if (vb) mx = mx > 1 ? mx : 1;
                 nb += SLOTS;
+                cb = cb_rest;
+            }
+            if (filt) {
+                if (lane == 0) cbl[f] = cb;
+                nb = cb ? 0 : 255;
             }
             if (nb < kf) { // more candidates: another pass
                 w.stC = wl(w.stC, f, nb | (mx << 8) | ((int)flags << 16) | (nm << 24));
@@ -987,6 +1061,7 @@ __device__ __forceinline__ void build_tables(const ScreenParams &p, unsigned cha
     const float *xyz = uniptr(r.xyz);
     float *St = reinterpret_cast<float *>(rec + rec_s_off<G>());
     float *Pt = reinterpret_cast<float *>(rec + rec_p_off<G>(L.ksumtot));
+    unsigned char *Vt = rec + rec_v_off<G>(L.ksumtot, L.T, (uint32_t)L.nl);
     const int nl = L.nl, K = p.M.K;
     uint32_t pair_base = 0;
     for (int i = 0; i < nl; ++i) {
@@ -1077,6 +1152,15 @@ __device__ __forceinline__ void build_tables(const ScreenParams &p, unsigned cha
                 // match_utils.py:71-74: -1 unless num_fails <= L1 * L2 / 2; entries that fail the prefilter are -1 (graph_match.py:266-268)
                 const float value = (near_any && 2 * fails <= L1 * L2) ? acc : -1.f;
                 if (on) Pt[(size_t)(pair_base + (uint32_t)e) * G + c] = value;
+                const unsigned long long pos = __ballot(on && value > 0.f);
+                if (on && c == 0) {
+                    const unsigned long long m = (pos >> (s * G)) & GM;
+                    unsigned char *ve = Vt + (size_t)(pair_base + (uint32_t)e) * vmask_bytes<G>();
+                    if (G <= 8) *ve = (unsigned char)m;
+                    else if (G == 16) *reinterpret_cast<uint16_t *>(ve) = (uint16_t)m;
+                    else if (G == 32) *reinterpret_cast<uint32_t *>(ve) = (uint32_t)m;
+                    else *reinterpret_cast<unsigned long long *>(ve) = m;
+                }
             }
             pair_base += (uint32_t)E;
         }
@@ -1268,6 +1352,7 @@ __device__ __forceinline__ bool prepare_walk(const ScreenParams &p, unsigned cha
     w.Sb = rec + rec_s_off<G>();
     w.Pb = rec + rec_p_off<G>(ksumtot);
     w.Rb = rec + rec_r_off<G>(ksumtot, T);
+    w.Vb = rec + rec_v_off<G>(ksumtot, T, (uint32_t)nl);
     w.nl = nl;
     w.hk = lane < nl ? (int)H->k[lane] : 0;
     w.hks = lane <= nl ? (int)H->ksum[lane] : 0;
@@ -1312,11 +1397,12 @@ __device__ __forceinline__ void run_job(const ScreenParams &p, unsigned char *ld
     uint16_t *pathbuf = reinterpret_cast<uint16_t *>(lds + kOffPath);
     double *tch = reinterpret_cast<double *>(lds + ws.off_tch);
     double *tc = reinterpret_cast<double *>(lds + ws.off_tc);
+    unsigned long long *cbl = reinterpret_cast<unsigned long long *>(lds + ws.off_cb);
     const unsigned long long t_d = __builtin_amdgcn_s_memtime();
     unsigned long long budget = ((p.flags & 2) || p.last_round) ? ~0ull : (unsigned long long)p.budget;
     bool export_mode = false, split = is_task;
     for (;;) {
-        const int rc = walk<G>(w, p, tot, pool, pathbuf, tch, tc, rec16, export_mode, budget, wave_id, stat);
+        const int rc = walk<G>(w, p, tot, pool, pathbuf, tch, tc, cbl, rec16, export_mode, budget, wave_id, stat);
         if (rc != kOverBudget) break;
         if (lane == 0) ++stat->over;
         budget = ~0ull;
