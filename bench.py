@@ -302,7 +302,7 @@ def main():
                 "profiled_pass_ms": prof["ms_total"],
                 "note": "HIP-event times of one extra, untimed pass with pmx_set_profiling(1) (event records on the call's stream, no synchronisation); "
                         "the timed steps run with profiling off. The path is not HBM-bound (SURVEY.md section 0, DESIGN.md section 4): what binds is "
-                        "instruction issue, see `issue`.",
+                        "the CU's scalar instruction issue (DESIGN.md section 4, profiles/r3_pmc_sq_summary.json).",
             },
             # what the kernels do per ligand, and how that compares with the CU's issue rate (one VALU and one SALU wave-instruction
             # per cycle and CU: MI355X_MICROARCH.md); instruction counts from profiles/r3_pmc_sq.json
