@@ -408,7 +408,14 @@ __device__ __forceinline__ bool probe(Walk<G> &w, int f, int nm, int cand, uint6
                     const bool on = nb + s < kf;
                     const uint32_t bo = on ? lane_off : (uint32_t)c * 4u;
                     bool ok = on && ((mask >> c) & 1ull);
-                    for (int q = 0; q < nm; ++q) ok = ok && *reinterpret_cast<const float *>(Pb + (((uint32_t)(rl(ebv, q) + nb) << PSH) + bo)) > 0.f;
+                    int q = 0;
+                    for (; q + 4 <= nm; q += 4) { // four rows in flight (no short circuit: the loads do not wait for each other)
+                        float v[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float *>(Pb + (((uint32_t)(rl(ebv, q + u) + nb) << PSH) + bo));
+                        ok = ok & (v[0] > 0.f) & (v[1] > 0.f) & (v[2] > 0.f) & (v[3] > 0.f);
+                    }
+                    for (; q < nm; ++q) ok = ok & (*reinterpret_cast<const float *>(Pb + (((uint32_t)(rl(ebv, q) + nb) << PSH) + bo)) > 0.f);
                     const unsigned long long vb = __ballot(ok);
                     ++passes;
                     if (!vb) {
@@ -526,15 +533,19 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
                         const bool in = lane < kf;
                         const uint32_t lo_ = (uint32_t)(in ? lane : 0) * VB;
                         unsigned long long m = mask;
-                        for (int q = 0; q < nm; ++q) {
+                        auto vload = [&](int q) -> unsigned long long {
                             const unsigned char *ve = Vb + (uint32_t)rl(ebv, q) * VB + lo_;
-                            unsigned long long v;
-                            if (G <= 8) v = *ve;
-                            else if (G == 16) v = *reinterpret_cast<const uint16_t *>(ve);
-                            else if (G == 32) v = *reinterpret_cast<const uint32_t *>(ve);
-                            else v = *reinterpret_cast<const unsigned long long *>(ve);
-                            m &= v;
+                            if (G <= 8) return *ve;
+                            else if (G == 16) return *reinterpret_cast<const uint16_t *>(ve);
+                            else if (G == 32) return *reinterpret_cast<const uint32_t *>(ve);
+                            else return *reinterpret_cast<const unsigned long long *>(ve);
+                        };
+                        int q = 0;
+                        for (; q + 4 <= nm; q += 4) { // four masks in flight
+                            const unsigned long long v0 = vload(q), v1 = vload(q + 1), v2 = vload(q + 2), v3 = vload(q + 3);
+                            m &= (v0 & v1) & (v2 & v3);
                         }
+                        for (; q < nm; ++q) m &= vload(q);
                         cb = __ballot(in && m != 0ull);
                         flags |= kFiltered;
                         ++w.passes;
@@ -629,9 +640,20 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
                     const float self1 = *reinterpret_cast<const float *>(Sb + (((uint32_t)ks1 << PSH) + bo1));
                     bool base_valid = on1;
                     double base_sum = 0.0;
-                    for (int q = 0; q < nm; ++q) {
+                    int q = 0;
+                    for (; q + 4 <= nm; q += 4) { // four rows in flight, added in order
+                        float v[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float *>(Pb + (((uint32_t)rl(ebv1, q + u)) << PSH) + bo1);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            base_valid = base_valid & (v[u] > 0.f);
+                            base_sum += (double)v[u];
+                        }
+                    }
+                    for (; q < nm; ++q) {
                         const float v = *reinterpret_cast<const float *>(Pb + (((uint32_t)rl(ebv1, q)) << PSH) + bo1);
-                        base_valid = base_valid && v > 0.f;
+                        base_valid = base_valid & (v > 0.f);
                         base_sum += (double)v;
                     }
                     // entry((f, b) -> (f + 1, b')) = rowbase[f] + b * k1 + b'
