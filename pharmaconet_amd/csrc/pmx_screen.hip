@@ -274,6 +274,7 @@ __global__ void fn_build_kernel(DevModel M, Weights W, const uint64_t *subnodes,
 #define PMX_TC_LEVELS 4
 #endif
 constexpr int kTcLevels = PMX_TC_LEVELS;
+static_assert(kTcLevels >= 1 && kTcLevels <= 8, "cache slot number is three bits of Walk::hk");
 template <int G>
 struct WaveShape {
     uint32_t kp;     // candidates per level, padded
@@ -364,6 +365,9 @@ __host__ __device__ constexpr uint64_t group_mask() {
     return G >= 64 ? ~0ull : ((1ull << (G & 63)) - 1ull);
 }
 
+// per-level facts in bits 8.. of Walk::hk: the last level | its parent level with the children's leaves fused into its pass |
+// a level whose children's totals are cached (slot number in bits 12..14)
+constexpr int kLvLeaf = 256, kLvFuse = 512, kLvCache = 1024;
 constexpr unsigned kMatched = 1, kAny = 2, kSkipped = 4, kCached = 8, kFused = 16, kFiltered = 32;
 constexpr double kBoundSlack = 1.0 + 1e-9; // covers the float64 rounding of the sums the bound is compared with
 
@@ -386,7 +390,7 @@ __device__ __forceinline__ bool probe(Walk<G> &w, int f, int nm, int cand, uint6
     // enter the child
     const int fbase = f;
     {
-        const int kf = rl(w.hk, f);
+        const int kf = rl(w.hk, f) & 255;
         w.matRB = wl(w.matRB, nm, rl(w.hrow, f) - kf * rl(w.hks, f + 1));
         w.matKA = wl(w.matKA, nm, kf | (cand << 8) | (f << 16));
     }
@@ -400,7 +404,7 @@ __device__ __forceinline__ bool probe(Walk<G> &w, int f, int nm, int cand, uint6
         if (f == nl) { // below the last level: a leaf
             ret = (flags & kMatched) ? 1 : 0;
         } else {
-            const int kf = rl(w.hk, f), ksf = rl(w.hks, f);
+            const int kf = rl(w.hk, f) & 255, ksf = rl(w.hks, f);
             bool descended = false;
             if (nb < kf) {
                 const int ebv = w.matRB + __mul24(w.matKA & 255, ksf) + __mul24((w.matKA >> 8) & 255, kf);
@@ -481,7 +485,7 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
     const uint32_t lane_off = (uint32_t)lane * 4u; // (s * G + c) floats: candidate nb + s, conformer c
     const int nl = w.nl;
     const unsigned char *Sb = w.Sb, *Pb = w.Pb, *Rb = w.Rb, *Vb = w.Vb;
-    const bool no_bound = (p.flags & 4) != 0;
+    const int bound_from = (p.flags & 4) ? 255 : 4; // matches on the path from which children are bound-tested
     const bool no_filter = (p.flags & 128) != 0;
 
     const uint32_t budget32 = (export_mode || budget > 0xfffffff0ull) ? 0xffffffffu : (uint32_t)budget; // (a walk of 2^32 passes does not end in this life)
@@ -503,14 +507,16 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
         const int nm = (sc >> 24) & 255;
         uint64_t mask = (uint64_t)(uint32_t)rl(w.stA, f);
         if (G > 32) mask |= (uint64_t)(uint32_t)rl(w.stB, f) << 32;
-        const int kf = rl(w.hk, f), ksf = rl(w.hks, f);
-        const bool leaf_level = f == nl - 1;
+        // what is fixed per level was worked out once per job (prepare_walk): bits 8.. of the level's entry
+        const int hv = rl(w.hk, f);
+        const int kf = hv & 255, ksf = rl(w.hks, f);
+        const bool leaf_level = (hv & kLvLeaf) != 0;
         if (nb < kf) {
             // ---------------------------------------------------------------- one pass over candidates nb .. nb + SLOTS - 1
             const double tparent = tot[nm * G + c];
             // the bound row and the pooled maxima go out with the table loads (one memory round trip per pass, not two); frames
             // f < nl only, so row f + 1 exists
-            const bool bounded = nm >= 4 && !leaf_level && !no_bound;
+            const bool bounded = nm >= bound_from && !leaf_level;
             double rbound = 0.0, pooled = 0.0;
             if (bounded) {
                 rbound = *reinterpret_cast<const double *>(Rb + (((uint32_t)(f + 1) << (PSH + 1)) + 8u * (uint32_t)c));
@@ -572,8 +578,8 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
             double t;
             bool valid;
             // cache slot of this frame: the kTcLevels frames above the fused one, one pass wide
-            const int tci = nl - 3 - f;
-            const bool cacheable = tci >= 0 && tci < kTcLevels && kf <= SLOTS && !(p.flags & 64);
+            const int tci = (hv >> 12) & 7;
+            const bool cacheable = (hv & kLvCache) != 0;
             if (cacheable && (flags & kCached)) { // back from a child: the remaining candidates as evaluated on the way in
                 const unsigned long long vb0 = *reinterpret_cast<const unsigned long long *>(tc + kTcLevels * 64 + tci);
                 const int src = lane + nb * G;
@@ -625,14 +631,14 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
                 const double bp = pooled > w.best ? pooled : w.best;
                 ab = __ballot(valid && (t + rbound) * kBoundSlack > bp);
             }
-            if (!done && f == nl - 2 && rl(w.hk, f + 1) <= SLOTS && !(p.flags & 32)) {
+            if (!done && (hv & kLvFuse)) {
                 // The children of this frame are frames of the last level, whose children are leaves: finish all of them here.
                 // Lane (s', c) takes leaf candidate s' of level f + 1; what a leaf's total and validity owe to the path above
                 // this frame is computed once, then every surviving child b of this pass adds its own pair entry:
                 //   total(b, b') = (total(b) + S[f + 1][b']) + (sum_q P[q -> (f + 1, b')] + P[(f, b) -> (f + 1, b')])   (tree.py:38-41)
                 // in the reference's order (the child is the deepest ancestor, so its entry comes last).
                 if (ab) {
-                    const int f1 = f + 1, k1 = rl(w.hk, f1), ks1 = rl(w.hks, f1);
+                    const int f1 = f + 1, k1 = rl(w.hk, f1) & 255, ks1 = rl(w.hks, f1);
                     tch[lane] = t; // the children's totals, read back per child by every slot
                     const int ebv1 = w.matRB + __mul24(w.matKA & 255, ks1) + __mul24((w.matKA >> 8) & 255, k1);
                     const bool on1 = s < k1;
@@ -1376,7 +1382,14 @@ __device__ __forceinline__ bool prepare_walk(const ScreenParams &p, unsigned cha
     w.Rb = rec + rec_r_off<G>(ksumtot, T);
     w.Vb = rec + rec_v_off<G>(ksumtot, T, (uint32_t)nl);
     w.nl = nl;
-    w.hk = lane < nl ? (int)H->k[lane] : 0;
+    {
+        const int kl = lane < nl ? (int)H->k[lane] : 0, knext = lane + 1 < nl ? (int)H->k[lane + 1] : 0;
+        const int tci = nl - 3 - lane;
+        int kind = lane == nl - 1 ? kLvLeaf : 0;
+        if (lane == nl - 2 && knext <= 64 / G && !(p.flags & 32)) kind |= kLvFuse;
+        if (tci >= 0 && tci < kTcLevels && kl <= 64 / G && !(p.flags & 64)) kind |= kLvCache | (tci << 12);
+        w.hk = kl | kind;
+    }
     w.hks = lane <= nl ? (int)H->ksum[lane] : 0;
     w.hrow = lane < nl ? (int)H->rowbase[lane] : 0;
     const int nm0 = uni((int)th->nm), f0 = uni((int)th->f0);
