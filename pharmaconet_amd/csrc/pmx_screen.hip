@@ -609,29 +609,25 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
                 // (v_min_f32 skips a NaN entry - a zero-weight pair, match_utils.py:50-52 - but the sum does not: NaN is not > 0)
                 valid = on && ((mask >> c) & 1ull) && lo > 0.f && sum == sum;
                 t = (tparent + (double)self) + sum; // parent + self + accumulated pair (tree.py:38-41)
-                if (cacheable && nb == 0) { // first pass of the frame
-                    tc[tci * 64 + lane] = t;
-                    const unsigned long long vb0 = __ballot(valid);
-                    if (lane == 0) *reinterpret_cast<unsigned long long *>(tc + kTcLevels * 64 + tci) = vb0;
-                    flags |= kCached;
-                }
             }
             const unsigned long long vb = __ballot(valid);
+            if (cacheable && !(flags & kCached)) { // first pass of the frame (a cached frame has one window)
+                tc[tci * 64 + lane] = t;
+                if (lane == 0) *reinterpret_cast<unsigned long long *>(tc + kTcLevels * 64 + tci) = vb;
+                flags |= kCached;
+            }
             ++w.passes;
             if (vb) flags |= kAny;
-            bool done = false; // the pass is over and the walker stays in this frame
+            unsigned long long ab = vb;
+            if (bounded && vb) { // the children hold >= 5 matches: drop those that cannot raise a maximum
+                const double bp = pooled > w.best ? pooled : w.best;
+                ab = __ballot(valid && (t + rbound) * kBoundSlack > bp);
+            }
             if (leaf_level) {
                 if (valid && t > w.best) w.best = t; // graph_match.py:105-108
                 nb += SLOTS;
                 cb = cb_rest;
-                done = true;
-            }
-            unsigned long long ab = vb;
-            if (!done && bounded && vb) { // the children hold >= 5 matches: drop those that cannot raise a maximum
-                const double bp = pooled > w.best ? pooled : w.best;
-                ab = __ballot(valid && (t + rbound) * kBoundSlack > bp);
-            }
-            if (!done && (hv & kLvFuse)) {
+            } else if (hv & kLvFuse) {
                 // The children of this frame are frames of the last level, whose children are leaves: finish all of them here.
                 // Lane (s', c) takes leaf candidate s' of level f + 1; what a leaf's total and validity owe to the path above
                 // this frame is computed once, then every surviving child b of this pass adds its own pair entry:
@@ -687,9 +683,7 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
                 nb += SLOTS;
                 cb = cb_rest;
                 flags |= kFused;
-                done = true;
-            }
-            if (!done && ab) {
+            } else if (ab) {
                 bool keep = true; // the walker descends itself
                 if (export_mode && nl - (f + 1) >= (int)p.min_levels) {
                     // Over budget: hand the surviving children of this pass to the task queue - one reservation, one record
@@ -764,7 +758,6 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
                             cb &= ~((2ull << bfirst) - 1ull);
                         }
                         keep = false;
-                        done = true;
                     } else if (lane == 0) {
                         p.ctl->qflag = 1; // shard full: walk the subtree here
                     }
@@ -795,8 +788,7 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
                     lds_sync(); // the child's total is read by all slots
                     continue;
                 }
-            }
-            if (!done) { // every existing child of this pass was dropped (or none existed)
+            } else { // every existing child of this pass was dropped (or none existed)
                 if (vb) mx = mx > 1 ? mx : 1;
                 nb += SLOTS;
                 cb = cb_rest;
