@@ -1,4 +1,4 @@
-// pmx_api.hip - host side of libpmx.so: the C ABI of include/pmx.h over the kernels of pmx_kernels.hip.
+// pmx_api.hip - host side of libpmx.so: the C ABI of include/pmx.h over the kernels of pmx_screen.hip.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>

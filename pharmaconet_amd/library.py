@@ -253,6 +253,10 @@ def cluster_ligand(lig: LigandFeatures) -> ClusteredLigand:
 
 
 # ----------------------------------------------------------------------- packing
+class LigandTooLarge(ValueError):
+    """The ligand exceeds a structural limit of the GPU engine (include/pmx.h)."""
+
+
 def pack_clustered_ligand(cl: ClusteredLigand) -> bytes:
     """Sort clusters by `priority_fn` (`graph_match.py:43-60`, stable like `sorted`, `:87`),
     renumber nodes cluster by cluster and emit one record."""
@@ -276,11 +280,11 @@ def pack_clustered_ligand(cl: ClusteredLigand) -> bytes:
     positions = np.asarray(cl.positions, dtype=np.float32)
     num_conf = int(positions.shape[1]) if positions.ndim == 3 else 0
     if n > MAX_LIGAND_NODES:
-        raise ValueError(f"ligand has {n} pharmacophore nodes; at most {MAX_LIGAND_NODES} are supported")
+        raise LigandTooLarge(f"ligand has {n} pharmacophore nodes; at most {MAX_LIGAND_NODES} are supported")
     if len(order) > MAX_LIGAND_CLUSTERS:
-        raise ValueError(f"ligand has {len(order)} clusters; at most {MAX_LIGAND_CLUSTERS} are supported")
+        raise LigandTooLarge(f"ligand has {len(order)} clusters; at most {MAX_LIGAND_CLUSTERS} are supported")
     if not 1 <= num_conf <= MAX_CONFORMERS:
-        raise ValueError(f"ligand has {num_conf} conformers; between 1 and {MAX_CONFORMERS} are supported")
+        raise LigandTooLarge(f"ligand has {num_conf} conformers; between 1 and {MAX_CONFORMERS} are supported")
     head = _HEADER.pack(n, num_conf, len(order), 0)
     typemask = np.asarray(cl.typemask, dtype=np.uint8)[node_order].tobytes()
     ends = bytes(cluster_end)
@@ -357,10 +361,6 @@ def pack_features_native(mols: Sequence[LigandFeatures] | dict[str, np.ndarray],
     return PackedLibrary(offsets, data[: int(nbytes.value)]), status
 
 
-class LigandTooLarge(ValueError):
-    """The ligand exceeds a structural limit of the GPU engine (include/pmx.h)."""
-
-
 # A header-only record (0 nodes, 0 conformers): the engine reports PMX_LIGAND_UNSUPPORTED and a NaN score for it.
 UNSUPPORTED_RECORD = _HEADER.pack(0, 0, 0, 0) + b"\0" * (RECORD_ALIGN - _HEADER.size)
 
@@ -370,9 +370,7 @@ def pack_ligand_or_marker(lig: LigandFeatures) -> tuple[bytes, str | None]:
     (returned with the reason) instead of raising: one oversized molecule must not abort a whole screen."""
     try:
         return pack_ligand(lig), None
-    except ValueError as e:
-        if "supported" not in str(e):
-            raise
+    except LigandTooLarge as e:
         return UNSUPPORTED_RECORD, str(e)
 
 
