@@ -53,7 +53,7 @@ struct FnTable {
 };
 
 // Header of one ligand's tables, in a wave's slice or in the arena:
-//   [RecHeader][best u64[G]][S float[ksumtot][G]][P float[T][G]][R double[nl + 1][G]][V mask[T]]
+//   [RecHeader][best u64[G]][S float[ksumtot][G]][P float[T][G]][R double[nl + 1][G]][W double[ksumtot][G]][V mask[T]]
 // V[e] = the conformers c with P[e][c] > 0 (one bit per conformer, max(G, 8) / 8 bytes per entry): what decides which
 // children of a tree node exist (tree.py:78-84), read with the lanes spread over candidates.
 // Pair entry ((i, a), (j, b)), i < j: rowbase[i] + k[i] * (ksum[j] - ksum[i + 1]) + a * k[j] + b.
@@ -88,13 +88,17 @@ __host__ __device__ constexpr uint32_t vmask_bytes() {
     return G < 8 ? 1u : (uint32_t)G / 8u;
 }
 template <int G>
-__host__ __device__ inline uint32_t rec_v_off(uint32_t ksumtot, uint32_t T, uint32_t nl) {
+__host__ __device__ inline uint32_t rec_w_off(uint32_t ksumtot, uint32_t T, uint32_t nl) {
     return rec_r_off<G>(ksumtot, T) + (nl + 1u) * G * 8u;
+}
+template <int G>
+__host__ __device__ inline uint32_t rec_v_off(uint32_t ksumtot, uint32_t T, uint32_t nl) {
+    return rec_w_off<G>(ksumtot, T, nl) + ksumtot * G * 8u;
 }
 template <int G>
 __host__ __device__ inline uint64_t rec_bytes(uint32_t ksumtot, uint32_t T, uint32_t nl) {
     return (uint64_t)rec_s_off<G>() + round16((uint64_t)ksumtot * G * 4) + round16((uint64_t)T * G * 4) + (uint64_t)(nl + 1) * G * 8 +
-           round16((uint64_t)T * vmask_bytes<G>());
+           (uint64_t)ksumtot * G * 8 + round16((uint64_t)T * vmask_bytes<G>());
 }
 
 // A subtree handed to the task queue: its root has >= 5 matches (see walk()).
@@ -347,7 +351,7 @@ static_assert(sizeof(WaveStats) == 128, "WaveStats layout");
 template <int G>
 struct Walk {
     // tables of the job
-    const unsigned char *Sb, *Pb, *Rb, *Vb;
+    const unsigned char *Sb, *Pb, *Rb, *Wb, *Vb;
     int nl;
     int hk, hks, hrow; // lane l: k[l], ksum[l], rowbase[l]
     // path: lane q holds match q
@@ -484,7 +488,7 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
     const int s = lane / G, c = lane % G;
     const uint32_t lane_off = (uint32_t)lane * 4u; // (s * G + c) floats: candidate nb + s, conformer c
     const int nl = w.nl;
-    const unsigned char *Sb = w.Sb, *Pb = w.Pb, *Rb = w.Rb, *Vb = w.Vb;
+    const unsigned char *Sb = w.Sb, *Pb = w.Pb, *Wb = w.Wb, *Vb = w.Vb;
     const int bound_from = (p.flags & 4) ? 255 : 4; // matches on the path from which children are bound-tested
     const bool no_filter = (p.flags & 128) != 0;
 
@@ -517,11 +521,8 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
             // the bound row and the pooled maxima go out with the table loads (one memory round trip per pass, not two); frames
             // f < nl only, so row f + 1 exists
             const bool bounded = nm >= bound_from && !leaf_level;
-            double rbound = 0.0, pooled = 0.0;
-            if (bounded) {
-                rbound = *reinterpret_cast<const double *>(Rb + (((uint32_t)(f + 1) << (PSH + 1)) + 8u * (uint32_t)c));
-                pooled = __longlong_as_double((long long)pool[c]);
-            }
+            double pooled = 0.0;
+            if (bounded) pooled = __longlong_as_double((long long)pool[c]);
             // pair-table rows of the matched ancestors against level f: lane q
             const int ebv = w.matRB + __mul24(w.matKA & 255, ksf) + __mul24((w.matKA >> 8) & 255, kf);
             // A frame with more candidates than slots is *filtered* first: which candidates exist as children - some conformer of
@@ -575,6 +576,9 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
             }
             const bool on = bvec < kf;
             const int b_first = filt ? (cb ? __ffsll(cb) - 1 : 0) : nb; // a candidate idle slots may read (in bounds)
+            // the candidate's bound goes out with the table loads (one memory round trip per pass, not two)
+            double rbound = 0.0;
+            if (bounded) rbound = *reinterpret_cast<const double *>(Wb + (((uint32_t)(ksf + (on ? bvec : b_first))) << (PSH + 1)) + 8u * (uint32_t)c);
             double t;
             bool valid;
             // cache slot of this frame: the kTcLevels frames above the fused one, one pass wide
@@ -1202,9 +1206,11 @@ __device__ __forceinline__ void build_bounds(const ScreenParams &p, unsigned cha
     const float *St = reinterpret_cast<const float *>(rec + rec_s_off<G>());
     const float *Pt = reinterpret_cast<const float *>(rec + rec_p_off<G>(L.ksumtot));
     double *Rt = reinterpret_cast<double *>(rec + rec_r_off<G>(L.ksumtot, L.T));
+    double *Wt = reinterpret_cast<double *>(rec + rec_w_off<G>(L.ksumtot, L.T, (uint32_t)L.nl));
     const int nl = L.nl;
     if (p.flags & 4) { // debug: nothing is ever dropped
         for (int l = s; l <= nl; l += SLOTS) Rt[(size_t)l * G + c] = __builtin_inf();
+        for (uint32_t e = s; e < L.ksumtot; e += SLOTS) Wt[(size_t)e * G + c] = __builtin_inf();
         return;
     }
     double suffix = 0.0;
@@ -1224,6 +1230,7 @@ __device__ __forceinline__ void build_bounds(const ScreenParams &p, unsigned cha
                 }
                 v += (double)m;
             }
+            Wt[(size_t)(ksl + b) * G + c] = v; // base(l, b), replaced by the candidate's own bound below
             u = v > u ? v : u;
         }
 #pragma unroll
@@ -1233,6 +1240,54 @@ __device__ __forceinline__ void build_bounds(const ScreenParams &p, unsigned cha
         }
         suffix += u;
         if (s == 0) Rt[(size_t)l * G + c] = suffix;
+    }
+    // W[(f, b)][c]: what the levels below f can add under a path whose newest match is (f, b) - as U, but with (f, b)'s own
+    // pair entries instead of level f's maxima, over the candidates compatible with (f, b) only. Levels in ascending order:
+    // the entries of the levels l > f still hold base(l, .).
+    wave_sync();
+    if (p.flags & 512) { // experiment switch: the per-level bound for every candidate
+        for (int f = 0; f < nl; ++f) {
+            const int kf = uni(lk[f]), ksf = uni(ksum[f]);
+            const double r = Rt[(size_t)(f + 1) * G + c];
+            wave_sync();
+            for (int b = s; b < kf; b += SLOTS) Wt[(size_t)(ksf + b) * G + c] = r;
+        }
+        return;
+    }
+    for (int f = 0; f < nl; ++f) {
+        const int kf = uni(lk[f]), ksf = uni(ksum[f]);
+        for (int b0 = 0; b0 < kf; b0 += SLOTS) { // slot s <-> candidate b0 + s of level f
+            const int b = b0 + s;
+            const bool on = b < kf;
+            double acc = 0.0;
+            for (int l = f + 1; l < nl; ++l) {
+                const int kl = uni(lk[l]), ksl = uni(ksum[l]);
+                const uint32_t e_fl = (uint32_t)uni((int)rowbase[f]) + (uint32_t)kf * (uint32_t)(ksl - uni((int)ksum[f + 1]));
+                double u = 0.0;
+                for (int b1 = 0; b1 < kl; ++b1) {
+                    const double base = Wt[(size_t)(ksl + b1) * G + c];
+                    // level f's entries against (l, b1): every slot reads its own candidate's, the largest of all is what
+                    // base(l, b1) counted for level f
+                    float mf = 0.f, pb = 0.f;
+                    for (int a0 = 0; a0 < kf; a0 += SLOTS) {
+                        const int a = a0 + s;
+                        const float pv = a < kf ? Pt[(size_t)(e_fl + (uint32_t)a * (uint32_t)kl + (uint32_t)b1) * G + c] : 0.f;
+                        mf = pv > mf ? pv : mf;
+                        pb = a0 == b0 ? pv : pb;
+                    }
+#pragma unroll
+                    for (int d = G; d < 64; d <<= 1) {
+                        const float o = __shfl_xor(mf, d);
+                        mf = o > mf ? o : mf;
+                    }
+                    const double val = (base - (double)mf) + (double)pb;
+                    u = (pb > 0.f && val > u) ? val : u;
+                }
+                acc += u;
+            }
+            if (on) Wt[(size_t)(ksf + b) * G + c] = acc * (1.0 + 1e-12);
+        }
+        wave_sync();
     }
 }
 
@@ -1372,6 +1427,7 @@ __device__ __forceinline__ bool prepare_walk(const ScreenParams &p, unsigned cha
     w.Sb = rec + rec_s_off<G>();
     w.Pb = rec + rec_p_off<G>(ksumtot);
     w.Rb = rec + rec_r_off<G>(ksumtot, T);
+    w.Wb = rec + rec_w_off<G>(ksumtot, T, (uint32_t)nl);
     w.Vb = rec + rec_v_off<G>(ksumtot, T, (uint32_t)nl);
     w.nl = nl;
     {
