@@ -222,7 +222,8 @@ def test_scores_do_not_depend_on_how_the_work_is_cut(monkeypatch):
         {"PMX_TREE_FLAGS": "64"},                    # no cache of the children's totals: every return evaluates the frame again
         {"PMX_TREE_FLAGS": "96"},
         {"PMX_TREE_FLAGS": "128"},                   # frames with more candidates than slots are not filtered through the V masks first
-        {"PMX_TREE_FLAGS": "256"},                   # a ligand's subtrees spread over the queue shards instead of kept in one
+        {"PMX_TREE_FLAGS": "256"},
+        {"PMX_TREE_FLAGS": "512"},                   # children tested against the per-level bound instead of their own                   # a ligand's subtrees spread over the queue shards instead of kept in one
     ):
         with monkeypatch.context() as mp:
             for k, v in env.items():
