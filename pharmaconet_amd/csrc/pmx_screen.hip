@@ -91,14 +91,19 @@ template <int G>
 __host__ __device__ inline uint32_t rec_w_off(uint32_t ksumtot, uint32_t T, uint32_t nl) {
     return rec_r_off<G>(ksumtot, T) + (nl + 1u) * G * 8u;
 }
+// (per-candidate bounds exist where a pass holds >= 4 candidates: 1 .. 16 conformer lanes; see build_bounds)
+template <int G>
+__host__ __device__ constexpr bool cand_bounds() {
+    return 64 / G >= 4;
+}
 template <int G>
 __host__ __device__ inline uint32_t rec_v_off(uint32_t ksumtot, uint32_t T, uint32_t nl) {
-    return rec_w_off<G>(ksumtot, T, nl) + ksumtot * G * 8u;
+    return rec_w_off<G>(ksumtot, T, nl) + (cand_bounds<G>() ? ksumtot * G * 8u : 0u);
 }
 template <int G>
 __host__ __device__ inline uint64_t rec_bytes(uint32_t ksumtot, uint32_t T, uint32_t nl) {
     return (uint64_t)rec_s_off<G>() + round16((uint64_t)ksumtot * G * 4) + round16((uint64_t)T * G * 4) + (uint64_t)(nl + 1) * G * 8 +
-           (uint64_t)ksumtot * G * 8 + round16((uint64_t)T * vmask_bytes<G>());
+           (cand_bounds<G>() ? (uint64_t)ksumtot * G * 8 : 0ull) + round16((uint64_t)T * vmask_bytes<G>());
 }
 
 // A subtree handed to the task queue: its root has >= 5 matches (see walk()).
@@ -578,7 +583,10 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
             const int b_first = filt ? (cb ? __ffsll(cb) - 1 : 0) : nb; // a candidate idle slots may read (in bounds)
             // the candidate's bound goes out with the table loads (one memory round trip per pass, not two)
             double rbound = 0.0;
-            if (bounded) rbound = *reinterpret_cast<const double *>(Wb + (((uint32_t)(ksf + (on ? bvec : b_first))) << (PSH + 1)) + 8u * (uint32_t)c);
+            if (bounded) {
+                if constexpr (cand_bounds<G>()) rbound = *reinterpret_cast<const double *>(Wb + (((uint32_t)(ksf + (on ? bvec : b_first))) << (PSH + 1)) + 8u * (uint32_t)c);
+                else rbound = *reinterpret_cast<const double *>(w.Rb + (((uint32_t)(f + 1) << (PSH + 1)) + 8u * (uint32_t)c));
+            }
             double t;
             bool valid;
             // cache slot of this frame: the kTcLevels frames above the fused one, one pass wide
@@ -1210,7 +1218,8 @@ __device__ __forceinline__ void build_bounds(const ScreenParams &p, unsigned cha
     const int nl = L.nl;
     if (p.flags & 4) { // debug: nothing is ever dropped
         for (int l = s; l <= nl; l += SLOTS) Rt[(size_t)l * G + c] = __builtin_inf();
-        for (uint32_t e = s; e < L.ksumtot; e += SLOTS) Wt[(size_t)e * G + c] = __builtin_inf();
+        if (cand_bounds<G>())
+            for (uint32_t e = s; e < L.ksumtot; e += SLOTS) Wt[(size_t)e * G + c] = __builtin_inf();
         return;
     }
     double suffix = 0.0;
@@ -1230,7 +1239,7 @@ __device__ __forceinline__ void build_bounds(const ScreenParams &p, unsigned cha
                 }
                 v += (double)m;
             }
-            Wt[(size_t)(ksl + b) * G + c] = v; // base(l, b), replaced by the candidate's own bound below
+            if (cand_bounds<G>()) Wt[(size_t)(ksl + b) * G + c] = v; // base(l, b), replaced by the candidate's own bound below
             u = v > u ? v : u;
         }
 #pragma unroll
@@ -1244,8 +1253,16 @@ __device__ __forceinline__ void build_bounds(const ScreenParams &p, unsigned cha
     // W[(f, b)][c]: what the levels below f can add under a path whose newest match is (f, b) - as U, but with (f, b)'s own
     // pair entries instead of level f's maxima, over the candidates compatible with (f, b) only. Levels in ascending order:
     // the entries of the levels l > f still hold base(l, .).
+    if (!cand_bounds<G>()) return; // one or two candidates per pass (32 / 64 conformers): the walker uses R
     wave_sync();
-    if (p.flags & 512) { // experiment switch: the per-level bound for every candidate
+    // (the work below grows with windows^2 per level: with very many candidates it would cost more than the walk saves, and
+    // every candidate gets its level's bound instead)
+    uint32_t cost = 0;
+    for (int f = 0; f < nl; ++f) {
+        const uint32_t wf = ((uint32_t)uni(lk[f]) + SLOTS - 1) / SLOTS;
+        cost += wf * wf * (L.ksumtot - (uint32_t)uni((int)ksum[f + 1]));
+    }
+    if ((p.flags & 512) || cost > 8192u) {
         for (int f = 0; f < nl; ++f) {
             const int kf = uni(lk[f]), ksf = uni(ksum[f]);
             const double r = Rt[(size_t)(f + 1) * G + c];
