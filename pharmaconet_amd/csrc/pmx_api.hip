@@ -597,7 +597,7 @@ static int score_screen(const pmx_model *model, const pmx_library *lib, const We
     p.status = status_dev;
     const int rounds = (int)std::max<long>(1, env_long("PMX_ROUNDS", 12));
     p.last_round = 0;
-    p.pad_ = 0;
+    p.bound_cost = (uint32_t)std::max<long>(0, env_long("PMX_BOUND_COST", 8192));
     const bool exact = (p.flags & 8) != 0;
     const size_t lds = shape.bytes;
     if (g_profiling && first_model) HIPCHECK(hipEventRecord(ws.ev[0], stream));

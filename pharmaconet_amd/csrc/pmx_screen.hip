@@ -171,7 +171,7 @@ struct ScreenParams {
     uint32_t max_nodes;        // of the library (sizes the LDS node tables)
     unsigned long long max_passes;
     uint32_t last_round;       // task_kernel: never queue (walk every subtree to its end)
-    uint32_t pad_;
+    uint32_t bound_cost; // per-candidate bounds are built when their cost estimate stays below this (build_bounds)
     float *scores;
     int32_t *status;
     int mode;                  // 0: slice pass over [lo, hi); 1: large-slice pass over ovf_list; 2: arena pass over carry_list
@@ -1262,7 +1262,7 @@ __device__ __forceinline__ void build_bounds(const ScreenParams &p, unsigned cha
         const uint32_t wf = ((uint32_t)uni(lk[f]) + SLOTS - 1) / SLOTS;
         cost += wf * wf * (L.ksumtot - (uint32_t)uni((int)ksum[f + 1]));
     }
-    if ((p.flags & 512) || cost > 8192u) {
+    if ((p.flags & 512) || cost > p.bound_cost) {
         for (int f = 0; f < nl; ++f) {
             const int kf = uni(lk[f]), ksf = uni(ksum[f]);
             const double r = Rt[(size_t)(f + 1) * G + c];
