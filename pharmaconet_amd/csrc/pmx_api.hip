@@ -550,10 +550,10 @@ static int score_screen(const pmx_model *model, const pmx_library *lib, const We
     const WaveShape<G> shape = wave_shape<G>(model->dm.K, (int)p.max_nodes);
     const uint32_t waves_per_cu = (uint32_t)std::max<long>(1, std::min<long>({(long)(kLdsPerCu / shape.bytes), 4L * PMX_SCREEN_WAVES, env_long("PMX_WAVES_PER_CU", 32)}));
     const uint32_t grid = (uint32_t)ws.num_cu * waves_per_cu;
-    // per-wavefront slice: 48 KB at 8 conformer lanes (99.7 % of the bench library's ligands fit), scaled with the lanes
+    // per-wavefront slice: 80 KB at 8 conformer lanes (every ligand of the bench library fits), scaled with the lanes
     // (table bytes grow with the square of the model's cluster count: the 11-cluster 6OIM-like model is the reference point)
     const long k_scale = std::max(1L, std::min(16L, ((long)model->dm.K * model->dm.K + 60) / 121));
-    const uint32_t slice_bytes = (uint32_t)std::max<long>(4, env_long("PMX_SLICE_KB", 48L * std::max(1, G / 8) * k_scale)) * 1024u;
+    const uint32_t slice_bytes = (uint32_t)std::max<long>(4, env_long("PMX_SLICE_KB", 80L * std::max(1, G / 8) * k_scale)) * 1024u;
     rc = grow(&ws.slices, &ws.slices_bytes, (size_t)grid * slice_bytes, stream);
     if (rc) return rc;
     // large slices for the ligands whose tables exceed a slice: as large as a table of this model and library can get, at most

@@ -345,7 +345,7 @@ static_assert(kOffBits + 8 * PMX_MAX_LEVELS + 8 <= kOffPath && kOffPath + 2 * PM
 // of a frame with >= 4 matches (Y holds >= 5): every ancestor's skip decision is settled by Y's existence, decisions
 // inside Y's subtree depend on candidate existence only (nm + mx < 5 is never true there), and its leaves only feed a
 // per-conformer maximum. So Y may be (i) dropped when no leaf below it can exceed the maxima found so far - leaf totals
-// are bounded by total(Y) + R[f + 1] (build_bounds) - and (ii) walked by another wavefront (task queue); both count as
+// are bounded by total(Y) + W[Y] (build_bounds) - and (ii) walked by another wavefront (task queue); both count as
 // "returned >= 1" for the parent. Scores and every skip decision stay what the reference computes.
 struct WaveStats { // lives in LDS, updated by lane 0
     unsigned long long frames, passes, over, items, exact, longest, tasks, overflow;
