@@ -198,6 +198,21 @@ template <typename T>
 __device__ inline T *uniptr(T *p) {
     return reinterpret_cast<T *>(uni64(reinterpret_cast<uint64_t>(p)));
 }
+// Largest value of the wavefront, in every lane: butterfly inside the rows of 16 lanes (DPP), then the four rows.
+__device__ inline float wave_max_f32(float v) {
+    int x = __float_as_int(v);
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0xB1, 0xf, 0xf, false))); // quad_perm [1,0,3,2]
+    x = __float_as_int(v);
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x4E, 0xf, 0xf, false))); // quad_perm [2,3,0,1]
+    x = __float_as_int(v);
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x124, 0xf, 0xf, false))); // row_ror:4
+    x = __float_as_int(v);
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x128, 0xf, 0xf, false))); // row_ror:8
+    x = __float_as_int(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(x, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(x, 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(x, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(x, 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
 __device__ inline void wave_sync() { // LDS / global hand-over between the lanes of one wavefront
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -520,6 +535,12 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
         const int hv = rl(w.hk, f);
         const int kf = hv & 255, ksf = rl(w.hks, f);
         const bool leaf_level = (hv & kLvLeaf) != 0;
+        // ordered frames (all candidates in one pass): the walker visits the surviving child with the largest bound first;
+        // rem = the slots not visited yet, in lane f of stB
+        constexpr bool ORD = G >= 2 && G <= 32;
+        const bool ordered = ORD && kf <= SLOTS && !leaf_level && !(hv & kLvFuse) && !(p.flags & 2048);
+        uint32_t rem = 0xffffffffu;
+        if (ORD) rem = (uint32_t)rl(w.stB, f);
         if (nb < kf) {
             // ---------------------------------------------------------------- one pass over candidates nb .. nb + SLOTS - 1
             const double tparent = tot[nm * G + c];
@@ -622,6 +643,7 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
                 valid = on && ((mask >> c) & 1ull) && lo > 0.f && sum == sum;
                 t = (tparent + (double)self) + sum; // parent + self + accumulated pair (tree.py:38-41)
             }
+            if (ordered) valid = valid && ((rem >> s) & 1u);
             const unsigned long long vb = __ballot(valid);
             if (cacheable && !(flags & kCached)) { // first pass of the frame (a cached frame has one window)
                 tc[tci * 64 + lane] = t;
@@ -766,7 +788,12 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
                                 stat->passes += pp;
                             }
                             if (reach) mx = mx > 5 - nm ? mx : 5 - nm;
-                            nb = bfirst + 1;
+                            if (ordered) {
+                                rem &= ~(1u << first_ss);
+                                w.stB = wl(w.stB, f, (int)rem);
+                            } else {
+                                nb = bfirst + 1;
+                            }
                             cb &= ~((2ull << bfirst) - 1ull);
                         }
                         keep = false;
@@ -776,11 +803,22 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
                 }
                 if (keep) {
                     // descend into the first surviving child (tree.py:94-97)
-                    const int ss = (__ffsll(ab) - 1) / G;
-                    const unsigned long long before = ss == 0 ? 0ull : (vb & ((1ull << (ss * G)) - 1ull));
-                    if (before) mx = mx > 1 ? mx : 1; // existing children dropped by the bound test return at least 1
+                    int ss;
+                    if (ordered) {
+                        const bool alive = (ab >> lane) & 1ull;
+                        const float key = alive ? fmaxf((float)(t + rbound), 0.f) : -1.f; // (a NaN total orders as 0)
+                        const float top = wave_max_f32(key);
+                        ss = (__ffsll(__ballot(alive && key == top)) - 1) / G;
+                        if (vb != ab) mx = mx > 1 ? mx : 1; // (lanes fail the bound test only under >= 4 matches, where every existing child returns >= 1)
+                        rem &= ~(1u << ss);
+                        if (!(ab & ~(GM << (ss * G)))) nb = 255; // no other survivor: the frame ends with this child
+                    } else {
+                        ss = (__ffsll(ab) - 1) / G;
+                        const unsigned long long before = ss == 0 ? 0ull : (vb & ((1ull << (ss * G)) - 1ull));
+                        if (before) mx = mx > 1 ? mx : 1; // existing children dropped by the bound test return at least 1
+                    }
                     const int bsel = rl(bvec, ss * G);
-                    nb = bsel + 1;
+                    if (!ordered) nb = bsel + 1;
                     if (filt) { // what is left of the frame's candidates (the slots below ss were dropped)
                         cb &= ~((2ull << bsel) - 1ull);
                         if (lane == 0) cbl[f] = cb;
@@ -792,6 +830,7 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
                     w.stC = wl(wl(w.stC, f, nb | (mx << 8) | ((int)flags << 16) | (nm << 24)), f + 1, ((int)kMatched << 16) | ((nm + 1) << 24));
                     w.stA = wl(w.stA, f + 1, (int)(uint32_t)cmask);
                     if (G > 32) w.stB = wl(w.stB, f + 1, (int)(uint32_t)(cmask >> 32));
+                    if (ORD) w.stB = wl(wl(w.stB, f, (int)rem), f + 1, -1);
                     // entry(this match, level f', b') = rowbase[f] + k_f * (ksum[f'] - ksum[f + 1]) + b * k_f' + b'
                     w.matRB = wl(w.matRB, nm, rl(w.hrow, f) - kf * rl(w.hks, f + 1));
                     w.matKA = wl(w.matKA, nm, kf | (bsel << 8) | (f << 16));
@@ -837,6 +876,7 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
             w.stC = wl(wl(w.stC, f, nb | (mx << 8) | ((int)flags << 16) | (nm << 24)), f + 1, nm << 24);
             w.stA = wl(w.stA, f + 1, (int)(uint32_t)mask);
             if (G > 32) w.stB = wl(w.stB, f + 1, (int)(uint32_t)(mask >> 32));
+            if (ORD) w.stB = wl(w.stB, f + 1, -1);
             ++f;
             ++w.frames;
             continue;
@@ -1473,6 +1513,7 @@ __device__ __forceinline__ bool prepare_walk(const ScreenParams &p, unsigned cha
     const uint64_t mask0 = uni64(th->mask);
     w.stA = wl(w.stA, f0, (int)(uint32_t)mask0);
     if (G > 32) w.stB = wl(w.stB, f0, (int)(uint32_t)(mask0 >> 32));
+    else w.stB = -1;
     w.stC = wl(w.stC, f0, ((nm0 ? (int)kMatched : 0) << 16) | (nm0 << 24));
     wave_sync();
     if (!(p.flags & 4) && f0 < nl && nm0 >= 5) {
