@@ -535,10 +535,10 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
         const int hv = rl(w.hk, f);
         const int kf = hv & 255, ksf = rl(w.hks, f);
         const bool leaf_level = (hv & kLvLeaf) != 0;
-        // ordered frames (all candidates in one pass): the walker visits the surviving child with the largest bound first;
-        // rem = the slots not visited yet, in lane f of stB
+        // ordered frames: of the candidates of a pass (a window of the frame's candidates) the walker visits the surviving child
+        // with the largest bound first; rem = the slots of the window not visited yet, in lane f of stB
         constexpr bool ORD = G >= 2 && G <= 32;
-        const bool ordered = ORD && kf <= SLOTS && !leaf_level && !(hv & kLvFuse) && !(p.flags & 2048);
+        const bool ordered0 = ORD && !leaf_level && !(hv & kLvFuse) && !(p.flags & 2048);
         uint32_t rem = 0xffffffffu;
         if (ORD) rem = (uint32_t)rl(w.stB, f);
         if (nb < kf) {
@@ -600,6 +600,7 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
                     cb_rest = x;
                 }
             }
+            const bool ordered = ordered0 && !filt;
             const bool on = bvec < kf;
             const int b_first = filt ? (cb ? __ffsll(cb) - 1 : 0) : nb; // a candidate idle slots may read (in bounds)
             // the candidate's bound goes out with the table loads (one memory round trip per pass, not two)
@@ -777,6 +778,7 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
                         if (deep) {
                             mx = mx > 1 ? mx : 1; // children given away (or dropped) return at least 1
                             nb += SLOTS;
+                            rem = 0xffffffffu;
                             cb = cb_rest;
                         } else {
                             uint32_t pp = 0;
@@ -811,7 +813,10 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
                         ss = (__ffsll(__ballot(alive && key == top)) - 1) / G;
                         if (vb != ab) mx = mx > 1 ? mx : 1; // (lanes fail the bound test only under >= 4 matches, where every existing child returns >= 1)
                         rem &= ~(1u << ss);
-                        if (!(ab & ~(GM << (ss * G)))) nb = 255; // no other survivor: the frame ends with this child
+                        if (!(ab & ~(GM << (ss * G)))) { // no other survivor: the window ends with this child
+                            nb += SLOTS;
+                            rem = 0xffffffffu;
+                        }
                     } else {
                         ss = (__ffsll(ab) - 1) / G;
                         const unsigned long long before = ss == 0 ? 0ull : (vb & ((1ull << (ss * G)) - 1ull));
@@ -842,6 +847,7 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
             } else { // every existing child of this pass was dropped (or none existed)
                 if (vb) mx = mx > 1 ? mx : 1;
                 nb += SLOTS;
+                rem = 0xffffffffu;
                 cb = cb_rest;
             }
             if (filt) {
@@ -850,6 +856,7 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
             }
             if (nb < kf) { // more candidates: another pass
                 w.stC = wl(w.stC, f, nb | (mx << 8) | ((int)flags << 16) | (nm << 24));
+                if (ORD) w.stB = wl(w.stB, f, (int)rem);
                 continue;
             }
         }
