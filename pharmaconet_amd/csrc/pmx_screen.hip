@@ -605,7 +605,7 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
             const int b_first = filt ? (cb ? __ffsll(cb) - 1 : 0) : nb; // a candidate idle slots may read (in bounds)
             // the candidate's bound goes out with the table loads (one memory round trip per pass, not two)
             double rbound = 0.0;
-            if (bounded) {
+            if (bounded || (ordered && cand_bounds<G>())) { // (the bound also orders the children of frames it cannot drop yet)
                 if constexpr (cand_bounds<G>()) rbound = *reinterpret_cast<const double *>(Wb + (((uint32_t)(ksf + (on ? bvec : b_first))) << (PSH + 1)) + 8u * (uint32_t)c);
                 else rbound = *reinterpret_cast<const double *>(w.Rb + (((uint32_t)(f + 1) << (PSH + 1)) + 8u * (uint32_t)c));
             }
