@@ -548,7 +548,7 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
             // f < nl only, so row f + 1 exists
             const bool bounded = nm >= bound_from && !leaf_level;
             double pooled = 0.0;
-            if (bounded) pooled = __longlong_as_double((long long)pool[c]);
+            if (bounded || ordered0) pooled = __longlong_as_double((long long)pool[c]);
             // pair-table rows of the matched ancestors against level f: lane q
             const int ebv = w.matRB + __mul24(w.matKA & 255, ksf) + __mul24((w.matKA >> 8) & 255, kf);
             // A frame with more candidates than slots is *filtered* first: which candidates exist as children - some conformer of
@@ -654,11 +654,30 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
             ++w.passes;
             if (vb) flags |= kAny;
             unsigned long long ab = vb;
-            if (bounded && vb) { // the children hold >= 5 matches: drop those that cannot raise a maximum
+            // Children with fewer than 5 matches are bound-tested too where the frame is ordered: nothing below a child that
+            // fails can raise a maximum, so all the frame still needs from it is whether it reaches 5 matches (tree.py:98) -
+            // nothing at all once another child has (max_num_matches is a maximum), else what probe() answers.
+            const bool shallow = ordered && cand_bounds<G>() && nm < 4 && bound_from != 255 && !(p.flags & 4096);
+            if ((bounded || shallow) && vb) { // drop the children that cannot raise a maximum
                 const double bp = pooled > w.best ? pooled : w.best;
                 ab = __ballot(valid && (t + rbound) * kBoundSlack > bp);
             }
-            if (leaf_level) {
+            int probe_slot = -1; // a child of this pass whose reach is probed (one call site)
+            bool handled = false;
+            if (shallow && ab != vb) {
+                const bool slot_vb = ((vb >> (s * G)) & GM) != 0, slot_ab = ((ab >> (s * G)) & GM) != 0;
+                const unsigned long long dropped = __ballot(c == 0 && slot_vb && !slot_ab);
+                if (dropped) {
+                    if (mx >= 5 - nm) { // a sibling reached 5 matches already: the dropped children change nothing
+                        rem &= ~(uint32_t)__ballot(lane < SLOTS && ((dropped >> ((lane * G) & 63)) & 1ull));
+                    } else {
+                        probe_slot = (__ffsll(dropped) - 1) / G;
+                        handled = true;
+                    }
+                }
+            }
+            if (handled) {
+            } else if (leaf_level) {
                 if (valid && t > w.best) w.best = t; // graph_match.py:105-108
                 nb += SLOTS;
                 cb = cb_rest;
@@ -781,22 +800,7 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
                             rem = 0xffffffffu;
                             cb = cb_rest;
                         } else {
-                            uint32_t pp = 0;
-                            const int bfirst = rl(bvec, first_ss * G);
-                            const bool reach = probe<G>(w, f, nm, bfirst, (vb >> (first_ss * G)) & GM, pp);
-                            if (lane == 0) {
-                                stat->pad[0] += pp;
-                                stat->pad[1] += 1;
-                                stat->passes += pp;
-                            }
-                            if (reach) mx = mx > 5 - nm ? mx : 5 - nm;
-                            if (ordered) {
-                                rem &= ~(1u << first_ss);
-                                w.stB = wl(w.stB, f, (int)rem);
-                            } else {
-                                nb = bfirst + 1;
-                            }
-                            cb &= ~((2ull << bfirst) - 1ull);
+                            probe_slot = first_ss;
                         }
                         keep = false;
                     } else if (lane == 0) {
@@ -811,7 +815,7 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
                         const float key = alive ? fmaxf((float)(t + rbound), 0.f) : -1.f; // (a NaN total orders as 0)
                         const float top = wave_max_f32(key);
                         ss = (__ffsll(__ballot(alive && key == top)) - 1) / G;
-                        if (vb != ab) mx = mx > 1 ? mx : 1; // (lanes fail the bound test only under >= 4 matches, where every existing child returns >= 1)
+                        if (vb != ab) mx = mx > 1 ? mx : 1; // (an existing child - visited, dropped or probed - returns at least 1)
                         rem &= ~(1u << ss);
                         if (!(ab & ~(GM << (ss * G)))) { // no other survivor: the window ends with this child
                             nb += SLOTS;
@@ -849,6 +853,21 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
                 nb += SLOTS;
                 rem = 0xffffffffu;
                 cb = cb_rest;
+            }
+            if (probe_slot >= 0) { // (handed over, or dropped by the bound test: either way the walker does not go there)
+                uint32_t pp = 0;
+                const int bp_ = rl(bvec, probe_slot * G);
+                const bool reach = probe<G>(w, f, nm, bp_, (vb >> (probe_slot * G)) & GM, pp);
+                if (lane == 0) {
+                    stat->pad[0] += pp;
+                    stat->pad[1] += 1;
+                    stat->passes += pp;
+                }
+                mx = mx > 1 ? mx : 1;
+                if (reach) mx = mx > 5 - nm ? mx : 5 - nm;
+                if (ordered) rem &= ~(1u << probe_slot);
+                else nb = bp_ + 1;
+                cb &= ~((2ull << bp_) - 1ull);
             }
             if (filt) {
                 if (lane == 0) cbl[f] = cb;
