@@ -590,7 +590,7 @@ static int score_screen(const pmx_model *model, const pmx_library *lib, const We
     p.list_cap = super;
     p.queue = ws.queue;
     p.qcap = (uint32_t)std::min<size_t>(ws.queue_bytes / task_rec_bytes<G>() / kShards, 0x3fffffffu / kShards);
-    p.budget = (uint32_t)std::max<long>(16, env_long("PMX_BUDGET", 768));
+    p.budget = (uint32_t)std::max<long>(16, env_long("PMX_BUDGET", 512));
     p.min_levels = (uint32_t)std::max<long>(0, env_long("PMX_MIN_LEVELS", 3));
     p.max_passes = (unsigned long long)std::max<long>(1, env_long("PMX_MAXITERS", 1L << 40));
     p.scores = scores_dev;
