@@ -361,7 +361,10 @@ static_assert(kOffBits + 8 * PMX_MAX_LEVELS + 8 <= kOffPath && kOffPath + 2 * PM
 // inside Y's subtree depend on candidate existence only (nm + mx < 5 is never true there), and its leaves only feed a
 // per-conformer maximum. So Y may be (i) dropped when no leaf below it can exceed the maxima found so far - leaf totals
 // are bounded by total(Y) + W[Y] (build_bounds) - and (ii) walked by another wavefront (task queue); both count as
-// "returned >= 1" for the parent. Scores and every skip decision stay what the reference computes.
+// "returned >= 1" for the parent. A child Y with fewer than 5 matches whose bound fails feeds no maximum either; what its
+// parent's decision (nm + mx < 5) needs from it is whether a node with >= 5 matches exists below it - probe() - and nothing
+// once mx has reached 5 - nm through a sibling. The order in which children are visited changes neither maxima nor
+// existence. Scores and every skip decision stay what the reference computes.
 struct WaveStats { // lives in LDS, updated by lane 0
     unsigned long long frames, passes, over, items, exact, longest, tasks, overflow;
     unsigned long long cyc_scan, cyc_tables, cyc_bounds, cyc_walk, cyc_busy, cyc_idle, pad[2]; // s_memtime ticks per phase
