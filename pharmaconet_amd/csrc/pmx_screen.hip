@@ -523,10 +523,25 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
     // paths of the loop meet.) One iteration = one pass over the frame's next candidates, or the end of the frame.
     int f = w.f;
     int ret = 0;
+    // The walkers of a split ligand (its subtrees, and the walk that queued them) trade maxima through the ligand's record
+    // while they run, not only when they end: one returning atomic maximum per conformer every kShareEvery passes gives this
+    // wave's maxima to the others and theirs to this wave's bound test. (Maxima of leaves of the same tree: exact.)
+    constexpr uint32_t kShareEvery = 64;
+    uint32_t next_share = w.passes + kShareEvery;
     for (;;) {
         if (w.passes > budget32) { // over budget: the caller moves the job's tables to the arena and resumes in export mode
             w.f = f;
             return kOverBudget;
+        }
+        if (rec16 != 0u && w.passes >= next_share && !(p.flags & 8192)) {
+            next_share = w.passes + kShareEvery;
+            if (s == 0) {
+                unsigned long long *gb = reinterpret_cast<unsigned long long *>(p.arena + (size_t)rec16 * 16 + sizeof(RecHeader));
+                const unsigned long long mine = pool[c];
+                const unsigned long long theirs = mine ? atomicMax(&gb[c], mine) : __hip_atomic_load(&gb[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (theirs > mine) pool[c] = theirs;
+            }
+            lds_sync();
         }
         const int sc = rl(w.stC, f);
         int nb = sc & 255, mx = (sc >> 8) & 255;
