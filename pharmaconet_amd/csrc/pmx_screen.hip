@@ -526,7 +526,7 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
     // The walkers of a split ligand (its subtrees, and the walk that queued them) trade maxima through the ligand's record
     // while they run, not only when they end: one returning atomic maximum per conformer every kShareEvery passes gives this
     // wave's maxima to the others and theirs to this wave's bound test. (Maxima of leaves of the same tree: exact.)
-    constexpr uint32_t kShareEvery = 64;
+    constexpr uint32_t kShareEvery = 16;
     uint32_t next_share = w.passes + kShareEvery;
     for (;;) {
         if (w.passes > budget32) { // over budget: the caller moves the job's tables to the arena and resumes in export mode
