@@ -224,6 +224,7 @@ def test_scores_do_not_depend_on_how_the_work_is_cut(monkeypatch):
         {"PMX_TREE_FLAGS": "128"},                   # frames with more candidates than slots are not filtered through the V masks first
         {"PMX_TREE_FLAGS": "256"},
         {"PMX_TREE_FLAGS": "512"},
+        {"PMX_TREE_FLAGS": "8192"},                  # the walkers of a split ligand do not trade maxima while they run
         {"PMX_TREE_FLAGS": "4096"},                  # children with fewer than 5 matches are never bound-tested (walked, not probed)
         {"PMX_TREE_FLAGS": "2048"},                  # children visited first to last instead of largest bound first
         {"PMX_TREE_FLAGS": "2048", "PMX_BUDGET": "16", "PMX_MIN_LEVELS": "0"},                   # children tested against the per-level bound instead of their own                   # a ligand's subtrees spread over the queue shards instead of kept in one
