@@ -156,7 +156,7 @@ static int build_pair_functions(pmx_model *m, const pmx_model_desc *d, const std
     float h = 0.5f;
     while (h > std_min / 4.f && h > 1.f / 64.f) h *= 0.5f;
     const uint32_t ncell = (uint32_t)std::ceil((double)dmax / (double)h) + 1;
-    if (ncell > 16384 || (uint64_t)NS * NS * ncell * sizeof(FnCell) > (4ull << 30))
+    if (ncell > 16384 || (uint64_t)NS * NS * ncell * sizeof(FnCell) >= (4ull << 30)) // (the kernels address the table with 32-bit byte offsets)
         return fail(PMX_ERR_INVALID, "pair-function tables of this model would take %llu cells x %u x %u subsets", (unsigned long long)ncell, NS, NS);
     // exact pass window of every model edge
     std::vector<float> wlo((size_t)Nm * Nm), whi((size_t)Nm * Nm);

@@ -1017,7 +1017,8 @@ __device__ __forceinline__ ItemLoad item_load(const ScreenParams &p, uint32_t si
     L.t = fminf(x - (float)ci, 1.0f);
     L.d = d;
     L.sidu = sidu, L.sidv = sidv;
-    const float4 *cell = reinterpret_cast<const float4 *>(p.F.cells + (fn_index(p.F, sidu, sidv) * p.F.ncell + (uint32_t)ci));
+    const uint32_t off = (fn_index(p.F, sidu, sidv) * p.F.ncell + (uint32_t)ci) * 32u; // (the table is a few MB: 32 bits)
+    const float4 *cell = reinterpret_cast<const float4 *>(reinterpret_cast<const unsigned char *>(p.F.cells) + off);
     L.a = cell[0];
     L.b = cell[1];
     return L;
@@ -1141,7 +1142,10 @@ struct Pos3 {
 };
 
 // LigandNodeCluster.center / .size for one conformer (ligand.py:458-473).
-__device__ __forceinline__ void center_size(const float *xyz, int C, int start, int end, int cc, Pos3 &center, float &size) {
+// (a pointer into device memory, said so: a generic pointer costs flat loads, which also wait on the LDS counter, and 64-bit
+// address arithmetic per load)
+typedef const __attribute__((address_space(1))) float *GlobalFloats;
+__device__ __forceinline__ void center_size(GlobalFloats xyz, int C, int start, int end, int cc, Pos3 &center, float &size) {
     float sx = 0.f, sy = 0.f, sz = 0.f;
     for (int u = start; u < end; ++u) {
         const uint32_t o = (uint32_t)(u * 3 * C + cc);
@@ -1174,7 +1178,7 @@ __device__ __forceinline__ void build_tables(const ScreenParams &p, unsigned cha
     const uint16_t *ksum = reinterpret_cast<const uint16_t *>(lds + kOffKsum), *ncoff = reinterpret_cast<const uint16_t *>(lds + kOffNcoff);
     const uint8_t *cand = lds + ws.off_cand, *lcnt = lds + ws.off_lcnt;
     const uint16_t *nc = reinterpret_cast<const uint16_t *>(lds + ws.off_nc);
-    const float *xyz = uniptr(r.xyz);
+    GlobalFloats xyz = (GlobalFloats)uniptr(r.xyz);
     float *St = reinterpret_cast<float *>(rec + rec_s_off<G>());
     float *Pt = reinterpret_cast<float *>(rec + rec_p_off<G>(L.ksumtot));
     unsigned char *Vt = rec + rec_v_off<G>(L.ksumtot, L.T, (uint32_t)L.nl);
@@ -1697,7 +1701,7 @@ __global__ __launch_bounds__(64, PMX_SCREEN_WAVES) void ligand_kernel(const Scre
         const unsigned char *root = lds + ws.off_task;
         const uint32_t rec16 = (uint32_t)uni((int)reinterpret_cast<const TaskRec *>(root)->rec16);
         Walk<G> w;
-        if (prepare_walk<G>(p, lds, ws, root, rec, w)) run_job<G>(p, lds, ws, w, rec, rec16, false, wave_id, stat);
+        if (!(p.flags & 16384) && prepare_walk<G>(p, lds, ws, root, rec, w)) run_job<G>(p, lds, ws, w, rec, rec16, false, wave_id, stat);
     }
     wave_sync();
     if (lane0 == 0) flush_wave_stats(p, stat, wave_id, __builtin_amdgcn_s_memtime() - t_start);
