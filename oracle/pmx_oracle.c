@@ -23,6 +23,33 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* Tables of one ligand come out of a per-thread bump arena that is reset per ligand (the comparator used to call calloc per
+ * table); a request that does not fit a chunk falls back to calloc and is freed with the ligand. */
+#define ARENA_BYTES ((size_t)8 << 20)
+#define ARENA_SPILL 4096
+static _Thread_local unsigned char *tl_arena;
+static _Thread_local size_t tl_top;
+static _Thread_local void *tl_spill[ARENA_SPILL];
+static _Thread_local int tl_nspill;
+static void *arena_calloc(size_t n, size_t size) {
+    const size_t bytes = (n * size + 63) & ~(size_t)63;
+    if (!tl_arena) tl_arena = (unsigned char *)malloc(ARENA_BYTES);
+    if (tl_arena && tl_top + bytes <= ARENA_BYTES) {
+        void *p = tl_arena + tl_top;
+        tl_top += bytes;
+        memset(p, 0, bytes);
+        return p;
+    }
+    void *p = calloc(n ? n : 1, size ? size : 1);
+    if (tl_nspill < ARENA_SPILL) tl_spill[tl_nspill++] = p; /* (beyond that: leaked, never seen) */
+    return p;
+}
+static void arena_reset(void) {
+    for (int i = 0; i < tl_nspill; ++i) free(tl_spill[i]);
+    tl_nspill = 0;
+    tl_top = 0;
+}
+
 #define MAX_LEVELS 20 /* scoring/graph_match.py:88 */
 #define MAX_K 64
 #define MAX_N 64
@@ -183,7 +210,7 @@ static void build_node_matches(ctx_t *X, const float w[7]) {
         for (int s = 0; s < X->k[i]; ++s) {
             int a = X->cand[i][s];
             match_list *ml = &X->nm[i][s];
-            ml->items = (node_match *)calloc((size_t)(end - start), sizeof(node_match));
+            ml->items = (node_match *)arena_calloc((size_t)(end - start), sizeof(node_match));
             ml->len = 0;
             for (int u = start; u < end; ++u) { /* cluster iteration order, graph_match.py:159 */
                 node_match *it = &ml->items[ml->len];
@@ -208,7 +235,7 @@ static void build_tables(ctx_t *X, oracle_result *R) {
     int16_t fails[MAX_C];
     for (int i = 0; i < X->nl; ++i) {
         /* self table, match_utils.py:77-122 */
-        X->S[i] = (float *)calloc((size_t)X->k[i] * C, sizeof(float));
+        X->S[i] = (float *)arena_calloc((size_t)X->k[i] * C, sizeof(float));
         for (int s = 0; s < X->k[i]; ++s) {
             const match_list *ml = &X->nm[i][s];
             float *sc = X->S[i] + (size_t)s * C;
@@ -223,7 +250,7 @@ static void build_tables(ctx_t *X, oracle_result *R) {
         for (int j = i + 1; j < X->nl; ++j) {
             int cj = X->lev_cluster[j];
             int sj = cj ? L->cluster_end[cj - 1] : 0, ej = L->cluster_end[cj];
-            float *tab = (float *)calloc((size_t)X->k[i] * X->k[j] * C, sizeof(float));
+            float *tab = (float *)arena_calloc((size_t)X->k[i] * X->k[j] * C, sizeof(float));
             X->P[i][j] = tab;
             /* graph_match.py:240-241 */
             float ldist[MAX_C], lsize[MAX_C];
@@ -328,7 +355,8 @@ static int dfs(ctx_t *X, int level, int matched, int num_matches, const uint8_t 
 }
 
 static void score_ligand(const oracle_model *M, const uint8_t *rec, const float w[7], oracle_result *R, int variant) {
-    ctx_t *X = (ctx_t *)calloc(1, sizeof(ctx_t));
+    arena_reset();
+    ctx_t *X = (ctx_t *)arena_calloc(1, sizeof(ctx_t));
     memset(R, 0, sizeof(*R));
     X->M = M;
     X->variant = variant;
@@ -374,12 +402,7 @@ static void score_ligand(const oracle_model *M, const uint8_t *rec, const float 
         R->n_leaf = X->n_leaf;
         R->n_terms = X->n_terms;
     }
-    for (int i = 0; i < X->nl; ++i) {
-        free(X->S[i]);
-        for (int j = i + 1; j < X->nl; ++j) free(X->P[i][j]);
-        for (int s = 0; s < X->k[i]; ++s) free(X->nm[i][s].items);
-    }
-    free(X);
+    arena_reset();
 }
 
 /* Scores ligands [first, first+count) of a packed library. `results` may be NULL. Returns 0. */
