@@ -483,6 +483,8 @@ struct ScreenWs {
     size_t slices_bytes = 0;
     uint8_t *big = nullptr;
     size_t big_bytes = 0;
+    uint8_t *totbuf = nullptr;
+    size_t totbuf_bytes = 0;
     uint8_t *arena = nullptr;
     size_t arena_bytes = 0;
     uint8_t *queue = nullptr;
@@ -570,6 +572,11 @@ static int score_screen(const pmx_model *model, const pmx_library *lib, const We
     }
     rc = grow(&ws.big, &ws.big_bytes, (size_t)big_grid * big_bytes, stream);
     if (rc) return rc;
+    if (!totals_in_lds<G>()) {
+        rc = grow(&ws.totbuf, &ws.totbuf_bytes, (size_t)ws.num_cu * 4u * std::max(PMX_SCREEN_WAVES, PMX_TASK_WAVES) * kTotBufBytes, stream);
+        if (rc) return rc;
+    }
+    p.totbuf = ws.totbuf;
     rc = grow(&ws.arena, &ws.arena_bytes, (size_t)std::max<long>(16, env_long("PMX_ARENA_MB", 32768)) << 20, stream);
     if (rc) return rc;
     rc = grow(&ws.queue, &ws.queue_bytes, (size_t)std::max<long>(1, env_long("PMX_TASKQ_MB", 2048L * std::max(1, G / 8))) << 20, stream);
@@ -748,7 +755,7 @@ extern "C" int pmx_release_workspaces(int device) {
         }
         ScreenWs &w = *it->second;
         std::lock_guard<std::mutex> wl(w.mu);
-        for (void *q : {(void *)w.ctl, (void *)w.slices, (void *)w.big, (void *)w.arena, (void *)w.queue, (void *)w.lists})
+        for (void *q : {(void *)w.ctl, (void *)w.slices, (void *)w.big, (void *)w.totbuf, (void *)w.arena, (void *)w.queue, (void *)w.lists})
             if (q) (void)hipFree(q);
         for (auto &e : w.ev)
             if (e) (void)hipEventDestroy(e);

@@ -147,6 +147,14 @@ struct Ctl {
     unsigned long long stats[kScreenStatShards][kStatWords]; // sharded: [0] frames [1] passes [2] walks over budget [3] items [4] exact-count cells [5] longest walk [6] tasks [7] slice overflows [8..12] phase ticks
 };
 
+// With 32 or 64 conformer lanes the float64 path totals (21 rows of G) are 5 / 11 KB: kept in LDS they cap the CU at 8 wavefronts.
+// There they live in global memory (one buffer per wavefront, L1 / L2 resident), and the children cache - a frame of those
+// shapes never has all its candidates in one pass - has no LDS at all.
+constexpr uint32_t kTotBufBytes = 16384;
+template <int G>
+__host__ __device__ constexpr bool totals_in_lds() {
+    return G < 32;
+}
 struct ScreenParams {
     DevModel M;
     FnTable F;
@@ -157,6 +165,7 @@ struct ScreenParams {
     uint64_t first;            // library index of the call's first ligand
     uint32_t lo, hi;           // ligands [lo, hi) of the call (relative to first) are this super-chunk
     Ctl *ctl;
+    uint8_t *totbuf;           // [waves][kTotBufBytes]: the path totals of the 32 / 64-lane shapes (LDS at fewer lanes)
     uint8_t *slices;           // [waves][slice_bytes]
     uint32_t slice_bytes;
     uint8_t *arena;
@@ -320,7 +329,7 @@ __host__ __device__ inline WaveShape<G> wave_shape(int K, int max_nodes) {
     o += w.nc_cap * 2;
     o = (o + 15u) & ~15u;
     w.off_tot = o;
-    o += (PMX_MAX_LEVELS + 1) * G * 8;
+    if (totals_in_lds<G>()) o += (PMX_MAX_LEVELS + 1) * G * 8;
     w.off_pool = o;
     o += G * 8;
     w.off_stat = o; // the wave's statistics (kept out of the registers)
@@ -331,7 +340,7 @@ __host__ __device__ inline WaveShape<G> wave_shape(int K, int max_nodes) {
     w.off_tch = o; // totals of a frame's children (fused last two levels)
     o += 64 * 8;
     w.off_tc = o; // the children's totals of the kTcLevels deepest unfused frames + their validity ballots
-    o += kTcLevels * (64 * 8 + 8);
+    if (totals_in_lds<G>()) o += kTcLevels * (64 * 8 + 8);
     w.off_cb = o; // candidates of a filtered frame that are still to visit, one 64-bit set per level
     o += PMX_MAX_LEVELS * 8;
     w.bytes = o;
@@ -863,7 +872,8 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
                     w.matKA = wl(w.matKA, nm, kf | (bsel << 8) | (f << 16));
                     ++f;
                     ++w.frames;
-                    lds_sync(); // the child's total is read by all slots
+                    if (totals_in_lds<G>()) lds_sync(); // the child's total is read by all slots
+                    else wave_sync();
                     continue;
                 }
             } else { // every existing child of this pass was dropped (or none existed)
@@ -1523,7 +1533,7 @@ template <int G>
 __device__ __forceinline__ bool prepare_walk(const ScreenParams &p, unsigned char *lds, const WaveShape<G> &ws, const unsigned char *tr, unsigned char *rec, Walk<G> &w) {
     const int lane = lane_id();
     const int s = lane / G, c = lane % G;
-    double *tot = reinterpret_cast<double *>(lds + ws.off_tot);
+    double *tot = totals_in_lds<G>() ? reinterpret_cast<double *>(lds + ws.off_tot) : reinterpret_cast<double *>(p.totbuf + (size_t)blockIdx.x * kTotBufBytes);
     unsigned long long *pool = reinterpret_cast<unsigned long long *>(lds + ws.off_pool);
     const TaskRec *th = reinterpret_cast<const TaskRec *>(tr);
     const RecHeader *H = reinterpret_cast<const RecHeader *>(rec);
@@ -1540,7 +1550,7 @@ __device__ __forceinline__ bool prepare_walk(const ScreenParams &p, unsigned cha
         const int tci = nl - 3 - lane;
         int kind = lane == nl - 1 ? kLvLeaf : 0;
         if (lane == nl - 2 && knext <= 64 / G && !(p.flags & 32)) kind |= kLvFuse;
-        if (tci >= 0 && tci < kTcLevels && kl <= 64 / G && !(p.flags & 64)) kind |= kLvCache | (tci << 12);
+        if (totals_in_lds<G>() && tci >= 0 && tci < kTcLevels && kl <= 64 / G && !(p.flags & 64)) kind |= kLvCache | (tci << 12);
         w.hk = kl | kind;
     }
     w.hks = lane <= nl ? (int)H->ksum[lane] : 0;
@@ -1581,7 +1591,7 @@ __device__ __forceinline__ void run_job(const ScreenParams &p, unsigned char *ld
                                         const bool is_task, const uint32_t wave_id, WaveStats *stat) {
     const int lane = lane_id();
     const int s = lane / G, c = lane % G;
-    double *tot = reinterpret_cast<double *>(lds + ws.off_tot);
+    double *tot = totals_in_lds<G>() ? reinterpret_cast<double *>(lds + ws.off_tot) : reinterpret_cast<double *>(p.totbuf + (size_t)blockIdx.x * kTotBufBytes);
     unsigned long long *pool = reinterpret_cast<unsigned long long *>(lds + ws.off_pool);
     uint16_t *pathbuf = reinterpret_cast<uint16_t *>(lds + kOffPath);
     double *tch = reinterpret_cast<double *>(lds + ws.off_tch);
