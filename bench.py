@@ -141,6 +141,22 @@ def cpu_baseline(model, offsets, data, n_conf, budget_s=15.0):
     }, work
 
 
+def issue_block(n_lig, pass_ms):
+    """Scalar / vector wave-instructions per ligand (committed SQ counters) against the CU's issue rates at this run's pass time."""
+    try:
+        sq = json.loads((REPO / "profiles" / "r3_pmc_sq_summary.json").read_text())["counters"]
+        salu = sum(v["SQ_INSTS_SALU"] for v in sq.values()) / (2 * 200704)
+        valu = sum(v["SQ_INSTS_VALU"] for v in sq.values()) / (2 * 200704)
+    except Exception:
+        return None
+    cus, clock_hz = 256, 2.4e9
+    scalar_ms = salu * n_lig / cus / clock_hz * 1e3          # one scalar wave-instruction per cycle and CU
+    vector_ms = valu * n_lig * 2 / (4 * cus) / clock_hz * 1e3  # a wave64 VALU instruction holds one of 4 SIMD-32s for 2 cycles
+    return {"scalar_insts_per_ligand": salu, "vector_insts_per_ligand": valu, "scalar_unit_busy": scalar_ms / pass_ms,
+            "vector_units_busy": vector_ms / pass_ms, "pass_ms": pass_ms,
+            "note": "counts from profiles/r3_pmc_sq_summary.json (rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_VALU, 2 passes over 200704 ligands)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -302,8 +318,12 @@ def main():
                 "profiled_pass_ms": prof["ms_total"],
                 "note": "HIP-event times of one extra, untimed pass with pmx_set_profiling(1) (event records on the call's stream, no synchronisation); "
                         "the timed steps run with profiling off. The path is not HBM-bound (SURVEY.md section 0, DESIGN.md section 4): what binds is "
-                        "the CU's scalar instruction issue (DESIGN.md section 4, profiles/r3_pmc_sq_summary.json).",
+                        "the CU's scalar instruction issue, see `issue` (DESIGN.md section 4).",
             },
+            # The resource that is busiest on this path: the CU's scalar unit, one wave-instruction per cycle.
+            # Instruction counts per ligand from the committed PMC pass (profiles/r3_pmc_sq_summary.json: 200 704 ligands, the
+            # timed step + the profiled pass = 2 passes), priced at this run's time per pass.
+            "issue": issue_block(n_lig, prof["ms_total"]) if (args.conformers == 8 and len(pockets) == 1) else None,
             # what the kernels do per ligand, and how that compares with the CU's issue rate (one VALU and one SALU wave-instruction
             # per cycle and CU: MI355X_MICROARCH.md); instruction counts from profiles/r3_pmc_sq.json
             "work": {
