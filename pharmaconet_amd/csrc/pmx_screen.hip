@@ -1688,7 +1688,7 @@ __global__ __launch_bounds__(64, PMX_SCREEN_WAVES) void ligand_kernel(const Scre
     const WaveShape<G> ws = wave_shape<G>(p.M.K, (int)p.max_nodes);
     const uint32_t todo = p.mode == 0 ? p.hi - p.lo : (p.mode == 1 ? min(p.ctl->ovf_count, p.list_cap) : min(p.ctl->carry_count, p.list_cap));
     const uint32_t *list = p.mode == 1 ? p.ovf_list : p.carry_list;
-    constexpr uint32_t kBatch = 4; // ligands claimed per atomic on the cursor
+    constexpr uint32_t kBatch = 1; // ligands claimed per atomic on the cursor
     WaveStats *stat = reinterpret_cast<WaveStats *>(lds + ws.off_stat);
     if (lane0 < 16) reinterpret_cast<unsigned long long *>(stat)[lane0] = 0ull;
     wave_sync();
