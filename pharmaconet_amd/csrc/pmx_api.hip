@@ -597,7 +597,9 @@ static int score_screen(const pmx_model *model, const pmx_library *lib, const We
     p.list_cap = super;
     p.queue = ws.queue;
     p.qcap = (uint32_t)std::min<size_t>(ws.queue_bytes / task_rec_bytes<G>() / kShards, 0x3fffffffu / kShards);
-    p.budget = (uint32_t)std::max<long>(16, env_long("PMX_BUDGET", 512));
+    const uint32_t lig_budget = (uint32_t)std::max<long>(16, env_long("PMX_BUDGET", 512));
+    const uint32_t task_budget = (uint32_t)std::max<long>(16, env_long("PMX_TASK_BUDGET", lig_budget)); // a queued subtree's own budget
+    p.budget = lig_budget;
     p.min_levels = (uint32_t)std::max<long>(0, env_long("PMX_MIN_LEVELS", 3));
     p.max_passes = (unsigned long long)std::max<long>(1, env_long("PMX_MAXITERS", 1L << 40));
     p.scores = scores_dev;
@@ -620,6 +622,7 @@ static int score_screen(const pmx_model *model, const pmx_library *lib, const We
         ws.ligands_last = p.hi - p.lo;
         ctl_clear_kernel<<<dim3((sizeof(Ctl) / 4 + 255) / 256), dim3(256), 0, stream>>>(ws.ctl, (lo == 0 && first_model) ? 1 : 0);
         p.last_round = 0;
+        p.budget = lig_budget;
         // every ligand whose tables fit a slice
         p.slices = ws.slices;
         p.slice_bytes = slice_bytes;
@@ -633,6 +636,7 @@ static int score_screen(const pmx_model *model, const pmx_library *lib, const We
         if (g_profiling) HIPCHECK(hipEventRecord(ws.ev[2], stream));
         // the subtrees the over-budget walkers queued, and the ones those queue in turn: a fixed number of rounds, each a snapshot of
         // the queue and one persistent launch (an empty round exits at once); the last round walks everything to its end
+        p.budget = task_budget;
         for (int r = 0; r < rounds; ++r) {
             p.last_round = r + 1 == rounds ? 1u : 0u;
             round_kernel<<<dim3(1), dim3(64), 0, stream>>>(ws.ctl, p.qcap);
