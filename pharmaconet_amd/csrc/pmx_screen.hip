@@ -414,14 +414,9 @@ constexpr double kBoundSlack = 1.0 + 1e-9; // covers the float64 rounding of the
 // lanes above the current frame, which the walker re-writes when it descends itself.
 template <int G>
 __device__ __forceinline__ bool probe(Walk<G> &w, int f, int nm, int cand, uint64_t cmask, uint32_t &passes) {
-    constexpr int SLOTS = 64 / G;
-    constexpr int PSH = G == 1 ? 2 : G == 2 ? 3 : G == 4 ? 4 : G == 8 ? 5 : G == 16 ? 6 : G == 32 ? 7 : 8;
-    constexpr uint64_t GM = group_mask<G>();
     const int lane = lane_id();
-    const int s = lane / G, c = lane % G;
-    const uint32_t lane_off = (uint32_t)lane * 4u;
     const int nl = w.nl;
-    const unsigned char *Pb = w.Pb;
+    const unsigned char *Vb = w.Vb;
     if (nm + 1 >= 5) return true;
     // enter the child
     const int fbase = f;
@@ -444,42 +439,47 @@ __device__ __forceinline__ bool probe(Walk<G> &w, int f, int nm, int cand, uint6
             bool descended = false;
             if (nb < kf) {
                 const int ebv = w.matRB + __mul24(w.matKA & 255, ksf) + __mul24((w.matKA >> 8) & 255, kf);
-                while (nb < kf) {
-                    const bool on = nb + s < kf;
-                    const uint32_t bo = on ? lane_off : (uint32_t)c * 4u;
-                    bool ok = on && ((mask >> c) & 1ull);
-                    int q = 0;
-                    for (; q + 4 <= nm; q += 4) { // four rows in flight (no short circuit: the loads do not wait for each other)
-                        float v[4];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float *>(Pb + (((uint32_t)(rl(ebv, q + u) + nb) << PSH) + bo));
-                        ok = ok & (v[0] > 0.f) & (v[1] > 0.f) & (v[2] > 0.f) & (v[3] > 0.f);
-                    }
-                    for (; q < nm; ++q) ok = ok & (*reinterpret_cast<const float *>(Pb + (((uint32_t)(rl(ebv, q) + nb) << PSH) + bo)) > 0.f);
-                    const unsigned long long vb = __ballot(ok);
-                    ++passes;
-                    if (!vb) {
-                        nb += SLOTS;
-                        continue;
-                    }
+                // every candidate of the level at once, lane l <-> candidate l: which exist as children - some conformer of
+                // the frame has every pair entry > 0 - is one AND of V masks per matched ancestor (no table row is read)
+                constexpr uint32_t VB = vmask_bytes<G>();
+                const bool in = lane >= nb && lane < kf;
+                const uint32_t lo_ = (uint32_t)(lane < kf ? lane : 0) * VB;
+                auto vload = [&](int q) -> unsigned long long {
+                    const unsigned char *ve = Vb + (uint32_t)rl(ebv, q) * VB + lo_;
+                    if (G <= 8) return *ve;
+                    else if (G == 16) return *reinterpret_cast<const uint16_t *>(ve);
+                    else if (G == 32) return *reinterpret_cast<const uint32_t *>(ve);
+                    else return *reinterpret_cast<const unsigned long long *>(ve);
+                };
+                unsigned long long m = mask;
+                int q = 0;
+                for (; q + 4 <= nm; q += 4) { // four masks in flight
+                    const unsigned long long v0 = vload(q), v1 = vload(q + 1), v2 = vload(q + 2), v3 = vload(q + 3);
+                    m &= (v0 & v1) & (v2 & v3);
+                }
+                for (; q < nm; ++q) m &= vload(q);
+                const unsigned long long ex = __ballot(in && m != 0ull);
+                ++passes;
+                if (!ex) {
+                    nb = kf;
+                } else {
                     flags |= kAny;
                     if (nm + 1 >= 5) return true; // a node with 5 matches
-                    const int ss = (__ffsll(vb) - 1) / G;
-                    const int bsel = nb + ss;
+                    const int bsel = __ffsll(ex) - 1;
                     nb = bsel + 1;
                     w.stA = wl(w.stA, f, (int)(uint32_t)mask);
                     if (G > 32) w.stB = wl(w.stB, f, (int)(uint32_t)(mask >> 32));
                     w.stC = wl(w.stC, f, nb | (mx << 8) | ((int)flags << 16) | (nm << 24));
                     w.matRB = wl(w.matRB, nm, rl(w.hrow, f) - kf * rl(w.hks, f + 1));
                     w.matKA = wl(w.matKA, nm, kf | (bsel << 8) | (f << 16));
-                    mask = (vb >> (ss * G)) & GM;
+                    mask = (uint64_t)(uint32_t)rl((int)(uint32_t)m, bsel);
+                    if (G > 32) mask |= (uint64_t)(uint32_t)rl((int)(uint32_t)(m >> 32), bsel) << 32;
                     ++f;
                     ++nm;
                     flags = kMatched;
                     nb = 0;
                     mx = 0;
                     descended = true;
-                    break;
                 }
             }
             if (descended) continue;
