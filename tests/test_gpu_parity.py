@@ -157,6 +157,12 @@ def test_bench_size_library_properties_and_oracle_sample(oracle, monkeypatch):
         again = model.screen(lib).scores
     assert torch.equal(again, full)
     assert again.double().sum().item() == checksum
+    # the search as the reference runs it - every subtree walked, nothing dropped, probed, reordered or shared (PMX_TREE_FLAGS=4
+    # switches the bound test off, and with it everything built on it) - gives the same bits on every one of the ligands
+    with monkeypatch.context() as mp:
+        mp.setenv("PMX_TREE_FLAGS", "4")
+        whole_tree = model.screen(lib).scores
+    assert torch.equal(whole_tree, full)
     # oracle on a sample
     rng = np.random.default_rng(99)
     pick = np.sort(rng.choice(len(lib), size=3000, replace=False))
