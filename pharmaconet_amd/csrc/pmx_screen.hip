@@ -690,16 +690,18 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
                 ab = __ballot(valid && (t + rbound) * kBoundSlack > bp);
             }
             int probe_slot = -1; // a child of this pass whose reach is probed (one call site)
-            bool handled = false;
+            bool handled = false, pending = false;
             if (shallow && ab != vb) {
                 const bool slot_vb = ((vb >> (s * G)) & GM) != 0, slot_ab = ((ab >> (s * G)) & GM) != 0;
                 const unsigned long long dropped = __ballot(c == 0 && slot_vb && !slot_ab);
                 if (dropped) {
                     if (mx >= 5 - nm) { // a sibling reached 5 matches already: the dropped children change nothing
                         rem &= ~(uint32_t)__ballot(lane < SLOTS && ((dropped >> ((lane * G) & 63)) & 1ull));
-                    } else {
+                    } else if (!ab) { // nothing left to walk: the frame has to know
                         probe_slot = (__ffsll(dropped) - 1) / G;
                         handled = true;
+                    } else { // the survivors first: one of them reaching 5 matches saves the probes
+                        pending = true;
                     }
                 }
             }
@@ -844,7 +846,7 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
                         ss = (__ffsll(__ballot(alive && key == top)) - 1) / G;
                         if (vb != ab) mx = mx > 1 ? mx : 1; // (an existing child - visited, dropped or probed - returns at least 1)
                         rem &= ~(1u << ss);
-                        if (!(ab & ~(GM << (ss * G)))) { // no other survivor: the window ends with this child
+                        if (!(ab & ~(GM << (ss * G))) && !pending) { // no other survivor: the window ends with this child
                             nb += SLOTS;
                             rem = 0xffffffffu;
                         }
