@@ -1185,7 +1185,6 @@ __device__ __forceinline__ void build_tables(const ScreenParams &p, unsigned cha
     const int lane = lane_id();
     const int s = lane / G, c = lane % G;
     const int C = r.C, cc = c < C ? c : C - 1;
-    const bool lane_live = c < C;
     const uint8_t *lstart = lds + kOffStart, *lend = lds + kOffEnd, *lk = lds + kOffK;
     const uint16_t *ksum = reinterpret_cast<const uint16_t *>(lds + kOffKsum), *ncoff = reinterpret_cast<const uint16_t *>(lds + kOffNcoff);
     const uint8_t *cand = lds + ws.off_cand, *lcnt = lds + ws.off_lcnt;
@@ -1230,19 +1229,53 @@ __device__ __forceinline__ void build_tables(const ScreenParams &p, unsigned cha
             const float lsize = size_i + size_j;                                                  // :241
             const int E = ki * kj;
             const float inv_kj = 1.0f / (float)kj;
-            for (int e0 = 0; e0 < E; e0 += SLOTS) {
-                const int e = e0 + s;
-                const bool on = e < E;
-                const int ee = on ? e : e0;
-                const int sa = (int)(((float)ee + 0.5f) * inv_kj), sb = ee - sa * kj;
-                const int a = cand[i * ws.kp + sa], b = cand[j * ws.kp + sb];
-                // cluster-distance prefilter (graph_match.py:263-268): the entry is computed if some conformer passes
-                const float2 mp = p.M.cpair[a * K + b];
-                const bool near = on && lane_live && !((fabsf(ldist - mp.x) - lsize) > mp.y);
-                const unsigned long long nbal = __ballot(near);
-                float acc = 0.f;
-                int fails = 0;
-                if (nbal) {
+            // Which entries pass the cluster-distance prefilter (graph_match.py:263-268: an entry is computed if some conformer
+            // passes) is settled first, 64 entries at a time with the lanes spread over *entries* - for a model of 30-40 clusters
+            // most of the k_i k_j entries of a level pair fail, and walking them eight at a time was most of the table phase.
+            // Failing entries get their -1 row and empty mask right there; the passing ones are listed and computed eight at a time.
+            float *pf = reinterpret_cast<float *>(lds + ws.off_tch); // [G] cluster distance | [G] size sum, per conformer
+            uint8_t *plist = lds + ws.off_task;                      // passing entries of the chunk (the root record is written later)
+            if (s == 0) {
+                pf[c] = ldist;
+                pf[G + c] = lsize;
+            }
+            lds_sync();
+            for (int eb = 0; eb < E; eb += 64) {
+                unsigned long long pbal;
+                {
+                    const int e = eb + lane;
+                    const bool in = e < E;
+                    const int ee = in ? e : eb;
+                    const int sa = (int)(((float)ee + 0.5f) * inv_kj), sb = ee - sa * kj;
+                    const float2 mp = p.M.cpair[cand[i * ws.kp + sa] * K + cand[j * ws.kp + sb]];
+                    bool pass = false;
+                    for (int k = 0; k < C; ++k) pass = pass || !((fabsf(pf[k] - mp.x) - pf[G + k]) > mp.y);
+                    pass = pass && in;
+                    pbal = __ballot(pass);
+                    if (in && !pass) {
+                        float *row = Pt + (size_t)(pair_base + (uint32_t)e) * G;
+                        if (G >= 4) {
+#pragma unroll
+                            for (int g = 0; g < G; g += 4) *reinterpret_cast<float4 *>(row + g) = make_float4(-1.f, -1.f, -1.f, -1.f);
+                        } else {
+                            for (int g = 0; g < G; ++g) row[g] = -1.f;
+                        }
+                        unsigned char *ve = Vt + (size_t)(pair_base + (uint32_t)e) * vmask_bytes<G>();
+                        for (uint32_t g = 0; g < vmask_bytes<G>(); ++g) ve[g] = 0;
+                    }
+                    if (pass) {
+                        const uint32_t lo32 = (uint32_t)pbal, hi32 = (uint32_t)(pbal >> 32);
+                        plist[__builtin_amdgcn_mbcnt_hi(hi32, __builtin_amdgcn_mbcnt_lo(lo32, 0u))] = (uint8_t)lane;
+                    }
+                }
+                lds_sync();
+                const int npass = (int)__popcll(pbal);
+                for (int p0 = 0; p0 < npass; p0 += SLOTS) {
+                    const bool on = p0 + s < npass;
+                    const int e = eb + (int)plist[on ? p0 + s : p0];
+                    const int sa = (int)(((float)e + 0.5f) * inv_kj), sb = e - sa * kj;
+                    float acc = 0.f;
+                    int fails = 0;
                     const int rowa = nci + sa * ni, rowb = ncj + sb * nj;
                     if (EXACT) {
                         for (int u = 0; u < ni; ++u) {
@@ -1256,9 +1289,9 @@ __device__ __forceinline__ void build_tables(const ScreenParams &p, unsigned cha
                             }
                         }
                     } else {
-                        // the node pairs (u, v) in the reference's order (u outer), four at a time: coordinates, distances and cell loads
-                        // of the four go out together, then the four values are added in order (items past the end are
-                        // the empty subset pair: value 0, never a fail)
+                        // the node pairs (u, v) in the reference's order (u outer), two at a time: coordinates, distances and cell loads
+                        // of the two go out together, then the values are added in order (an item past the end is the empty
+                        // subset pair: value 0, never a fail)
                         constexpr int IB = PMX_ITEM_BATCH;
                         const int npair = ni * nj;
                         int uu = 0, vv = 0;
@@ -1278,21 +1311,21 @@ __device__ __forceinline__ void build_tables(const ScreenParams &p, unsigned cha
                         }
                     }
                     n_items += (uint32_t)(ni * nj);
+                    const int L1 = lcnt[i * ws.kp + sa], L2 = lcnt[j * ws.kp + sb]; // graph_match.py:164-171
+                    // match_utils.py:71-74: -1 unless num_fails <= L1 * L2 / 2
+                    const float value = 2 * fails <= L1 * L2 ? acc : -1.f;
+                    if (on) Pt[(size_t)(pair_base + (uint32_t)e) * G + c] = value;
+                    const unsigned long long pos = __ballot(on && value > 0.f);
+                    if (on && c == 0) {
+                        const unsigned long long m = (pos >> (s * G)) & GM;
+                        unsigned char *ve = Vt + (size_t)(pair_base + (uint32_t)e) * vmask_bytes<G>();
+                        if (G <= 8) *ve = (unsigned char)m;
+                        else if (G == 16) *reinterpret_cast<uint16_t *>(ve) = (uint16_t)m;
+                        else if (G == 32) *reinterpret_cast<uint32_t *>(ve) = (uint32_t)m;
+                        else *reinterpret_cast<unsigned long long *>(ve) = m;
+                    }
                 }
-                const bool near_any = ((nbal >> (s * G)) & GM) != 0;
-                const int L1 = lcnt[i * ws.kp + sa], L2 = lcnt[j * ws.kp + sb]; // graph_match.py:164-171
-                // match_utils.py:71-74: -1 unless num_fails <= L1 * L2 / 2; entries that fail the prefilter are -1 (graph_match.py:266-268)
-                const float value = (near_any && 2 * fails <= L1 * L2) ? acc : -1.f;
-                if (on) Pt[(size_t)(pair_base + (uint32_t)e) * G + c] = value;
-                const unsigned long long pos = __ballot(on && value > 0.f);
-                if (on && c == 0) {
-                    const unsigned long long m = (pos >> (s * G)) & GM;
-                    unsigned char *ve = Vt + (size_t)(pair_base + (uint32_t)e) * vmask_bytes<G>();
-                    if (G <= 8) *ve = (unsigned char)m;
-                    else if (G == 16) *reinterpret_cast<uint16_t *>(ve) = (uint16_t)m;
-                    else if (G == 32) *reinterpret_cast<uint32_t *>(ve) = (uint32_t)m;
-                    else *reinterpret_cast<unsigned long long *>(ve) = m;
-                }
+                lds_sync(); // (the list is rewritten by the next chunk)
             }
             pair_base += (uint32_t)E;
         }
