@@ -194,7 +194,8 @@ typedef struct {
     double ms_total;            /* the call's kernels, first to last */
     double ms_ligand, ms_tasks; /* of the last super-chunk: ligand kernels (tables + tree search within budget) | task rounds + finalize */
     uint64_t ligands_last;      /* ligands in that super-chunk */
-    uint64_t n_frames;          /* tree nodes entered (tree.py:15-53) */
+    uint64_t n_frames;          /* tree nodes entered (tree.py:15-53); walkers of a split ligand share maxima while they run, so this
+                                   count (not the scores) varies a little from run to run */
     uint64_t n_passes;          /* walker passes: evaluations of a frame's candidates (probes included) */
     uint64_t n_items;           /* table phase: (table entry, ligand node pair) evaluations per wavefront, i.e. / (64 / G) slots */
     uint64_t n_exact_cells;     /* items whose 2-sigma majority test was counted term by term (pass set not an interval), per lane */
@@ -202,7 +203,7 @@ typedef struct {
     uint64_t n_tasks;           /* subtrees taken from the task queue */
     uint64_t n_exported;        /* subtree records written to the task queue */
     uint64_t n_slice_overflow;  /* ligands whose tables did not fit a per-wavefront slice */
-    uint64_t n_probes, n_probe_passes; /* reachability searches for handing over subtrees below 5 matches */
+    uint64_t n_probes, n_probe_passes; /* reachability searches: subtrees below 5 matches that are handed over, or dropped by the bound test */
     uint64_t max_passes;        /* longest single walk */
     uint64_t queue_overflow;    /* 1 if a task queue shard filled up (results stay exact; raise PMX_TASKQ_MB) */
     uint64_t arena_bytes;       /* table arena in use at the end of the last super-chunk */
