@@ -208,6 +208,9 @@ typedef struct {
     uint64_t queue_overflow;    /* 1 if a task queue shard filled up (results stay exact; raise PMX_TASKQ_MB) */
     uint64_t arena_bytes;       /* table arena in use at the end of the last super-chunk */
     uint64_t ticks_scan, ticks_tables, ticks_bounds, ticks_walk, ticks_alive; /* s_memtime ticks summed over wavefronts, by phase */
+    uint64_t n_exact_values;    /* self-table items evaluated term by term because their cell of the tabulated function is not accurate relative
+                                   to the function's own (tail) value there, per lane */
+    uint64_t dbg[8];            /* walker counters of instrumented builds (-DPMX_COUNTERS, see csrc/pmx_screen.hip walk()); 0 otherwise */
 } pmx_score_stats;
 int pmx_score_stats_get(pmx_score_stats *out);
 int pmx_set_profiling(int enabled); /* when enabled pmx_score records HIP events around its phases (no synchronisation) */

@@ -78,7 +78,8 @@ class ScoreStats(ctypes.Structure):
         + [(n, ctypes.c_uint64) for n in (
             "ligands_last", "n_frames", "n_passes", "n_items", "n_exact_cells", "n_heavy", "n_tasks", "n_exported",
             "n_slice_overflow", "n_probes", "n_probe_passes", "max_passes", "queue_overflow", "arena_bytes",
-            "ticks_scan", "ticks_tables", "ticks_bounds", "ticks_walk", "ticks_alive")]
+            "ticks_scan", "ticks_tables", "ticks_bounds", "ticks_walk", "ticks_alive", "n_exact_values")]
+        + [("dbg", ctypes.c_uint64 * 8)]
     )
 
 

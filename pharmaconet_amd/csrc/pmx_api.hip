@@ -28,7 +28,7 @@ static thread_local char g_err[512] = "";
 static thread_local pmx_score_stats g_stats = {};
 static int g_profiling = 0;
 struct ScreenWs;
-static thread_local ScreenWs *g_last_screen = nullptr;
+static thread_local std::shared_ptr<ScreenWs> g_last_screen;
 static thread_local int g_last_device = 0;
 static int screen_stats(pmx_score_stats *out);
 
@@ -231,6 +231,15 @@ static int build_pair_functions(pmx_model *m, const pmx_model_desc *d, const std
     return PMX_OK;
 }
 
+// Cells whose polynomial deviates from the function by more than this, relative to the function, are flagged (FnCell) and
+// evaluated term by term where a self entry meets them. 5e-7 leaves room for the reference's own float32 rounding of
+// z and z^2 (about 1e-7 z^2 / 2 relative) inside the 2e-6 the parity tests allow.
+static double fn_rel_tol() {
+    const char *s = std::getenv("PMX_FN_RELTOL");
+    const double v = (s && *s) ? std::atof(s) : 5e-7;
+    return v > 0.0 ? v : 5e-7;
+}
+
 // The tabulated functions for the call's weights: built on `stream` the first time, kept for the last four weight sets.
 static int pair_functions(pmx_model *m, const Weights &W, hipStream_t stream, FnTable *out) {
     std::lock_guard<std::mutex> lock(m->fn_mu);
@@ -239,10 +248,15 @@ static int pair_functions(pmx_model *m, const Weights &W, hipStream_t stream, Fn
         if (std::memcmp(&e.W, &W, sizeof(W)) == 0) hit = &e;
     if (!hit) {
         if (m->fn.size() < 4) {
-            m->fn.emplace_back();
+            FnEntry fresh; // (enters the cache only once its buffer and event exist)
+            HIPCHECK(hipMalloc((void **)&fresh.cells, (size_t)m->NF * m->ncell * sizeof(FnCell)));
+            const hipError_t ee = hipEventCreateWithFlags(&fresh.ready, hipEventDisableTiming);
+            if (ee != hipSuccess) {
+                (void)hipFree(fresh.cells);
+                return fail(PMX_ERR_HIP, "hipEventCreateWithFlags failed: %s", hipGetErrorString(ee));
+            }
+            m->fn.push_back(fresh);
             hit = &m->fn.back();
-            HIPCHECK(hipMalloc((void **)&hit->cells, (size_t)m->NF * m->ncell * sizeof(FnCell)));
-            HIPCHECK(hipEventCreateWithFlags(&hit->ready, hipEventDisableTiming));
         } else { // recycle the least recently used entry once nothing queued still reads it
             hit = &m->fn[0];
             for (FnEntry &e : m->fn)
@@ -250,7 +264,7 @@ static int pair_functions(pmx_model *m, const Weights &W, hipStream_t stream, Fn
             HIPCHECK(hipDeviceSynchronize());
         }
         hit->W = W;
-        fn_build_kernel<<<dim3(m->NF), dim3(128), 0, stream>>>(m->dm, W, m->subnodes, m->NS, m->ncell, m->h, m->win, hit->cells);
+        fn_build_kernel<<<dim3(m->NF), dim3(128), 0, stream>>>(m->dm, W, m->subnodes, m->NS, m->ncell, m->h, m->win, hit->cells, fn_rel_tol());
         HIPCHECK(hipGetLastError());
         HIPCHECK(hipEventRecord(hit->ready, stream));
     } else {
@@ -490,6 +504,7 @@ struct ScreenWs {
     uint8_t *queue = nullptr;
     size_t queue_bytes = 0;
     uint32_t *lists = nullptr; // ovf | carry | heavy
+    size_t lists_bytes = 0;
     uint32_t list_cap = 0;
     int num_cu = 0;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr}; // profiling: call start | last super-chunk start | its ligand kernels done | end
@@ -497,19 +512,30 @@ struct ScreenWs {
     bool ev_valid = false;
     hipStream_t last_stream = nullptr;
     std::mutex mu; // held while a call enqueues (the workspace belongs to one call at a time, in stream order)
-};
-static std::map<std::pair<int, hipStream_t>, std::unique_ptr<ScreenWs>> g_screen; // (device, stream)
-
-static int ensure_screen(int device, hipStream_t stream, ScreenWs **out) {
-    ScreenWs *w;
-    {
-        std::lock_guard<std::mutex> lock(g_mu);
-        auto &slot = g_screen[std::make_pair(device, stream)];
-        if (!slot) slot.reset(new ScreenWs());
-        w = slot.get();
+    void free_buffers() {
+        for (void *q : {(void *)ctl, (void *)slices, (void *)big, (void *)totbuf, (void *)arena, (void *)queue, (void *)lists})
+            if (q) (void)hipFree(q);
+        ctl = nullptr, slices = big = totbuf = arena = queue = nullptr, lists = nullptr;
+        slices_bytes = big_bytes = totbuf_bytes = arena_bytes = queue_bytes = lists_bytes = 0;
+        list_cap = 0;
+        for (auto &e : ev) {
+            if (e) (void)hipEventDestroy(e);
+            e = nullptr;
+        }
+        ev_valid = false;
     }
-    *out = w;
-    return PMX_OK;
+    bool released = false; // pmx_release_workspaces took the buffers: a caller that was waiting on `mu` asks for a new workspace
+};
+// Workspaces are shared: the map, a call in progress and the thread that asks for the last call's statistics each hold a
+// reference, so pmx_release_workspaces can take a workspace out of the map and free its buffers while none of them is left
+// with a dangling pointer (the object itself goes with its last reference).
+static std::map<std::pair<int, hipStream_t>, std::shared_ptr<ScreenWs>> g_screen; // (device, stream)
+
+static std::shared_ptr<ScreenWs> ensure_screen(int device, hipStream_t stream) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    auto &slot = g_screen[std::make_pair(device, stream)];
+    if (!slot) slot = std::make_shared<ScreenWs>();
+    return slot;
 }
 
 template <typename T>
@@ -561,11 +587,13 @@ static int score_screen(const pmx_model *model, const pmx_library *lib, const We
     // large slices for the ligands whose tables exceed a slice: as large as a table of this model and library can get, at most
     // PMX_BIG_SLICE_MB each, PMX_BIG_TOTAL_MB together (what is larger still goes to the arena)
     uint32_t big_bytes, big_grid;
+    uint64_t worst_bytes;
     {
         const uint64_t nlmax = (uint64_t)std::min<int>(PMX_MAX_LEVELS, std::max(1, lib->info.max_clusters));
         const uint64_t K = (uint64_t)std::max(1, model->dm.K);
         const uint64_t worst = rec_bytes<G>((uint32_t)(nlmax * K), (uint32_t)(nlmax * (nlmax - 1) / 2 * K * K), (uint32_t)nlmax);
         const uint64_t cap = (uint64_t)std::max<long>(1, env_long("PMX_BIG_SLICE_MB", G >= 32 ? 4 : 32)) << 20;
+        worst_bytes = worst;
         big_bytes = (uint32_t)std::max<uint64_t>(slice_bytes, (std::min(worst, cap) + 4095) & ~4095ull);
         const uint64_t total = (uint64_t)std::max<long>(64, env_long("PMX_BIG_TOTAL_MB", G >= 32 ? 16384 : 4096)) << 20;
         big_grid = (uint32_t)std::max<uint64_t>(16, std::min<uint64_t>(grid, total / big_bytes));
@@ -577,18 +605,18 @@ static int score_screen(const pmx_model *model, const pmx_library *lib, const We
         if (rc) return rc;
     }
     p.totbuf = ws.totbuf;
-    rc = grow(&ws.arena, &ws.arena_bytes, (size_t)std::max<long>(16, env_long("PMX_ARENA_MB", 32768)) << 20, stream);
+    rc = grow(&ws.arena, &ws.arena_bytes, (size_t)std::max<long>(1, env_long("PMX_ARENA_MB", 32768)) << 20, stream);
     if (rc) return rc;
     rc = grow(&ws.queue, &ws.queue_bytes, (size_t)std::max<long>(1, env_long("PMX_TASKQ_MB", 2048L * std::max(1, G / 8))) << 20, stream);
     if (rc) return rc;
     // super-chunk: the arena holds the tables of the ligands whose tree is split, until the chunk's subtrees are done
     const uint32_t super = (uint32_t)std::max<long>(1024, std::min<long>(env_long("PMX_SUPER", std::max(16384L, (1L << 20) * 8 / std::max(G, 8) / k_scale)), 1 << 24));
-    {
-        size_t have = (size_t)ws.list_cap * 12;
-        rc = grow(&ws.lists, &have, (size_t)super * 12, stream);
-        if (rc) return rc;
-        ws.list_cap = super;
+    rc = grow(&ws.lists, &ws.lists_bytes, (size_t)super * 12, stream);
+    if (rc) {
+        ws.list_cap = 0;
+        return rc;
     }
+    ws.list_cap = super;
     p.arena = ws.arena;
     p.arena_bytes = std::min<unsigned long long>(ws.arena_bytes, (1ull << 36) - 4096);
     p.ovf_list = ws.lists;
@@ -601,11 +629,13 @@ static int score_screen(const pmx_model *model, const pmx_library *lib, const We
     const uint32_t task_budget = (uint32_t)std::max<long>(16, env_long("PMX_TASK_BUDGET", lig_budget)); // a queued subtree's own budget
     p.budget = lig_budget;
     p.min_levels = (uint32_t)std::max<long>(0, env_long("PMX_MIN_LEVELS", 3));
-    p.max_passes = (unsigned long long)std::max<long>(1, env_long("PMX_MAXITERS", 1L << 40));
     p.scores = scores_dev;
     p.status = status_dev;
     const int rounds = (int)std::max<long>(1, env_long("PMX_ROUNDS", 12));
     p.last_round = 0;
+    p.retry_in = nullptr;
+    p.retry_out = nullptr;
+    p.retry_slot = 0;
     p.bound_cost = (uint32_t)std::max<long>(0, env_long("PMX_BOUND_COST", 8192));
     const bool exact = (p.flags & 8) != 0;
     const size_t lds = shape.bytes;
@@ -631,18 +661,38 @@ static int score_screen(const pmx_model *model, const pmx_library *lib, const We
         p.slices = ws.big;
         p.slice_bytes = big_bytes;
         launch(1, big_grid);
-        // and what exceeds those from the arena
+        // and what exceeds those from the arena; ligands that find it full (of the tables of over-budget trees, or of each
+        // other) are listed in the storage of the overflow list, which is done with
+        p.retry_out = ws.lists;
+        p.retry_slot = 0;
         launch(2, big_grid);
         if (g_profiling) HIPCHECK(hipEventRecord(ws.ev[2], stream));
         // the subtrees the over-budget walkers queued, and the ones those queue in turn: a fixed number of rounds, each a snapshot of
         // the queue and one persistent launch (an empty round exits at once); the last round walks everything to its end
-        p.budget = task_budget;
-        for (int r = 0; r < rounds; ++r) {
-            p.last_round = r + 1 == rounds ? 1u : 0u;
-            round_kernel<<<dim3(1), dim3(64), 0, stream>>>(ws.ctl, p.qcap);
-            task_kernel<G><<<dim3(std::min<uint32_t>(grid, (uint32_t)ws.num_cu * 4u * PMX_TASK_WAVES)), dim3(64), lds, stream>>>(p);
+        auto rounds_and_finalize = [&]() {
+            p.budget = task_budget;
+            for (int r = 0; r < rounds; ++r) {
+                p.last_round = r + 1 == rounds ? 1u : 0u;
+                round_kernel<<<dim3(1), dim3(64), 0, stream>>>(ws.ctl, p.qcap);
+                task_kernel<G><<<dim3(std::min<uint32_t>(grid, (uint32_t)ws.num_cu * 4u * PMX_TASK_WAVES)), dim3(64), lds, stream>>>(p);
+            }
+            finalize_kernel<G><<<dim3((super + 255) / 256), dim3(256), 0, stream>>>(p);
+            p.last_round = 0;
+            p.budget = lig_budget;
+        };
+        rounds_and_finalize();
+        // Ligands the arena pass had no room for, with the arena to themselves (only models and libraries whose largest tables
+        // exceed a large slice ever get here): twice, the second time reporting what still does not fit.
+        if (worst_bytes > big_bytes) {
+            for (int t = 0; t < 2; ++t) {
+                retry_prep_kernel<<<dim3(1), dim3(64), 0, stream>>>(ws.ctl, (uint32_t)(t + 1) & 1u);
+                p.retry_in = t == 0 ? ws.lists : ws.lists + super;
+                p.retry_out = t == 0 ? ws.lists + super : nullptr;
+                p.retry_slot = (uint32_t)(t + 1) & 1u;
+                launch(3, big_grid);
+                rounds_and_finalize();
+            }
         }
-        finalize_kernel<G><<<dim3((super + 255) / 256), dim3(256), 0, stream>>>(p);
     }
     HIPCHECK(hipGetLastError());
     if (g_profiling) HIPCHECK(hipEventRecord(ws.ev[3], stream));
@@ -653,8 +703,10 @@ static int score_screen(const pmx_model *model, const pmx_library *lib, const We
 
 // Statistics of the last call on this thread's workspace: synchronises the stream the call ran on.
 static int screen_stats(pmx_score_stats *out) {
-    ScreenWs *w = g_last_screen;
-    if (!w || !w->ctl) return PMX_OK;
+    const std::shared_ptr<ScreenWs> w = g_last_screen;
+    if (!w) return PMX_OK;
+    std::lock_guard<std::mutex> lock(w->mu);
+    if (w->released || !w->ctl) return PMX_OK; // (the workspace was released after the call: its counters went with it)
     HIPCHECK(hipSetDevice(g_last_device));
     HIPCHECK(hipStreamSynchronize(w->last_stream));
     std::vector<unsigned char> host(sizeof(Ctl));
@@ -675,6 +727,8 @@ static int screen_stats(pmx_score_stats *out) {
     out->n_probes = st[7] >> 32;
     out->n_probe_passes = st[15];
     out->n_exported = st[14];
+    out->n_exact_values = st[13];
+    for (int i = 0; i < 8; ++i) out->dbg[i] = st[16 + i];
     out->ticks_scan = st[8], out->ticks_tables = st[9], out->ticks_bounds = st[10], out->ticks_walk = st[11], out->ticks_alive = st[12];
     out->queue_overflow = c->qflag;
     out->arena_bytes = c->arena_top;
@@ -688,7 +742,6 @@ static int screen_stats(pmx_score_stats *out) {
         HIPCHECK(hipEventElapsedTime(&ms, w->ev[2], w->ev[3]));
         out->ms_tasks = ms;
     }
-    if (c->err) return fail(PMX_ERR_INVALID, "tree walk hit the iteration cap (PMX_MAXITERS)");
     return PMX_OK;
 }
 
@@ -708,17 +761,22 @@ extern "C" int pmx_score_multi(const pmx_model *const *models, int n_models, con
     }
     if (first > lib->info.n_ligands || count > lib->info.n_ligands - first) return fail(PMX_ERR_INVALID, "ligand range out of bounds");
     g_stats = pmx_score_stats{};
-    g_last_screen = nullptr;
+    g_last_screen.reset();
     if (count == 0 || n_models == 0) return PMX_OK;
     HIPCHECK(hipSetDevice(lib->device));
     Weights W;
     for (int t = 0; t < PMX_NUM_TYPES; ++t) W.w[t] = weights[t];
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int G = next_pow2(std::max(1, std::min(lib->info.max_conformers, PMX_MAX_CONFORMERS)));
-    ScreenWs *ws = nullptr;
-    int rc = ensure_screen(lib->device, stream, &ws);
-    if (rc) return rc;
-    std::lock_guard<std::mutex> lock(ws->mu); // one call at a time enqueues on a (device, stream) workspace
+    int rc = PMX_OK;
+    std::shared_ptr<ScreenWs> ws;
+    std::unique_lock<std::mutex> lock;
+    for (;;) { // one call at a time enqueues on a (device, stream) workspace
+        ws = ensure_screen(lib->device, stream);
+        lock = std::unique_lock<std::mutex>(ws->mu);
+        if (!ws->released) break;
+        lock.unlock(); // released while this call waited: the map holds a fresh one (or will make one)
+    }
     for (int m = 0; m < n_models && rc == PMX_OK; ++m) {
         float *sc = scores_dev + (size_t)m * count;
         int32_t *st = m == 0 ? status_dev : nullptr;
@@ -751,20 +809,23 @@ int pmx_topk_release(int device);
 extern "C" int pmx_release_workspaces(int device) {
     HIPCHECK(hipSetDevice(device));
     HIPCHECK(hipDeviceSynchronize());
-    std::lock_guard<std::mutex> lock(g_mu);
-    for (auto it = g_screen.begin(); it != g_screen.end();) {
-        if (it->first.first != device) {
-            ++it;
-            continue;
+    std::vector<std::shared_ptr<ScreenWs>> taken;
+    {
+        std::lock_guard<std::mutex> lock(g_mu);
+        for (auto it = g_screen.begin(); it != g_screen.end();) {
+            if (it->first.first != device) {
+                ++it;
+                continue;
+            }
+            taken.push_back(std::move(it->second));
+            it = g_screen.erase(it);
         }
-        ScreenWs &w = *it->second;
-        std::lock_guard<std::mutex> wl(w.mu);
-        for (void *q : {(void *)w.ctl, (void *)w.slices, (void *)w.big, (void *)w.totbuf, (void *)w.arena, (void *)w.queue, (void *)w.lists})
-            if (q) (void)hipFree(q);
-        for (auto &e : w.ev)
-            if (e) (void)hipEventDestroy(e);
-        if (g_last_screen == &w) g_last_screen = nullptr;
-        it = g_screen.erase(it);
+    }
+    for (auto &w : taken) {
+        std::lock_guard<std::mutex> wl(w->mu); // a call that is enqueuing on this workspace finishes first
+        HIPCHECK(hipDeviceSynchronize());       // ... and what it enqueued
+        w->free_buffers();
+        w->released = true;
     }
     return pmx_topk_release(device);
 }

@@ -38,6 +38,12 @@ namespace pmx {
 // One cell of a tabulated pair function: value(t) = c0 + t (c1 + t (c2 + t (c3 + t (c4 + t c5)))), t in [0, 1) the position
 // inside the cell; the item passes the 2-sigma majority test of match_utils.py:56-61 iff lo <= d <= hi (lo = NaN: the pass
 // set is not an interval inside this cell - count the terms).
+// The lowest mantissa bit of c[5] is a flag: the polynomial is not accurate *relative to the function's own value* in this
+// cell (the far tails of the Gaussians, and the last cell, which stands for every distance beyond the grid). Entries of the
+// self table have no majority test (match_utils.py:77-122), so a self entry can consist of tail values only and be a
+// ligand's whole score: the self loop evaluates the terms of a flagged cell one by one, in the reference's float32
+// operations (exact_value). A pair entry that counts at all holds items that passed the 2-sigma majority test - values near
+// the functions' peaks, next to which a tail value's error is below float32 rounding - and ignores the flag.
 struct FnCell {
     float c[6];
     float lo, hi;
@@ -123,7 +129,7 @@ __host__ __device__ constexpr uint32_t task_rec_bytes() {
 }
 
 constexpr int kShards = 64; // task queue shards (= the wave size: a task wave finds its record with one scan over the shards)
-constexpr int kStatWords = 16;
+constexpr int kStatWords = 24;
 constexpr int kScreenStatShards = 64;
 
 // Device-side control block of one call (zeroed by ctl_clear_kernel at the start of every super-chunk).
@@ -135,16 +141,18 @@ struct Ctl {
     uint32_t carry_count; // ligands whose tables do not fit a large slice either
     uint32_t heavy_count; // records in the arena that finalize has to score
     uint32_t pad0;
+    uint32_t retry_count[2]; // ligands of the arena pass that found the arena full (retried with the arena to themselves)
+    uint32_t pad00[2];
     unsigned long long arena_top; // bump allocator (bytes)
     uint32_t qflag;               // a queue shard was full (the walker then keeps the subtree: exact, only slower)
-    uint32_t err;                 // 1: iteration cap hit (cannot happen for a finite tree), 2: a wave gave up waiting for work
+    uint32_t pad1;
     uint32_t q_res[kShards];      // records reserved
     uint32_t round_lo[kShards], round_hi[kShards]; // the records of the current round (round_kernel)
     uint32_t round_total, task_cursor;
     uint32_t pad[2];
     uint32_t xcd_cursor[8][16];   // task cursors of the round, one per group of 8 shards (one 64-byte line each)
     uint32_t round_inc[kShards];  // records of the round in shards 0 .. s (task number -> shard)
-    unsigned long long stats[kScreenStatShards][kStatWords]; // sharded: [0] frames [1] passes [2] walks over budget [3] items [4] exact-count cells [5] longest walk [6] tasks [7] slice overflows [8..12] phase ticks
+    unsigned long long stats[kScreenStatShards][kStatWords]; // sharded: [0] frames [1] passes [2] walks over budget [3] items [4] exact-count cells [5] longest walk [6] tasks [7] slice overflows [8..12] phase ticks [13] self items evaluated term by term
 };
 
 // With 32 or 64 conformer lanes the float64 path totals (21 rows of G) are 5 / 11 KB: kept in LDS they cap the CU at 8 wavefronts.
@@ -178,12 +186,14 @@ struct ScreenParams {
     uint32_t min_levels;       // only subtrees with at least this many levels below their root are queued
     uint32_t flags;            // 2: never queue, 4: no bound test, 8: exact Gaussian terms instead of the tabulated functions
     uint32_t max_nodes;        // of the library (sizes the LDS node tables)
-    unsigned long long max_passes;
     uint32_t last_round;       // task_kernel: never queue (walk every subtree to its end)
     uint32_t bound_cost; // per-candidate bounds are built when their cost estimate stays below this (build_bounds)
     float *scores;
     int32_t *status;
-    int mode;                  // 0: slice pass over [lo, hi); 1: large-slice pass over ovf_list; 2: arena pass over carry_list
+    int mode;                  // 0: slice pass over [lo, hi); 1: large-slice pass over ovf_list; 2: arena pass over carry_list; 3: arena pass over retry_in
+    const uint32_t *retry_in;  // mode 3: the ligands an earlier arena pass had no room for (count: ctl->retry_count[retry_slot ^ 1])
+    uint32_t *retry_out;       // modes 2, 3: where such ligands go (count: ctl->retry_count[retry_slot]); nullptr: they are reported as too large
+    uint32_t retry_slot;
 };
 
 
@@ -240,7 +250,7 @@ __device__ inline float norm3f(float dx, float dy, float dz) { // np.linalg.norm
 // at the two ends of a cell, evaluated in float64. `win` holds the exact pass windows of every cell (host, model-only).
 // A subset pair with a zero weight sum scores NaN in the reference (0 * (1 / 0), match_utils.py:50-52,69): NaN cells.
 __global__ void fn_build_kernel(DevModel M, Weights W, const uint64_t *subnodes, uint32_t NS, uint32_t ncell, float h,
-                                const float2 *win, FnCell *cells) {
+                                const float2 *win, FnCell *cells, double rel_tol) {
     const uint32_t fid = blockIdx.x;
     uint32_t sa, sb;
     if (M.symmetric) { // triangular: fid = sa (sa + 1) / 2 + sb, sb <= sa
@@ -292,6 +302,28 @@ __global__ void fn_build_kernel(DevModel M, Weights W, const uint64_t *subnodes,
         c.c[3] = (float)(10.0 * df - 6.0 * d1[0] - 4.0 * d1[1] - 1.5 * d2[0] + 0.5 * d2[1]);
         c.c[4] = (float)(-15.0 * df + 8.0 * d1[0] + 7.0 * d1[1] + 1.5 * d2[0] - d2[1]);
         c.c[5] = (float)(6.0 * df - 3.0 * d1[0] - 3.0 * d1[1] - 0.5 * d2[0] + 0.5 * d2[1]);
+        // worst deviation of the float32 polynomial from the function, relative to the function, at eight points inside the cell
+        bool rough = i + 1 == ncell; // (the last cell is also where every distance beyond the grid lands)
+        if (!empty && !nanfn && !rough) {
+            for (int k = 0; k < 8 && !rough; ++k) {
+                const double t = ((double)k + 0.5) * 0.125, x = ((double)i + t) * (double)h;
+                double s0 = 0.0;
+                for (uint64_t am = A; am; am &= am - 1) {
+                    const int m = __ffsll((unsigned long long)am) - 1;
+                    for (uint64_t bm = B; bm; bm &= bm - 1) {
+                        const int n = __ffsll((unsigned long long)bm) - 1;
+                        const float4 eg = M.edge[m * Nm + n];
+                        const float wprod = W.w[M.node_type[m]] * W.w[M.node_type[n]];
+                        const double z = (x - (double)eg.x) / (double)eg.w;
+                        s0 += (double)(wprod / eg.w) * exp(-0.5 * z * z);
+                    }
+                }
+                const double fx = s0 * inv_mn;
+                const double px = (double)c.c[0] + t * ((double)c.c[1] + t * ((double)c.c[2] + t * ((double)c.c[3] + t * ((double)c.c[4] + t * (double)c.c[5]))));
+                rough = fabs(px - fx) > rel_tol * fx;
+            }
+        }
+        c.c[5] = __uint_as_float((__float_as_uint(c.c[5]) & ~1u) | (rough ? 1u : 0u));
         if (nanfn) c.c[0] = __builtin_nanf("");
         const float2 w = win[(size_t)fid * ncell + i];
         c.lo = w.x;
@@ -333,7 +365,7 @@ __host__ __device__ inline WaveShape<G> wave_shape(int K, int max_nodes) {
     w.off_pool = o;
     o += G * 8;
     w.off_stat = o; // the wave's statistics (kept out of the registers)
-    o += 128;
+    o += 192; // sizeof(WaveStats)
     w.off_task = o; // subtree record of the root of the ligand in work
     o += task_rec_bytes<G>();
     o = (o + 15u) & ~15u;
@@ -376,9 +408,10 @@ static_assert(kOffBits + 8 * PMX_MAX_LEVELS + 8 <= kOffPath && kOffPath + 2 * PM
 // existence. Scores and every skip decision stay what the reference computes.
 struct WaveStats { // lives in LDS, updated by lane 0
     unsigned long long frames, passes, over, items, exact, longest, tasks, overflow;
-    unsigned long long cyc_scan, cyc_tables, cyc_bounds, cyc_walk, cyc_busy, cyc_idle, pad[2]; // s_memtime ticks per phase
+    unsigned long long cyc_scan, cyc_tables, cyc_bounds, cyc_walk, exactv, spare, pad[2]; // s_memtime ticks per phase | self items evaluated term by term
+    unsigned long long dbg[8]; // instrumented builds (-DPMX_COUNTERS): see walk()
 };
-static_assert(sizeof(WaveStats) == 128, "WaveStats layout");
+static_assert(sizeof(WaveStats) == 192, "WaveStats layout");
 
 template <int G>
 struct Walk {
@@ -537,13 +570,26 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
     // wave's maxima to the others and theirs to this wave's bound test. (Maxima of leaves of the same tree: exact.)
     constexpr uint32_t kShareEvery = 16;
     uint32_t next_share = w.passes + kShareEvery;
+#ifdef PMX_COUNTERS
+    uint32_t dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // fused passes | fused children | cached passes | leaf passes | other passes from the tables | descents | ancestors over table passes | shares
+#define PMX_COUNT(i, n) dbg[i] += (uint32_t)(n)
+    auto flush_dbg = [&]() {
+        if (lane == 0)
+            for (int i = 0; i < 8; ++i) stat->dbg[i] += dbg[i];
+    };
+#else
+#define PMX_COUNT(i, n)
+    auto flush_dbg = [&]() {};
+#endif
     for (;;) {
         if (w.passes > budget32) { // over budget: the caller moves the job's tables to the arena and resumes in export mode
             w.f = f;
+            flush_dbg();
             return kOverBudget;
         }
         if (rec16 != 0u && w.passes >= next_share && !(p.flags & 8192)) {
             next_share = w.passes + kShareEvery;
+            PMX_COUNT(7, 1);
             if (s == 0) {
                 unsigned long long *gb = reinterpret_cast<unsigned long long *>(p.arena + (size_t)rec16 * 16 + sizeof(RecHeader));
                 const unsigned long long mine = pool[c];
@@ -646,7 +692,10 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
                 const int src = lane + nb * G;
                 t = tc[tci * 64 + (on ? src : lane)];
                 valid = on && ((uni64(vb0) >> src) & 1ull);
+                PMX_COUNT(2, 1);
             } else {
+                PMX_COUNT(leaf_level ? 3 : 4, 1);
+                PMX_COUNT(6, nm);
                 const uint32_t bo = ((uint32_t)(on ? bvec : b_first) << PSH) + (uint32_t)c * 4u; // idle slots read an existing candidate
                 const float self = *reinterpret_cast<const float *>(Sb + (((uint32_t)ksf << PSH) + bo));
                 float lo = 1.f; // smallest pair entry: the candidate is valid for this conformer iff every entry is > 0 (tree.py:81)
@@ -717,6 +766,7 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
                 //   total(b, b') = (total(b) + S[f + 1][b']) + (sum_q P[q -> (f + 1, b')] + P[(f, b) -> (f + 1, b')])   (tree.py:38-41)
                 // in the reference's order (the child is the deepest ancestor, so its entry comes last).
                 if (ab) {
+                    PMX_COUNT(0, 1);
                     const int f1 = f + 1, k1 = rl(w.hk, f1) & 255, ks1 = rl(w.hks, f1);
                     tch[lane] = t; // the children's totals, read back per child by every slot
                     const int ebv1 = w.matRB + __mul24(w.matKA & 255, ks1) + __mul24((w.matKA >> 8) & 255, k1);
@@ -759,6 +809,7 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
                         const int r1 = 1 + (any1 ? 1 : 0);
                         mx = mx > r1 ? mx : r1;
                         ++w.frames;
+                        PMX_COUNT(1, 1);
                     }
                     w.passes += 1;
                 }
@@ -874,6 +925,7 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
                     w.matKA = wl(w.matKA, nm, kf | (bsel << 8) | (f << 16));
                     ++f;
                     ++w.frames;
+                    PMX_COUNT(5, 1);
                     if (totals_in_lds<G>()) lds_sync(); // the child's total is read by all slots
                     else wave_sync();
                     continue;
@@ -947,8 +999,10 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
             if (ret > pmx) w.stC = wl(w.stC, f, (pc & ~0xff00) | (ret << 8));
         }
     }
+    flush_dbg();
     return ret;
 }
+#undef PMX_COUNT
 
 
 // ------------------------------------------------------------------------------------------ table phase
@@ -960,11 +1014,42 @@ __device__ __forceinline__ uint32_t fn_index(const FnTable &F, uint32_t sidu, ui
     return sidu * F.NS + sidv;
 }
 
-// One (ligand node, ligand node) item of match_utils.py:26-69 for the subset pair `fid` at distance d: the tabulated sum
-// (already divided by |A||B|) and whether the item fails the majority test of :56-61.
-template <bool EXACT>
+// One (ligand node, ligand node) item term by term, in the float32 operations of the reference (match_utils.py:50-69 and
+// :108-120; same order as oracle/pmx_oracle.c node_pair_term): weights_sum by float32 additions, z = (d - mean) / std with
+// an IEEE division, exp(-0.5 z^2) to float32 accuracy, the likelihood added up in the order of itertools.product, then
+// likelihood * (1 / weights_sum) * (weights_sum / num_match). A subset pair whose weights sum to 0 gives NaN like the
+// reference (x * inf * 0). np = the terms within 2 sigma (:56-60). A, B non-empty.
+__device__ __forceinline__ float exact_value(const ScreenParams &p, uint64_t A, uint64_t B, float d, int &np) {
+    float weights_sum = 0.f;
+    for (uint64_t am = A; am; am &= am - 1) {
+        const float wa = p.W.w[p.M.node_type[__ffsll((unsigned long long)am) - 1]];
+        for (uint64_t bm = B; bm; bm &= bm - 1) weights_sum = weights_sum + wa * p.W.w[p.M.node_type[__ffsll((unsigned long long)bm) - 1]];
+    }
+    const int mn = __popcll(A) * __popcll(B);
+    const float normalize_coeff = 1.0f / weights_sum, score_coeff = weights_sum / (float)mn;
+    float likelihood = 0.f;
+    np = 0;
+    for (uint64_t am = A; am; am &= am - 1) {
+        const int m = __ffsll((unsigned long long)am) - 1;
+        const float wa = p.W.w[p.M.node_type[m]];
+        for (uint64_t bm = B; bm; bm &= bm - 1) {
+            const int n = __ffsll((unsigned long long)bm) - 1;
+            const float4 e = p.M.edge[m * p.M.Nm + n]; // {mean, s, T, std}
+            const float t = d - e.x, z = t / e.w;
+            np += fabsf(t) <= e.z ? 1 : 0; // == abs(z) < 2 (pmx_device.h)
+            const float wos = (wa * p.W.w[p.M.node_type[n]]) / e.w;
+            likelihood = likelihood + wos * expf(-0.5f * (z * z));
+        }
+    }
+    return likelihood * normalize_coeff * score_coeff;
+}
+
+// One (ligand node, ligand node) item of match_utils.py:26-69 for the subset pair (sidu, sidv) at distance d: the tabulated
+// sum (already divided by |A||B|) and whether the item fails the majority test of :56-61. SELF: the item belongs to a self
+// entry, where a cell flagged as rough (FnCell) is evaluated term by term. EXACT (PMX_TREE_FLAGS & 8): every item is.
+template <bool EXACT, bool SELF>
 __device__ __forceinline__ void item(const ScreenParams &p, uint32_t sidu, uint32_t sidv, float d, float &acc, int &fails,
-                                     uint32_t &n_exact) {
+                                     uint32_t &n_exact, uint32_t &n_exactv) {
     if (!EXACT) {
         const float x = d * p.F.inv_h; // exact: inv_h is a power of two
         const int ci = min((int)x, (int)p.F.ncell - 1);
@@ -976,6 +1061,15 @@ __device__ __forceinline__ void item(const ScreenParams &p, uint32_t sidu, uint3
         v = __builtin_fmaf(t, v, a.z);
         v = __builtin_fmaf(t, v, a.y);
         v = __builtin_fmaf(t, v, a.x);
+        if (SELF) {
+            if (__builtin_expect((__float_as_uint(b.y) & 1u) != 0u && sidu != 0u && sidv != 0u, 0)) {
+                int np;
+                v = exact_value(p, p.subnodes[sidu], p.subnodes[sidv], d, np);
+                ++n_exactv;
+            }
+            acc = acc + v;
+            return; // (no majority test on self entries)
+        }
         acc = acc + v;
         if (__builtin_expect(b.z != b.z, 0)) { // the pass set is not one interval inside this cell: count the terms
             const uint64_t A = p.subnodes[sidu], B = p.subnodes[sidv];
@@ -992,28 +1086,12 @@ __device__ __forceinline__ void item(const ScreenParams &p, uint32_t sidu, uint3
         }
         return;
     }
-    // debug / validation (flags & 8): the Gaussian terms themselves, float32 like match_utils.py, one v_exp_f32 per term
+    // debug / validation (flags & 8): every item term by term
     const uint64_t A = p.subnodes[sidu], B = p.subnodes[sidv];
     if (!A || !B) return;
-    float sum = 0.f;
-    int np = 0;
-    bool a_nz = false, b_nz = false;
-    for (uint64_t am = A; am; am &= am - 1) a_nz = a_nz || p.W.w[p.M.node_type[__ffsll((unsigned long long)am) - 1]] != 0.f;
-    for (uint64_t bm = B; bm; bm &= bm - 1) b_nz = b_nz || p.W.w[p.M.node_type[__ffsll((unsigned long long)bm) - 1]] != 0.f;
-    for (uint64_t am = A; am; am &= am - 1) {
-        const int m = __ffsll((unsigned long long)am) - 1;
-        for (uint64_t bm = B; bm; bm &= bm - 1) {
-            const int n = __ffsll((unsigned long long)bm) - 1;
-            const float4 e = p.M.edge[m * p.M.Nm + n];
-            const float coef = (p.W.w[p.M.node_type[m]] * p.W.w[p.M.node_type[n]]) / e.w;
-            const float t = fabsf(d - e.x), q = t * e.y;
-            sum = __builtin_fmaf(coef, __builtin_amdgcn_exp2f(-(q * q)), sum);
-            np += t <= e.z ? 1 : 0;
-        }
-    }
-    const int mn = __popcll(A) * __popcll(B);
-    acc = acc + ((a_nz && b_nz) ? sum / (float)mn : __builtin_nanf(""));
-    fails += 2 * np < mn ? 1 : 0;
+    int np;
+    acc = acc + exact_value(p, A, B, d, np);
+    fails += 2 * np < __popcll(A) * __popcll(B) ? 1 : 0;
 }
 
 // The same item in two steps, so that the loads of several items are in flight together: address + loads, then value + test.
@@ -1179,7 +1257,7 @@ __device__ __forceinline__ void center_size(GlobalFloats xyz, int C, int start, 
 // The self / pair score tables of match_utils.py for the ligand whose levels are in LDS, into `rec`.
 template <int G, bool EXACT>
 __device__ __forceinline__ void build_tables(const ScreenParams &p, unsigned char *lds, const WaveShape<G> &ws, const Record &r, const LevelInfo &L,
-                                             unsigned char *rec, uint32_t &n_items, uint32_t &n_exact) {
+                                             unsigned char *rec, uint32_t &n_items, uint32_t &n_exact, uint32_t &n_exactv) {
     constexpr int SLOTS = 64 / G;
     constexpr uint64_t GM = group_mask<G>();
     const int lane = lane_id();
@@ -1211,7 +1289,7 @@ __device__ __forceinline__ void build_tables(const ScreenParams &p, unsigned cha
                 for (int v = u + 1; v < ni; ++v) {
                     const uint32_t ov = (uint32_t)((si + v) * 3 * C + cc);
                     const float d = norm3f(ux - xyz[ov], uy - xyz[ov + C], uz - xyz[ov + 2 * C]);
-                    item<EXACT>(p, sidu, nc[row + v], d, acc, fails, n_exact);
+                    item<EXACT, true>(p, sidu, nc[row + v], d, acc, fails, n_exact, n_exactv);
                     ++n_items;
                 }
             }
@@ -1285,7 +1363,7 @@ __device__ __forceinline__ void build_tables(const ScreenParams &p, unsigned cha
                             for (int v = 0; v < nj; ++v) {
                                 const uint32_t ov = (uint32_t)((sj + v) * 3 * C + cc);
                                 const float d = norm3f(ux - xyz[ov], uy - xyz[ov + C], uz - xyz[ov + 2 * C]);
-                                item<EXACT>(p, sidu, nc[rowb + v], d, acc, fails, n_exact);
+                                item<EXACT, false>(p, sidu, nc[rowb + v], d, acc, fails, n_exact, n_exactv);
                             }
                         }
                     } else {
@@ -1502,11 +1580,20 @@ __device__ __forceinline__ unsigned char *prepare_ligand(const ScreenParams &p, 
             return nullptr;
         }
     } else {
-        const unsigned long long off = bytes64 < (1ull << 31) ? arena_alloc(p, (uint32_t)bytes64) : ~0ull;
-        if (off == ~0ull) { // no room in the arena
+        const bool fits = bytes64 < (1ull << 31) && bytes64 + 256ull <= p.arena_bytes;
+        const unsigned long long off = fits ? arena_alloc(p, (uint32_t)bytes64) : ~0ull;
+        if (off == ~0ull) {
+            // No room. Tables larger than the whole arena are reported; otherwise the arena is full of other ligands' tables (it
+            // is a bump allocator that empties between passes), which says nothing about this ligand: it is listed and taken
+            // again by a later arena pass that starts empty, so that a score does not depend on what else is in the batch.
             if (lane == 0) {
-                p.scores[li] = __builtin_nanf("");
-                if (p.status) p.status[li] = PMX_LIGAND_TOO_LARGE;
+                if (fits && p.retry_out) {
+                    const uint32_t o = atomicAdd(&p.ctl->retry_count[p.retry_slot], 1u);
+                    if (o < p.list_cap) p.retry_out[o] = li;
+                } else {
+                    p.scores[li] = __builtin_nanf("");
+                    if (p.status) p.status[li] = PMX_LIGAND_TOO_LARGE;
+                }
             }
             return nullptr;
         }
@@ -1533,9 +1620,9 @@ __device__ __forceinline__ unsigned char *prepare_ligand(const ScreenParams &p, 
     }
     if (lane <= L.nl) H->ksum[lane] = ksum[lane];
     if (lane < G) reinterpret_cast<unsigned long long *>(rec + sizeof(RecHeader))[lane] = 0ull;
-    uint32_t n_items = 0, n_exact = 0;
+    uint32_t n_items = 0, n_exact = 0, n_exactv = 0;
     const unsigned long long t_b = __builtin_amdgcn_s_memtime();
-    build_tables<G, EXACT>(p, lds, ws, r, L, rec, n_items, n_exact);
+    build_tables<G, EXACT>(p, lds, ws, r, L, rec, n_items, n_exact, n_exactv);
     wave_sync();
     const unsigned long long t_c = __builtin_amdgcn_s_memtime();
     build_bounds<G>(p, lds, L, rec);
@@ -1559,6 +1646,7 @@ __device__ __forceinline__ unsigned char *prepare_ligand(const ScreenParams &p, 
         stat->items += n_items;
     }
     if (n_exact) atomicAdd(&stat->exact, (unsigned long long)n_exact);
+    if (n_exactv) atomicAdd(&stat->exactv, (unsigned long long)n_exactv);
     return rec;
 }
 
@@ -1708,7 +1796,10 @@ __device__ inline void flush_wave_stats(const ScreenParams &p, const WaveStats *
     atomicAdd(st + 10, stat->cyc_bounds);
     atomicAdd(st + 11, stat->cyc_walk);
     atomicAdd(st + 12, alive);
-    atomicAdd(st + 13, stat->cyc_idle);
+    atomicAdd(st + 13, stat->exactv);
+#ifdef PMX_COUNTERS
+    for (int i = 0; i < 8; ++i) atomicAdd(st + 16 + i, stat->dbg[i]);
+#endif
 }
 
 // Persistent wavefronts (one per block) over the ligands of a pass: build a ligand's tables in the wave's slice (modes 0 / 1)
@@ -1721,11 +1812,12 @@ __global__ __launch_bounds__(64, PMX_SCREEN_WAVES) void ligand_kernel(const Scre
     const int lane0 = lane_id();
     const uint32_t wave_id = blockIdx.x;
     const WaveShape<G> ws = wave_shape<G>(p.M.K, (int)p.max_nodes);
-    const uint32_t todo = p.mode == 0 ? p.hi - p.lo : (p.mode == 1 ? min(p.ctl->ovf_count, p.list_cap) : min(p.ctl->carry_count, p.list_cap));
-    const uint32_t *list = p.mode == 1 ? p.ovf_list : p.carry_list;
+    const uint32_t todo = p.mode == 0 ? p.hi - p.lo
+                          : min(p.mode == 1 ? p.ctl->ovf_count : (p.mode == 2 ? p.ctl->carry_count : p.ctl->retry_count[p.retry_slot ^ 1u]), p.list_cap);
+    const uint32_t *list = p.mode == 1 ? p.ovf_list : (p.mode == 2 ? p.carry_list : p.retry_in);
     constexpr uint32_t kBatch = 1; // ligands claimed per atomic on the cursor
     WaveStats *stat = reinterpret_cast<WaveStats *>(lds + ws.off_stat);
-    if (lane0 < 16) reinterpret_cast<unsigned long long *>(stat)[lane0] = 0ull;
+    if (lane0 < (int)(sizeof(WaveStats) / 8)) reinterpret_cast<unsigned long long *>(stat)[lane0] = 0ull;
     wave_sync();
     const unsigned long long t_start = __builtin_amdgcn_s_memtime();
     uint32_t lig_next = 0, lig_end = 0;
@@ -1774,7 +1866,6 @@ __global__ void round_kernel(Ctl *ctl, uint32_t qcap) {
         ctl->round_total = n;
         ctl->task_cursor = 0;
         for (int x = 0; x < 8; ++x) ctl->xcd_cursor[x][0] = 0;
-        ctl->stats[0][6] += n; // subtrees of the call (this kernel is alone on the stream)
     }
 }
 
@@ -1792,7 +1883,7 @@ __global__ __launch_bounds__(64, PMX_TASK_WAVES) void task_kernel(const ScreenPa
     if (total == 0) return;
     const WaveShape<G> ws = wave_shape<G>(p.M.K, (int)p.max_nodes);
     WaveStats *stat = reinterpret_cast<WaveStats *>(lds + ws.off_stat);
-    if (lane0 < 16) reinterpret_cast<unsigned long long *>(stat)[lane0] = 0ull;
+    if (lane0 < (int)(sizeof(WaveStats) / 8)) reinterpret_cast<unsigned long long *>(stat)[lane0] = 0ull;
     wave_sync();
     const unsigned long long t_start = __builtin_amdgcn_s_memtime();
     // Task number -> (shard, record) through the inclusive counts round_kernel left. Shards 8x .. 8x + 7 (a contiguous range
@@ -1845,13 +1936,28 @@ __global__ void finalize_kernel(const ScreenParams p) {
     p.scores[H->lig] = (float)(sum / (double)C);
 }
 
+// In front of an arena pass over the ligands the last one had no room for: every subtree of the super-chunk is done and
+// finalize has run, so the arena and the task queue start empty again.
+__global__ void retry_prep_kernel(Ctl *ctl, uint32_t slot_out) {
+    const int lane = threadIdx.x & 63;
+    ctl->q_res[lane] = 0;
+    ctl->round_lo[lane] = 0;
+    ctl->round_hi[lane] = 0;
+    if (lane == 0) {
+        ctl->arena_top = 0;
+        ctl->heavy_count = 0;
+        ctl->cursor[3] = 0;
+        ctl->retry_count[slot_out] = 0;
+    }
+}
+
 // Start of a super-chunk: cursors, lists, arena and queue are empty again (the statistics survive unless asked).
 __global__ void ctl_clear_kernel(Ctl *ctl, int clear_stats) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t head_words = offsetof(Ctl, stats) / 4, all_words = sizeof(Ctl) / 4;
     uint32_t *w = reinterpret_cast<uint32_t *>(ctl);
     if (i < head_words) {
-        if (i != offsetof(Ctl, err) / 4 && i != offsetof(Ctl, qflag) / 4) w[i] = 0;
+        if (i != offsetof(Ctl, qflag) / 4) w[i] = 0;
         else if (clear_stats) w[i] = 0;
     } else if (i < all_words && clear_stats) {
         w[i] = 0;

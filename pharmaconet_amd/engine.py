@@ -246,7 +246,7 @@ def score_one(model, ligand, weights: dict[str, float] | None = None, device=Non
 def last_score_stats() -> dict:
     st = _ffi.ScoreStats()
     _ffi.check(_ffi.load().pmx_score_stats_get(ctypes.byref(st)))
-    return {name: getattr(st, name) for name, _ in st._fields_}
+    return {name: (list(getattr(st, name)) if name == "dbg" else getattr(st, name)) for name, _ in st._fields_}
 
 
 def release_workspaces(device=None) -> None:

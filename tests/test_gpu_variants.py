@@ -177,6 +177,34 @@ def test_small_arena_changes_nothing_but_time(monkeypatch):
         engine.release_workspaces()
 
 
+def test_arena_pass_is_retried_with_the_arena_empty(monkeypatch):
+    """a ligand whose tables need the arena (larger than any slice) must not be reported as too large because the
+    arena happened to be full of other ligands' tables - it is a bump allocator - when its turn came. Four ligands of the
+    64-conformer stress set have tables of 1.9 - 2.7 MB; with large slices of 1 MB they go to the arena, and an arena of 6 MB
+    holds at most two of them next to the tables of the over-budget trees. Every ligand is scored, to the reference's floats."""
+    from pharmaconet_amd import engine
+
+    model, lib, weights, d = load_golden("set_s64_c64")
+    engine.release_workspaces()
+    try:
+        with monkeypatch.context() as mp:
+            mp.setenv("PMX_BIG_SLICE_MB", "1")
+            mp.setenv("PMX_ARENA_MB", "6")
+            got, status = _gpu(model, lib, weights)
+        assert np.all(status == 0), status
+        assert rel_err(got, d["score"]).max() < RTOL
+        engine.release_workspaces()
+        with monkeypatch.context() as mp:  # an arena smaller than the largest table: that ligand, and only that kind, is reported
+            mp.setenv("PMX_BIG_SLICE_MB", "1")
+            mp.setenv("PMX_ARENA_MB", "2")
+            got, status = _gpu(model, lib, weights)
+        ok = status == 0
+        assert 0 < (~ok).sum() <= 4 and np.all(status[~ok] == 2) and np.all(np.isnan(got[~ok]))
+        assert rel_err(got[ok], d["score"][ok]).max() < RTOL
+    finally:
+        engine.release_workspaces()
+
+
 def test_sixteen_pockets_one_library():
     """BASELINE.json configs[3]: a batch of 16 distinct pockets against one shared library through pmx_score_multi;
     every (pocket, ligand) score against the reference's own (fixture minted by tests/golden/make_golden_pockets.py)."""
