@@ -232,12 +232,22 @@ static int build_pair_functions(pmx_model *m, const pmx_model_desc *d, const std
 }
 
 // Cells whose polynomial deviates from the function by more than this, relative to the function, are flagged (FnCell) and
-// evaluated term by term where a self entry meets them. 5e-7 leaves room for the reference's own float32 rounding of
-// z and z^2 (about 1e-7 z^2 / 2 relative) inside the 2e-6 the parity tests allow.
+// evaluated term by term where a self entry meets them. 2e-7 is just above what the float32 coefficients themselves cost
+// (each rounded to 6e-8 of its value) and leaves room for the reference's own float32 rounding of z and z^2 (about
+// 1e-7 z^2 / 2 relative) inside the 2e-6 the parity tests allow; on the bench library 1-3 self items per ligand are flagged.
 static double fn_rel_tol() {
     const char *s = std::getenv("PMX_FN_RELTOL");
-    const double v = (s && *s) ? std::atof(s) : 5e-7;
-    return v > 0.0 ? v : 5e-7;
+    const double v = (s && *s) ? std::atof(s) : 2e-7;
+    return v > 0.0 ? v : 2e-7;
+}
+
+// ... and cells where the terms that make up the function are beyond exp(-6) of their peaks (weighted mean of z^2 / 2 above 6,
+// |z| > 3.46): there the reference's own float32 rounding of z and z^2 reaches 1e-6 of the value, and only the same operations
+// in the same order reproduce it.
+static double fn_max_exponent() {
+    const char *s = std::getenv("PMX_FN_MAXEXP");
+    const double v = (s && *s) ? std::atof(s) : 6.0;
+    return v > 0.0 ? v : 6.0;
 }
 
 // The tabulated functions for the call's weights: built on `stream` the first time, kept for the last four weight sets.
@@ -264,7 +274,7 @@ static int pair_functions(pmx_model *m, const Weights &W, hipStream_t stream, Fn
             HIPCHECK(hipDeviceSynchronize());
         }
         hit->W = W;
-        fn_build_kernel<<<dim3(m->NF), dim3(128), 0, stream>>>(m->dm, W, m->subnodes, m->NS, m->ncell, m->h, m->win, hit->cells, fn_rel_tol());
+        fn_build_kernel<<<dim3(m->NF), dim3(128), 0, stream>>>(m->dm, W, m->subnodes, m->NS, m->ncell, m->h, m->win, hit->cells, fn_rel_tol(), fn_max_exponent());
         HIPCHECK(hipGetLastError());
         HIPCHECK(hipEventRecord(hit->ready, stream));
     } else {

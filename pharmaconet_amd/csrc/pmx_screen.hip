@@ -250,7 +250,7 @@ __device__ inline float norm3f(float dx, float dy, float dz) { // np.linalg.norm
 // at the two ends of a cell, evaluated in float64. `win` holds the exact pass windows of every cell (host, model-only).
 // A subset pair with a zero weight sum scores NaN in the reference (0 * (1 / 0), match_utils.py:50-52,69): NaN cells.
 __global__ void fn_build_kernel(DevModel M, Weights W, const uint64_t *subnodes, uint32_t NS, uint32_t ncell, float h,
-                                const float2 *win, FnCell *cells, double rel_tol) {
+                                const float2 *win, FnCell *cells, double rel_tol, double max_exponent) {
     const uint32_t fid = blockIdx.x;
     uint32_t sa, sb;
     if (M.symmetric) { // triangular: fid = sa (sa + 1) / 2 + sb, sb <= sa
@@ -307,7 +307,7 @@ __global__ void fn_build_kernel(DevModel M, Weights W, const uint64_t *subnodes,
         if (!empty && !nanfn && !rough) {
             for (int k = 0; k < 8 && !rough; ++k) {
                 const double t = ((double)k + 0.5) * 0.125, x = ((double)i + t) * (double)h;
-                double s0 = 0.0;
+                double s0 = 0.0, e0 = 0.0;
                 for (uint64_t am = A; am; am &= am - 1) {
                     const int m = __ffsll((unsigned long long)am) - 1;
                     for (uint64_t bm = B; bm; bm &= bm - 1) {
@@ -315,12 +315,16 @@ __global__ void fn_build_kernel(DevModel M, Weights W, const uint64_t *subnodes,
                         const float4 eg = M.edge[m * Nm + n];
                         const float wprod = W.w[M.node_type[m]] * W.w[M.node_type[n]];
                         const double z = (x - (double)eg.x) / (double)eg.w;
-                        s0 += (double)(wprod / eg.w) * exp(-0.5 * z * z);
+                        const double g = (double)(wprod / eg.w) * exp(-0.5 * z * z);
+                        s0 += g;
+                        e0 += g * (0.5 * z * z);
                     }
                 }
                 const double fx = s0 * inv_mn;
                 const double px = (double)c.c[0] + t * ((double)c.c[1] + t * ((double)c.c[2] + t * ((double)c.c[3] + t * ((double)c.c[4] + t * (double)c.c[5]))));
-                rough = fabs(px - fx) > rel_tol * fx;
+                // ... and where the function is down to exp(-max_exponent) of its terms' peaks: the reference computes z and z^2 in
+                // float32, which moves exp(-z^2 / 2) by up to 1.8e-7 z^2 / 2 of its value - rounding a smooth table cannot follow
+                rough = fabs(px - fx) > rel_tol * fx || e0 > max_exponent * s0;
             }
         }
         c.c[5] = __uint_as_float((__float_as_uint(c.c[5]) & ~1u) | (rough ? 1u : 0u));
@@ -440,6 +444,44 @@ constexpr int kLvLeaf = 256, kLvFuse = 512, kLvCache = 1024;
 constexpr unsigned kMatched = 1, kAny = 2, kSkipped = 4, kCached = 8, kFused = 16, kFiltered = 32;
 constexpr double kBoundSlack = 1.0 + 1e-9; // covers the float64 rounding of the sums the bound is compared with
 
+
+// Row loops of the walker: `load(q)` for q = 0 .. n - 1 go out kRowBatch at a time and `use(value)` takes them in order; what is
+// left at the end goes out as ONE batch too. (A remainder loop that loads one row, waits, uses it and loads the next costs a
+// memory round trip per row: with 7 matched ancestors - the average of a table pass - that was four round trips instead of two.)
+#ifndef PMX_ROW_BATCH
+#define PMX_ROW_BATCH 4
+#endif
+constexpr int kRowBatch = PMX_ROW_BATCH;
+template <int N, typename Load, typename Use>
+__device__ __forceinline__ void rows_batch(int q, Load &&load, Use &&use) {
+    decltype(load(0)) v[N];
+#pragma unroll
+    for (int u = 0; u < N; ++u) v[u] = load(q + u);
+#pragma unroll
+    for (int u = 0; u < N; ++u) use(v[u]);
+}
+template <typename Load, typename Use>
+__device__ __forceinline__ void for_rows(int n, Load &&load, Use &&use) {
+    int q = 0;
+    for (; q + kRowBatch <= n; q += kRowBatch) rows_batch<kRowBatch>(q, load, use);
+    static_assert(kRowBatch == 4 || kRowBatch == 8, "remainder cases");
+    if (kRowBatch == 8 && n - q >= 4) {
+        switch (n - q) {
+        case 7: rows_batch<7>(q, load, use); break;
+        case 6: rows_batch<6>(q, load, use); break;
+        case 5: rows_batch<5>(q, load, use); break;
+        default: rows_batch<4>(q, load, use); break;
+        }
+        return;
+    }
+    switch (n - q) {
+    case 3: rows_batch<3>(q, load, use); break;
+    case 2: rows_batch<2>(q, load, use); break;
+    case 1: rows_batch<1>(q, load, use); break;
+    default: break;
+    }
+}
+
 // Can the child (frame f, candidate `cand`, conformer mask `cmask`) of the current frame, which holds nm matches, still
 // reach 5 matches - i.e. does the reference's tree hold a node with >= 5 matches below it? The same depth-first search on
 // validity alone (no totals), stopped at the first such node; it follows the skip rule of tree.py:98, under which a node
@@ -485,12 +527,7 @@ __device__ __forceinline__ bool probe(Walk<G> &w, int f, int nm, int cand, uint6
                     else return *reinterpret_cast<const unsigned long long *>(ve);
                 };
                 unsigned long long m = mask;
-                int q = 0;
-                for (; q + 4 <= nm; q += 4) { // four masks in flight
-                    const unsigned long long v0 = vload(q), v1 = vload(q + 1), v2 = vload(q + 2), v3 = vload(q + 3);
-                    m &= (v0 & v1) & (v2 & v3);
-                }
-                for (; q < nm; ++q) m &= vload(q);
+                for_rows(nm, vload, [&](unsigned long long v) { m &= v; });
                 const unsigned long long ex = __ballot(in && m != 0ull);
                 ++passes;
                 if (!ex) {
@@ -646,12 +683,7 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
                             else if (G == 32) return *reinterpret_cast<const uint32_t *>(ve);
                             else return *reinterpret_cast<const unsigned long long *>(ve);
                         };
-                        int q = 0;
-                        for (; q + 4 <= nm; q += 4) { // four masks in flight
-                            const unsigned long long v0 = vload(q), v1 = vload(q + 1), v2 = vload(q + 2), v3 = vload(q + 3);
-                            m &= (v0 & v1) & (v2 & v3);
-                        }
-                        for (; q < nm; ++q) m &= vload(q);
+                        for_rows(nm, vload, [&](unsigned long long v) { m &= v; });
                         cb = __ballot(in && m != 0ull);
                         flags |= kFiltered;
                         ++w.passes;
@@ -700,22 +732,12 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
                 const float self = *reinterpret_cast<const float *>(Sb + (((uint32_t)ksf << PSH) + bo));
                 float lo = 1.f; // smallest pair entry: the candidate is valid for this conformer iff every entry is > 0 (tree.py:81)
                 double sum = 0.0;
-                int q = 0;
-                for (; q + 4 <= nm; q += 4) {
-                    float v[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float *>(Pb + (((uint32_t)rl(ebv, q + u) << PSH) + bo));
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        lo = fminf(lo, v[u]);
-                        sum += (double)v[u];
-                    }
-                }
-                for (; q < nm; ++q) {
-                    const float v = *reinterpret_cast<const float *>(Pb + (((uint32_t)rl(ebv, q) << PSH) + bo));
-                    lo = fminf(lo, v);
-                    sum += (double)v;
-                }
+                for_rows(
+                    nm, [&](int q) { return *reinterpret_cast<const float *>(Pb + (((uint32_t)rl(ebv, q) << PSH) + bo)); },
+                    [&](float v) {
+                        lo = fminf(lo, v);
+                        sum += (double)v;
+                    });
                 // (v_min_f32 skips a NaN entry - a zero-weight pair, match_utils.py:50-52 - but the sum does not: NaN is not > 0)
                 valid = on && ((mask >> c) & 1ull) && lo > 0.f && sum == sum;
                 t = (tparent + (double)self) + sum; // parent + self + accumulated pair (tree.py:38-41)
@@ -775,22 +797,12 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
                     const float self1 = *reinterpret_cast<const float *>(Sb + (((uint32_t)ks1 << PSH) + bo1));
                     bool base_valid = on1;
                     double base_sum = 0.0;
-                    int q = 0;
-                    for (; q + 4 <= nm; q += 4) { // four rows in flight, added in order
-                        float v[4];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float *>(Pb + (((uint32_t)rl(ebv1, q + u)) << PSH) + bo1);
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            base_valid = base_valid & (v[u] > 0.f);
-                            base_sum += (double)v[u];
-                        }
-                    }
-                    for (; q < nm; ++q) {
-                        const float v = *reinterpret_cast<const float *>(Pb + (((uint32_t)rl(ebv1, q)) << PSH) + bo1);
-                        base_valid = base_valid & (v > 0.f);
-                        base_sum += (double)v;
-                    }
+                    for_rows(
+                        nm, [&](int q) { return *reinterpret_cast<const float *>(Pb + (((uint32_t)rl(ebv1, q)) << PSH) + bo1); },
+                        [&](float v) { // added in order
+                            base_valid = base_valid & (v > 0.f);
+                            base_sum += (double)v;
+                        });
                     // entry((f, b) -> (f + 1, b')) = rowbase[f] + b * k1 + b'
                     const uint32_t row_f = (uint32_t)rl(w.hrow, f);
                     lds_sync();
@@ -1565,7 +1577,7 @@ __device__ __forceinline__ unsigned char *prepare_ligand(const ScreenParams &p, 
     const uint64_t bytes64 = rec_bytes<G>(L.ksumtot, L.T, (uint32_t)L.nl);
     unsigned char *rec = p.slices + (size_t)wave_id * p.slice_bytes;
     uint32_t rec16 = 0;
-    if (p.mode != 2) {
+    if (p.mode < 2) {
         if (bytes64 > p.slice_bytes) { // tables do not fit the slice: a later pass with larger slices (or the arena) takes this ligand
             if (lane == 0) {
                 if (p.mode == 0) {

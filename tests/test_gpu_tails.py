@@ -135,7 +135,10 @@ def test_self_entries_in_the_tails_match_the_oracle(name, n_conf, delta, oracle,
     print(f"{name} C={n_conf}: {n_pairs} subset pairs, {n_checked} scores above {FLOOR:g}; max rel err vs oracle {worst:.2e}, "
           f"default vs term-by-term {worst_vs_exact:.2e}; {n_slow} self items evaluated term by term")
     assert n_slow > 0  # the sweep reaches the flagged cells
-    assert worst_vs_exact <= 1e-6
+    # The term-by-term phase reproduces the reference's float32 rounding of z and z^2 (up to 1.8e-7 z^2 / 2 of a term), a table of
+    # the smooth function cannot: cells are evaluated term by term from exponent 6 on, below that the two differ by up to
+    # 6 * 1.8e-7 + the table's 2e-7 + the float32 Horner steps.
+    assert worst_vs_exact <= 1.8e-6
 
 
 def test_tail_self_entry_decides_a_whole_ligand(oracle):

@@ -188,6 +188,7 @@ def test_arena_pass_is_retried_with_the_arena_empty(monkeypatch):
     engine.release_workspaces()
     try:
         with monkeypatch.context() as mp:
+            mp.setenv("PMX_SLICE_KB", "64")
             mp.setenv("PMX_BIG_SLICE_MB", "1")
             mp.setenv("PMX_ARENA_MB", "6")
             got, status = _gpu(model, lib, weights)
@@ -195,6 +196,7 @@ def test_arena_pass_is_retried_with_the_arena_empty(monkeypatch):
         assert rel_err(got, d["score"]).max() < RTOL
         engine.release_workspaces()
         with monkeypatch.context() as mp:  # an arena smaller than the largest table: that ligand, and only that kind, is reported
+            mp.setenv("PMX_SLICE_KB", "64")
             mp.setenv("PMX_BIG_SLICE_MB", "1")
             mp.setenv("PMX_ARENA_MB", "2")
             got, status = _gpu(model, lib, weights)
