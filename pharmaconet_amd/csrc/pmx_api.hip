@@ -496,43 +496,63 @@ static bool trace_on() {
 }
 
 // ------------------------------------------------------------------------------------ the screening engine (pmx_screen.hip)
-// Everything a call does is enqueued on the caller's stream: no device-to-host read, no host thread, no lock held while
-// kernels run. Per super-chunk of <= PMX_SUPER ligands: clear the control block; ligand_kernel over the range (tables in
-// per-wave slices); ligand_kernel over the ligands whose tables need the arena; a fixed number of task rounds (each a
-// snapshot of the queue + one persistent launch that exits at once when the round is empty; the last round never
-// queues); finalize; then the same once more for ligands the arena had no room for (normally none).
-struct ScreenWs {
+// A call is cut into chunks of <= PMX_SUPER ligands (per pocket); a chunk is: clear the control block; ligand_kernel over the
+// range (tables in per-wave slices); ligand_kernel over the ligands whose tables need larger slices / the arena; a fixed
+// number of task rounds (each a snapshot of the queue + one persistent launch that exits at once when the round is empty; the
+// last round never queues); finalize. The ligand kernels of all chunks go out on the caller's stream; the task rounds of a
+// chunk go out on a side stream of the workspace, behind an event of the chunk's ligand kernels, and so run *next to* the
+// ligand kernels of the following chunk (of the same pocket or the next one): two sets of control block / arena / queue /
+// lists alternate, a set is reused when its chunk's rounds are done (event), and the caller's stream waits for the side
+// stream at the end - everything stays ordered on the caller's stream, nothing is read back, no host thread. The two kernels
+// share the wave slots of a CU (PMX_LIG_SHARE): the walkers of the task rounds are bound by scalar issue, the table phase
+// of the ligand kernel by vector issue and memory, so side by side they fill what the other leaves idle.
+struct ChunkSet {
     Ctl *ctl = nullptr;
-    uint8_t *slices = nullptr;
-    size_t slices_bytes = 0;
-    uint8_t *big = nullptr;
-    size_t big_bytes = 0;
-    uint8_t *totbuf = nullptr;
-    size_t totbuf_bytes = 0;
     uint8_t *arena = nullptr;
     size_t arena_bytes = 0;
     uint8_t *queue = nullptr;
     size_t queue_bytes = 0;
     uint32_t *lists = nullptr; // ovf | carry | heavy
     size_t lists_bytes = 0;
-    uint32_t list_cap = 0;
+    hipEvent_t lig_done = nullptr, tasks_done = nullptr;
+    bool pending = false; // tasks_done was recorded by the call in progress
+};
+struct ScreenWs {
+    ChunkSet set[2];
+    uint8_t *slices = nullptr;
+    size_t slices_bytes = 0;
+    uint8_t *big = nullptr;
+    size_t big_bytes = 0;
+    uint8_t *totbuf = nullptr;
+    size_t totbuf_bytes = 0;
     int num_cu = 0;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr}; // profiling: call start | last super-chunk start | its ligand kernels done | end
+    hipStream_t side = nullptr; // the task rounds' stream
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // profiling: call start | last chunk: ligand kernels start, done | end | last chunk: rounds start, done
     uint64_t ligands_last = 0;
     bool ev_valid = false;
+    bool ctl_used[2] = {false, false};
     hipStream_t last_stream = nullptr;
     std::mutex mu; // held while a call enqueues (the workspace belongs to one call at a time, in stream order)
     void free_buffers() {
-        for (void *q : {(void *)ctl, (void *)slices, (void *)big, (void *)totbuf, (void *)arena, (void *)queue, (void *)lists})
+        for (ChunkSet &c : set) {
+            for (void *q : {(void *)c.ctl, (void *)c.arena, (void *)c.queue, (void *)c.lists})
+                if (q) (void)hipFree(q);
+            for (hipEvent_t e : {c.lig_done, c.tasks_done})
+                if (e) (void)hipEventDestroy(e);
+            c = ChunkSet{};
+        }
+        for (void *q : {(void *)slices, (void *)big, (void *)totbuf})
             if (q) (void)hipFree(q);
-        ctl = nullptr, slices = big = totbuf = arena = queue = nullptr, lists = nullptr;
-        slices_bytes = big_bytes = totbuf_bytes = arena_bytes = queue_bytes = lists_bytes = 0;
-        list_cap = 0;
+        slices = big = totbuf = nullptr;
+        slices_bytes = big_bytes = totbuf_bytes = 0;
         for (auto &e : ev) {
             if (e) (void)hipEventDestroy(e);
             e = nullptr;
         }
+        if (side) (void)hipStreamDestroy(side);
+        side = nullptr;
         ev_valid = false;
+        ctl_used[0] = ctl_used[1] = false;
     }
     bool released = false; // pmx_release_workspaces took the buffers: a caller that was waiting on `mu` asks for a new workspace
 };
@@ -548,163 +568,251 @@ static std::shared_ptr<ScreenWs> ensure_screen(int device, hipStream_t stream) {
     return slot;
 }
 
+// (a buffer only ever grows; queued work may still use the old one, on the caller's stream or on the side stream)
 template <typename T>
-static int grow(T **ptr, size_t *have, size_t want, hipStream_t stream) {
+static int grow(T **ptr, size_t *have, size_t want, hipStream_t stream, hipStream_t side, size_t min_bytes = 0) {
     if (*have >= want) return PMX_OK;
     if (*ptr) {
-        HIPCHECK(hipStreamSynchronize(stream)); // queued work may still use the old buffer (only when a buffer grows)
+        HIPCHECK(hipStreamSynchronize(stream));
+        if (side) HIPCHECK(hipStreamSynchronize(side));
         (void)hipFree(*ptr);
         *ptr = nullptr;
         *have = 0;
     }
-    HIPCHECK(hipMalloc((void **)ptr, want));
+    // min_bytes: the buffer is a cache (the table arena) - a smaller one is slower, never wrong: halve on out-of-memory
+    for (;;) {
+        const hipError_t e = hipMalloc((void **)ptr, want);
+        if (e == hipSuccess) break;
+        (void)hipGetLastError();
+        if (e != hipErrorOutOfMemory || min_bytes == 0 || want / 2 < min_bytes)
+            return fail(e == hipErrorOutOfMemory ? PMX_ERR_OOM : PMX_ERR_HIP, "hipMalloc of %zu bytes failed: %s", want, hipGetErrorString(e));
+        want /= 2;
+    }
     *have = want;
     return PMX_OK;
 }
 
+// What one pocket of a call needs: kernel parameters, launch shapes, chunk size.
+struct PocketPlan {
+    ScreenParams p;
+    size_t lds = 0;
+    uint32_t waves_per_cu = 0;
+    uint32_t slice_bytes = 0, big_bytes = 0, big_grid = 0;
+    uint64_t worst_bytes = 0;
+    uint32_t super = 0;
+};
+
 template <int G>
-static int score_screen(const pmx_model *model, const pmx_library *lib, const Weights &W, uint64_t first, uint64_t count, float *scores_dev,
-                        int32_t *status_dev, hipStream_t stream, ScreenWs &ws, bool first_model) {
+static int score_screen(const pmx_model *const *models, int n_models, const pmx_library *lib, const Weights &W, uint64_t first, uint64_t count,
+                        float *scores_dev, int32_t *status_dev, hipStream_t stream, ScreenWs &ws) {
     if (count > 0xfffffff0ull) return fail(PMX_ERR_INVALID, "more than 2^32 ligands in one call");
-    if (!ws.ctl) {
+    if (!ws.num_cu) {
         hipDeviceProp_t prop;
         HIPCHECK(hipGetDeviceProperties(&prop, lib->device));
         ws.num_cu = prop.multiProcessorCount;
-        HIPCHECK(hipMalloc((void **)&ws.ctl, sizeof(Ctl)));
         for (auto &e : ws.ev) HIPCHECK(hipEventCreate(&e));
+        HIPCHECK(hipStreamCreateWithFlags(&ws.side, hipStreamNonBlocking));
+        for (ChunkSet &c : ws.set) {
+            HIPCHECK(hipMalloc((void **)&c.ctl, sizeof(Ctl)));
+            HIPCHECK(hipEventCreateWithFlags(&c.lig_done, hipEventDisableTiming));
+            HIPCHECK(hipEventCreateWithFlags(&c.tasks_done, hipEventDisableTiming));
+        }
     }
-    ScreenParams p;
-    p.M = model->dm;
-    int rc = pair_functions(const_cast<pmx_model *>(model), W, stream, &p.F);
-    if (rc) return rc;
-    p.lib = lib->dl;
-    p.sidtab = model->sidtab;
-    p.subnodes = model->subnodes;
-    p.W = W;
-    p.first = first;
-    p.ctl = ws.ctl;
-    p.flags = (uint32_t)env_long("PMX_TREE_FLAGS", 0);
-    p.max_nodes = (uint32_t)std::max(4, std::min(lib->info.max_nodes, PMX_MAX_LIGAND_NODES));
-    const WaveShape<G> shape = wave_shape<G>(model->dm.K, (int)p.max_nodes);
-    const uint32_t waves_per_cu = (uint32_t)std::max<long>(1, std::min<long>({(long)(kLdsPerCu / shape.bytes), 4L * PMX_SCREEN_WAVES, env_long("PMX_WAVES_PER_CU", 32)}));
-    const uint32_t grid = (uint32_t)ws.num_cu * waves_per_cu;
-    // per-wavefront slice: 80 KB at 8 conformer lanes (every ligand of the bench library fits), scaled with the lanes
-    // (table bytes grow with the square of the model's cluster count: the 11-cluster 6OIM-like model is the reference point)
-    const long k_scale = std::max(1L, std::min(16L, ((long)model->dm.K * model->dm.K + 60) / 121));
-    const uint32_t slice_bytes = (uint32_t)std::max<long>(4, env_long("PMX_SLICE_KB", 80L * std::max(1, G / 8) * k_scale)) * 1024u;
-    rc = grow(&ws.slices, &ws.slices_bytes, (size_t)grid * slice_bytes, stream);
-    if (rc) return rc;
-    // large slices for the ligands whose tables exceed a slice: as large as a table of this model and library can get, at most
-    // PMX_BIG_SLICE_MB each, PMX_BIG_TOTAL_MB together (what is larger still goes to the arena)
-    uint32_t big_bytes, big_grid;
-    uint64_t worst_bytes;
-    {
-        const uint64_t nlmax = (uint64_t)std::min<int>(PMX_MAX_LEVELS, std::max(1, lib->info.max_clusters));
-        const uint64_t K = (uint64_t)std::max(1, model->dm.K);
-        const uint64_t worst = rec_bytes<G>((uint32_t)(nlmax * K), (uint32_t)(nlmax * (nlmax - 1) / 2 * K * K), (uint32_t)nlmax);
-        const uint64_t cap = (uint64_t)std::max<long>(1, env_long("PMX_BIG_SLICE_MB", G >= 32 ? 4 : 32)) << 20;
-        worst_bytes = worst;
-        big_bytes = (uint32_t)std::max<uint64_t>(slice_bytes, (std::min(worst, cap) + 4095) & ~4095ull);
-        const uint64_t total = (uint64_t)std::max<long>(64, env_long("PMX_BIG_TOTAL_MB", G >= 32 ? 16384 : 4096)) << 20;
-        big_grid = (uint32_t)std::max<uint64_t>(16, std::min<uint64_t>(grid, total / big_bytes));
-    }
-    rc = grow(&ws.big, &ws.big_bytes, (size_t)big_grid * big_bytes, stream);
-    if (rc) return rc;
-    if (!totals_in_lds<G>()) {
-        rc = grow(&ws.totbuf, &ws.totbuf_bytes, (size_t)ws.num_cu * 4u * std::max(PMX_SCREEN_WAVES, PMX_TASK_WAVES) * kTotBufBytes, stream);
-        if (rc) return rc;
-    }
-    p.totbuf = ws.totbuf;
-    rc = grow(&ws.arena, &ws.arena_bytes, (size_t)std::max<long>(1, env_long("PMX_ARENA_MB", 32768)) << 20, stream);
-    if (rc) return rc;
-    rc = grow(&ws.queue, &ws.queue_bytes, (size_t)std::max<long>(1, env_long("PMX_TASKQ_MB", 2048L * std::max(1, G / 8))) << 20, stream);
-    if (rc) return rc;
-    // super-chunk: the arena holds the tables of the ligands whose tree is split, until the chunk's subtrees are done
-    const uint32_t super = (uint32_t)std::max<long>(1024, std::min<long>(env_long("PMX_SUPER", std::max(16384L, (1L << 20) * 8 / std::max(G, 8) / k_scale)), 1 << 24));
-    rc = grow(&ws.lists, &ws.lists_bytes, (size_t)super * 12, stream);
-    if (rc) {
-        ws.list_cap = 0;
-        return rc;
-    }
-    ws.list_cap = super;
-    p.arena = ws.arena;
-    p.arena_bytes = std::min<unsigned long long>(ws.arena_bytes, (1ull << 36) - 4096);
-    p.ovf_list = ws.lists;
-    p.carry_list = ws.lists + super;
-    p.heavy_list = ws.lists + 2 * (size_t)super;
-    p.list_cap = super;
-    p.queue = ws.queue;
-    p.qcap = (uint32_t)std::min<size_t>(ws.queue_bytes / task_rec_bytes<G>() / kShards, 0x3fffffffu / kShards);
+    const uint32_t flags = (uint32_t)env_long("PMX_TREE_FLAGS", 0);
+    const uint32_t max_nodes = (uint32_t)std::max(4, std::min(lib->info.max_nodes, PMX_MAX_LIGAND_NODES));
     const uint32_t lig_budget = (uint32_t)std::max<long>(16, env_long("PMX_BUDGET", 512));
     const uint32_t task_budget = (uint32_t)std::max<long>(16, env_long("PMX_TASK_BUDGET", lig_budget)); // a queued subtree's own budget
-    p.budget = lig_budget;
-    p.min_levels = (uint32_t)std::max<long>(0, env_long("PMX_MIN_LEVELS", 3));
-    p.scores = scores_dev;
-    p.status = status_dev;
     const int rounds = (int)std::max<long>(1, env_long("PMX_ROUNDS", 12));
-    p.last_round = 0;
-    p.retry_in = nullptr;
-    p.retry_out = nullptr;
-    p.retry_slot = 0;
-    p.bound_cost = (uint32_t)std::max<long>(0, env_long("PMX_BOUND_COST", 8192));
-    const bool exact = (p.flags & 8) != 0;
-    const size_t lds = shape.bytes;
-    if (g_profiling && first_model) HIPCHECK(hipEventRecord(ws.ev[0], stream));
-    auto launch = [&](int mode, uint32_t blocks) {
-        p.mode = mode;
-        if (exact) ligand_kernel<G, true><<<dim3(blocks), dim3(64), lds, stream>>>(p);
-        else ligand_kernel<G, false><<<dim3(blocks), dim3(64), lds, stream>>>(p);
-    };
-    for (uint64_t lo = 0; lo < count; lo += super) {
-        p.lo = (uint32_t)lo;
-        p.hi = (uint32_t)std::min<uint64_t>(count, lo + super);
-        if (g_profiling) HIPCHECK(hipEventRecord(ws.ev[1], stream));
-        ws.ligands_last = p.hi - p.lo;
-        ctl_clear_kernel<<<dim3((sizeof(Ctl) / 4 + 255) / 256), dim3(256), 0, stream>>>(ws.ctl, (lo == 0 && first_model) ? 1 : 0);
-        p.last_round = 0;
+    const bool exact = (flags & 8) != 0;
+
+    // ---- per pocket: parameters and launch shapes
+    std::vector<PocketPlan> plan((size_t)n_models);
+    size_t slices_need = 0, big_need = 0, totbuf_need = 0;
+    uint32_t super_max = 0;
+    bool retry_possible = false;
+    for (int m = 0; m < n_models; ++m) {
+        const pmx_model *model = models[m];
+        PocketPlan &pl = plan[(size_t)m];
+        ScreenParams &p = pl.p;
+        p = ScreenParams{};
+        p.M = model->dm;
+        int rc = pair_functions(const_cast<pmx_model *>(model), W, stream, &p.F);
+        if (rc) return rc;
+        p.lib = lib->dl;
+        p.sidtab = model->sidtab;
+        p.subnodes = model->subnodes;
+        p.W = W;
+        p.first = first;
+        p.flags = flags;
+        p.max_nodes = max_nodes;
         p.budget = lig_budget;
-        // every ligand whose tables fit a slice
-        p.slices = ws.slices;
-        p.slice_bytes = slice_bytes;
-        launch(0, grid);
-        // the others with large slices (fewer wavefronts)
-        p.slices = ws.big;
-        p.slice_bytes = big_bytes;
-        launch(1, big_grid);
-        // and what exceeds those from the arena; ligands that find it full (of the tables of over-budget trees, or of each
-        // other) are listed in the storage of the overflow list, which is done with
-        p.retry_out = ws.lists;
-        p.retry_slot = 0;
-        launch(2, big_grid);
-        if (g_profiling) HIPCHECK(hipEventRecord(ws.ev[2], stream));
-        // the subtrees the over-budget walkers queued, and the ones those queue in turn: a fixed number of rounds, each a snapshot of
-        // the queue and one persistent launch (an empty round exits at once); the last round walks everything to its end
-        auto rounds_and_finalize = [&]() {
-            p.budget = task_budget;
-            for (int r = 0; r < rounds; ++r) {
-                p.last_round = r + 1 == rounds ? 1u : 0u;
-                round_kernel<<<dim3(1), dim3(64), 0, stream>>>(ws.ctl, p.qcap);
-                task_kernel<G><<<dim3(std::min<uint32_t>(grid, (uint32_t)ws.num_cu * 4u * PMX_TASK_WAVES)), dim3(64), lds, stream>>>(p);
-            }
-            finalize_kernel<G><<<dim3((super + 255) / 256), dim3(256), 0, stream>>>(p);
+        p.min_levels = (uint32_t)std::max<long>(0, env_long("PMX_MIN_LEVELS", 3));
+        p.bound_cost = (uint32_t)std::max<long>(0, env_long("PMX_BOUND_COST", 8192));
+        p.scores = scores_dev + (size_t)m * count;
+        p.status = m == 0 ? status_dev : nullptr;
+        const WaveShape<G> shape = wave_shape<G>(model->dm.K, (int)max_nodes);
+        pl.lds = shape.bytes;
+        pl.waves_per_cu = (uint32_t)std::max<long>(2, std::min<long>({(long)(kLdsPerCu / shape.bytes), 4L * PMX_SCREEN_WAVES, env_long("PMX_WAVES_PER_CU", 32)}));
+        const uint32_t grid = (uint32_t)ws.num_cu * pl.waves_per_cu;
+        // per-wavefront slice: 80 KB at 8 conformer lanes (every ligand of the bench library fits), scaled with the lanes
+        // (table bytes grow with the square of the model's cluster count: the 11-cluster 6OIM-like model is the reference point)
+        const long k_scale = std::max(1L, std::min(16L, ((long)model->dm.K * model->dm.K + 60) / 121));
+        pl.slice_bytes = (uint32_t)std::max<long>(4, env_long("PMX_SLICE_KB", 80L * std::max(1, G / 8) * k_scale)) * 1024u;
+        slices_need = std::max(slices_need, (size_t)grid * pl.slice_bytes);
+        // large slices for the ligands whose tables exceed a slice: as large as a table of this model and library can get, at most
+        // PMX_BIG_SLICE_MB each, PMX_BIG_TOTAL_MB together (what is larger still goes to the arena)
+        {
+            const uint64_t nlmax = (uint64_t)std::min<int>(PMX_MAX_LEVELS, std::max(1, lib->info.max_clusters));
+            const uint64_t K = (uint64_t)std::max(1, model->dm.K);
+            const uint64_t worst = rec_bytes<G>((uint32_t)(nlmax * K), (uint32_t)(nlmax * (nlmax - 1) / 2 * K * K), (uint32_t)nlmax);
+            const uint64_t cap = (uint64_t)std::max<long>(1, env_long("PMX_BIG_SLICE_MB", G >= 32 ? 4 : 32)) << 20;
+            pl.worst_bytes = worst;
+            pl.big_bytes = (uint32_t)std::max<uint64_t>(pl.slice_bytes, (std::min(worst, cap) + 4095) & ~4095ull);
+            const uint64_t total = (uint64_t)std::max<long>(64, env_long("PMX_BIG_TOTAL_MB", G >= 32 ? 16384 : 4096)) << 20;
+            pl.big_grid = (uint32_t)std::max<uint64_t>(16, std::min<uint64_t>(grid, total / pl.big_bytes));
+        }
+        big_need = std::max(big_need, (size_t)pl.big_grid * pl.big_bytes);
+        retry_possible = retry_possible || pl.worst_bytes > pl.big_bytes;
+        if (!totals_in_lds<G>()) totbuf_need = (size_t)ws.num_cu * 4u * std::max(PMX_SCREEN_WAVES, PMX_TASK_WAVES) * kTotBufBytes * 2u; // ligand kernel | task kernel
+        // chunk: what the arena has to hold at a time are the tables of the chunk's split trees. (Cutting a pocket's pass into more
+        // chunks than the arena asks for does not pay: every chunk ends in a dozen rounds with a tail each - 1 M ligands in 8
+        // chunks: 258 ms back to back, 234 ms with the rounds beside the next chunk's ligand kernel, 207 ms in one chunk.)
+        const long super_dflt = std::max(16384L, (1L << 20) * 8 / std::max(G, 8) / k_scale);
+        pl.super = (uint32_t)std::max<long>(1024, std::min<long>(env_long("PMX_SUPER", super_dflt), 1 << 24));
+        super_max = std::max(super_max, pl.super);
+    }
+    int rc = grow(&ws.slices, &ws.slices_bytes, slices_need, stream, ws.side);
+    if (rc) return rc;
+    rc = grow(&ws.big, &ws.big_bytes, big_need, stream, ws.side);
+    if (rc) return rc;
+    if (totbuf_need) {
+        rc = grow(&ws.totbuf, &ws.totbuf_bytes, totbuf_need, stream, ws.side);
+        if (rc) return rc;
+    }
+    for (ChunkSet &c : ws.set) {
+        // (PMX_ARENA_MB / PMX_TASKQ_MB are per set; a smaller arena than asked for is slower - more trees walked by one
+        // wavefront alone - never wrong, so it shrinks when memory is short: several streams each keep a workspace)
+        rc = grow(&c.arena, &c.arena_bytes, (size_t)std::max<long>(1, env_long("PMX_ARENA_MB", 16384)) << 20, stream, ws.side, std::min<size_t>((size_t)1 << 30, (size_t)std::max<long>(1, env_long("PMX_ARENA_MB", 16384)) << 20));
+        if (rc) return rc;
+        rc = grow(&c.queue, &c.queue_bytes, (size_t)std::max<long>(1, env_long("PMX_TASKQ_MB", 1024L * std::max(1, G / 8))) << 20, stream, ws.side);
+        if (rc) return rc;
+        rc = grow(&c.lists, &c.lists_bytes, (size_t)super_max * 12, stream, ws.side);
+        if (rc) return rc;
+    }
+    uint64_t n_chunks = 0;
+    for (const PocketPlan &pl : plan) n_chunks += (count + pl.super - 1) / pl.super;
+    // The rounds go to the side stream when there is something to run them next to. (Not when an arena pass may have to be
+    // retried: the retry's ligand kernels use the large slices, as the next chunk's do.)
+    // [MI355X]: 4 M ligands of the bench library in 4 chunks 797 ms against 822 ms back to back; 16 pockets x 200 704 ligands
+    // 3.79 s against 3.70 s - successive pockets differ too much in what their two phases cost for a fixed split of the wave
+    // slots - so the default is: beside each other within a pocket, one after the other across pockets.
+    const bool overlap = n_chunks >= 2 && !retry_possible && env_long("PMX_OVERLAP", n_models == 1 ? 1 : 0) != 0;
+    hipStream_t side = overlap ? ws.side : stream;
+    const double lig_share = std::min(0.9, std::max(0.1, std::atof(std::getenv("PMX_LIG_SHARE") ? std::getenv("PMX_LIG_SHARE") : "0.5")));
+
+    if (g_profiling) HIPCHECK(hipEventRecord(ws.ev[0], stream));
+    ws.ctl_used[0] = ws.ctl_used[1] = false;
+    ws.set[0].pending = ws.set[1].pending = false;
+    uint64_t seq = 0;
+    for (int m = 0; m < n_models; ++m) {
+        PocketPlan &pl = plan[(size_t)m];
+        ScreenParams p = pl.p;
+        const uint32_t super = pl.super;
+        const uint32_t full = pl.waves_per_cu;
+        const uint32_t lig_waves = std::min(full - 1, std::max(1u, (uint32_t)(full * lig_share + 0.5)));
+        for (uint64_t lo = 0; lo < count; lo += super, ++seq) {
+            const bool first_chunk = seq == 0, last_chunk = seq + 1 == n_chunks;
+            ChunkSet &c = ws.set[seq & 1];
+            const int ci = (int)(seq & 1);
+            p.lo = (uint32_t)lo;
+            p.hi = (uint32_t)std::min<uint64_t>(count, lo + super);
+            p.ctl = c.ctl;
+            p.arena = c.arena;
+            p.arena_bytes = std::min<unsigned long long>(c.arena_bytes, (1ull << 36) - 4096);
+            p.ovf_list = c.lists;
+            p.carry_list = c.lists + super;
+            p.heavy_list = c.lists + 2 * (size_t)super;
+            p.list_cap = super;
+            p.queue = c.queue;
+            p.qcap = (uint32_t)std::min<size_t>(c.queue_bytes / task_rec_bytes<G>() / kShards, 0x3fffffffu / kShards);
+            p.totbuf = ws.totbuf;
+            // this set's last chunk (two chunks ago) has to be through its rounds
+            if (overlap && c.pending) HIPCHECK(hipStreamWaitEvent(stream, c.tasks_done, 0));
+            if (g_profiling && last_chunk) HIPCHECK(hipEventRecord(ws.ev[1], stream));
+            ws.ligands_last = p.hi - p.lo;
+            ctl_clear_kernel<<<dim3((sizeof(Ctl) / 4 + 255) / 256), dim3(256), 0, stream>>>(c.ctl, ws.ctl_used[ci] ? 0 : 1);
+            ws.ctl_used[ci] = true;
+            // the first chunk's ligand kernel has the device to itself, the others share it with the rounds of the chunk before
+            const uint32_t lig_grid = (uint32_t)ws.num_cu * ((overlap && !first_chunk) ? lig_waves : full);
+            const uint32_t task_grid = (uint32_t)ws.num_cu * std::min<uint32_t>(4u * PMX_TASK_WAVES, (overlap && !last_chunk) ? full - lig_waves : full);
+            auto launch = [&](int mode, uint32_t blocks, hipStream_t on) {
+                p.mode = mode;
+                if (exact) ligand_kernel<G, true><<<dim3(blocks), dim3(64), pl.lds, on>>>(p);
+                else ligand_kernel<G, false><<<dim3(blocks), dim3(64), pl.lds, on>>>(p);
+            };
             p.last_round = 0;
             p.budget = lig_budget;
-        };
-        rounds_and_finalize();
-        // Ligands the arena pass had no room for, with the arena to themselves (only models and libraries whose largest tables
-        // exceed a large slice ever get here): twice, the second time reporting what still does not fit.
-        if (worst_bytes > big_bytes) {
-            for (int t = 0; t < 2; ++t) {
-                retry_prep_kernel<<<dim3(1), dim3(64), 0, stream>>>(ws.ctl, (uint32_t)(t + 1) & 1u);
-                p.retry_in = t == 0 ? ws.lists : ws.lists + super;
-                p.retry_out = t == 0 ? ws.lists + super : nullptr;
-                p.retry_slot = (uint32_t)(t + 1) & 1u;
-                launch(3, big_grid);
-                rounds_and_finalize();
+            // every ligand whose tables fit a slice
+            p.slices = ws.slices;
+            p.slice_bytes = pl.slice_bytes;
+            launch(0, lig_grid, stream);
+            // the others with large slices (fewer wavefronts)
+            p.slices = ws.big;
+            p.slice_bytes = pl.big_bytes;
+            launch(1, std::min(pl.big_grid, lig_grid), stream);
+            // and what exceeds those from the arena; ligands that find it full (of the tables of over-budget trees, or of each
+            // other) are listed in the storage of the overflow list, which is done with
+            p.retry_out = c.lists;
+            p.retry_slot = 0;
+            launch(2, std::min(pl.big_grid, lig_grid), stream);
+            if (g_profiling && last_chunk) HIPCHECK(hipEventRecord(ws.ev[2], stream));
+            if (overlap) {
+                HIPCHECK(hipEventRecord(c.lig_done, stream));
+                HIPCHECK(hipStreamWaitEvent(side, c.lig_done, 0));
+            }
+            if (g_profiling && last_chunk) HIPCHECK(hipEventRecord(ws.ev[4], side));
+            // the subtrees the over-budget walkers queued, and the ones those queue in turn: a fixed number of rounds, each a snapshot of
+            // the queue and one persistent launch (an empty round exits at once); the last round walks everything to its end
+            if (!totals_in_lds<G>()) p.totbuf = ws.totbuf + ws.totbuf_bytes / 2;
+            auto rounds_and_finalize = [&]() {
+                p.budget = task_budget;
+                for (int r = 0; r < rounds; ++r) {
+                    p.last_round = r + 1 == rounds ? 1u : 0u;
+                    round_kernel<<<dim3(1), dim3(64), 0, side>>>(c.ctl, p.qcap);
+                    task_kernel<G><<<dim3(task_grid), dim3(64), pl.lds, side>>>(p);
+                }
+                finalize_kernel<G><<<dim3((super + 255) / 256), dim3(256), 0, side>>>(p);
+                p.last_round = 0;
+                p.budget = lig_budget;
+            };
+            rounds_and_finalize();
+            // Ligands the arena pass had no room for, with the arena to themselves (only models and libraries whose largest tables
+            // exceed a large slice ever get here; `side` is the caller's stream then): twice, the second time reporting what
+            // still does not fit.
+            if (pl.worst_bytes > pl.big_bytes) {
+                for (int t = 0; t < 2; ++t) {
+                    retry_prep_kernel<<<dim3(1), dim3(64), 0, side>>>(c.ctl, (uint32_t)(t + 1) & 1u);
+                    p.retry_in = t == 0 ? c.lists : c.lists + super;
+                    p.retry_out = t == 0 ? c.lists + super : nullptr;
+                    p.retry_slot = (uint32_t)(t + 1) & 1u;
+                    p.totbuf = ws.totbuf;
+                    launch(3, std::min(pl.big_grid, lig_grid), side);
+                    if (!totals_in_lds<G>()) p.totbuf = ws.totbuf + ws.totbuf_bytes / 2;
+                    rounds_and_finalize();
+                }
+                p.retry_in = nullptr;
+            }
+            if (g_profiling && last_chunk) HIPCHECK(hipEventRecord(ws.ev[5], side));
+            if (overlap) {
+                HIPCHECK(hipEventRecord(c.tasks_done, side));
+                c.pending = true;
             }
         }
     }
     HIPCHECK(hipGetLastError());
+    if (overlap) // the call ends on the caller's stream
+        for (ChunkSet &c : ws.set)
+            if (c.pending) HIPCHECK(hipStreamWaitEvent(stream, c.tasks_done, 0));
     if (g_profiling) HIPCHECK(hipEventRecord(ws.ev[3], stream));
     ws.ev_valid = g_profiling != 0;
     ws.last_stream = stream;
@@ -716,16 +824,21 @@ static int screen_stats(pmx_score_stats *out) {
     const std::shared_ptr<ScreenWs> w = g_last_screen;
     if (!w) return PMX_OK;
     std::lock_guard<std::mutex> lock(w->mu);
-    if (w->released || !w->ctl) return PMX_OK; // (the workspace was released after the call: its counters went with it)
+    if (w->released || !w->num_cu) return PMX_OK; // (the workspace was released after the call: its counters went with it)
     HIPCHECK(hipSetDevice(g_last_device));
     HIPCHECK(hipStreamSynchronize(w->last_stream));
-    std::vector<unsigned char> host(sizeof(Ctl));
-    HIPCHECK(hipMemcpy(host.data(), w->ctl, sizeof(Ctl), hipMemcpyDeviceToHost));
-    const Ctl *c = reinterpret_cast<const Ctl *>(host.data());
     unsigned long long st[kStatWords] = {0};
-    for (int sh = 0; sh < kScreenStatShards; ++sh)
-        for (int i = 0; i < kStatWords; ++i) st[i] = (i == 5) ? std::max(st[i], c->stats[sh][i]) : st[i] + c->stats[sh][i];
+    std::vector<unsigned char> host(sizeof(Ctl));
     *out = pmx_score_stats{};
+    for (int ci = 0; ci < 2; ++ci) {
+        if (!w->ctl_used[ci]) continue;
+        HIPCHECK(hipMemcpy(host.data(), w->set[ci].ctl, sizeof(Ctl), hipMemcpyDeviceToHost));
+        const Ctl *c = reinterpret_cast<const Ctl *>(host.data());
+        for (int sh = 0; sh < kScreenStatShards; ++sh)
+            for (int i = 0; i < kStatWords; ++i) st[i] = (i == 5) ? std::max(st[i], c->stats[sh][i]) : st[i] + c->stats[sh][i];
+        out->queue_overflow |= c->qflag;
+        out->arena_bytes = std::max<uint64_t>(out->arena_bytes, c->arena_top);
+    }
     out->n_frames = st[0];
     out->n_passes = st[1];
     out->n_heavy = st[2];
@@ -740,8 +853,6 @@ static int screen_stats(pmx_score_stats *out) {
     out->n_exact_values = st[13];
     for (int i = 0; i < 8; ++i) out->dbg[i] = st[16 + i];
     out->ticks_scan = st[8], out->ticks_tables = st[9], out->ticks_bounds = st[10], out->ticks_walk = st[11], out->ticks_alive = st[12];
-    out->queue_overflow = c->qflag;
-    out->arena_bytes = c->arena_top;
     out->ligands_last = w->ligands_last;
     if (w->ev_valid) {
         float ms = 0.f;
@@ -749,7 +860,7 @@ static int screen_stats(pmx_score_stats *out) {
         out->ms_total = ms;
         HIPCHECK(hipEventElapsedTime(&ms, w->ev[1], w->ev[2]));
         out->ms_ligand = ms;
-        HIPCHECK(hipEventElapsedTime(&ms, w->ev[2], w->ev[3]));
+        HIPCHECK(hipEventElapsedTime(&ms, w->ev[4], w->ev[5]));
         out->ms_tasks = ms;
     }
     return PMX_OK;
@@ -787,18 +898,14 @@ extern "C" int pmx_score_multi(const pmx_model *const *models, int n_models, con
         if (!ws->released) break;
         lock.unlock(); // released while this call waited: the map holds a fresh one (or will make one)
     }
-    for (int m = 0; m < n_models && rc == PMX_OK; ++m) {
-        float *sc = scores_dev + (size_t)m * count;
-        int32_t *st = m == 0 ? status_dev : nullptr;
-        switch (G) {
-        case 1: rc = score_screen<1>(models[m], lib, W, first, count, sc, st, stream, *ws, m == 0); break;
-        case 2: rc = score_screen<2>(models[m], lib, W, first, count, sc, st, stream, *ws, m == 0); break;
-        case 4: rc = score_screen<4>(models[m], lib, W, first, count, sc, st, stream, *ws, m == 0); break;
-        case 8: rc = score_screen<8>(models[m], lib, W, first, count, sc, st, stream, *ws, m == 0); break;
-        case 16: rc = score_screen<16>(models[m], lib, W, first, count, sc, st, stream, *ws, m == 0); break;
-        case 32: rc = score_screen<32>(models[m], lib, W, first, count, sc, st, stream, *ws, m == 0); break;
-        default: rc = score_screen<64>(models[m], lib, W, first, count, sc, st, stream, *ws, m == 0); break;
-        }
+    switch (G) {
+    case 1: rc = score_screen<1>(models, n_models, lib, W, first, count, scores_dev, status_dev, stream, *ws); break;
+    case 2: rc = score_screen<2>(models, n_models, lib, W, first, count, scores_dev, status_dev, stream, *ws); break;
+    case 4: rc = score_screen<4>(models, n_models, lib, W, first, count, scores_dev, status_dev, stream, *ws); break;
+    case 8: rc = score_screen<8>(models, n_models, lib, W, first, count, scores_dev, status_dev, stream, *ws); break;
+    case 16: rc = score_screen<16>(models, n_models, lib, W, first, count, scores_dev, status_dev, stream, *ws); break;
+    case 32: rc = score_screen<32>(models, n_models, lib, W, first, count, scores_dev, status_dev, stream, *ws); break;
+    default: rc = score_screen<64>(models, n_models, lib, W, first, count, scores_dev, status_dev, stream, *ws); break;
     }
     g_last_screen = ws;
     g_last_device = lib->device;

@@ -449,7 +449,7 @@ constexpr double kBoundSlack = 1.0 + 1e-9; // covers the float64 rounding of the
 // left at the end goes out as ONE batch too. (A remainder loop that loads one row, waits, uses it and loads the next costs a
 // memory round trip per row: with 7 matched ancestors - the average of a table pass - that was four round trips instead of two.)
 #ifndef PMX_ROW_BATCH
-#define PMX_ROW_BATCH 4
+#define PMX_ROW_BATCH 8
 #endif
 constexpr int kRowBatch = PMX_ROW_BATCH;
 template <int N, typename Load, typename Use>
@@ -609,7 +609,7 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
     uint32_t next_share = w.passes + kShareEvery;
 #ifdef PMX_COUNTERS
     uint32_t dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // fused passes | fused children | cached passes | leaf passes | other passes from the tables | descents | ancestors over table passes | shares
-#define PMX_COUNT(i, n) dbg[i] += (uint32_t)(n)
+#define PMX_COUNT(i, n) do { if (PMX_COUNTERS == 1) dbg[i] += (uint32_t)(n); } while (0)
     auto flush_dbg = [&]() {
         if (lane == 0)
             for (int i = 0; i < 8; ++i) stat->dbg[i] += dbg[i];
@@ -752,6 +752,9 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
             ++w.passes;
             if (vb) flags |= kAny;
             unsigned long long ab = vb;
+#if defined(PMX_COUNTERS) && PMX_COUNTERS == 2
+            const unsigned long long dbg_vb = vb;
+#endif
             // Children with fewer than 5 matches are bound-tested too where the frame is ordered: nothing below a child that
             // fails can raise a maximum, so all the frame still needs from it is whether it reaches 5 matches (tree.py:98) -
             // nothing at all once another child has (max_num_matches is a maximum), else what probe() answers.
@@ -760,6 +763,19 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
                 const double bp = pooled > w.best ? pooled : w.best;
                 ab = __ballot(valid && (t + rbound) * kBoundSlack > bp);
             }
+#if defined(PMX_COUNTERS) && PMX_COUNTERS == 2
+            { // what the bound test does: [0] passes without an existing child [1] passes whose existing children are all dropped [2] existing children [3] survivors [4] passes under >= 5 matches [5] survivors under >= 5 matches [6] existing under >= 5 [7] passes back from a child (cached)
+                auto slots = [&](unsigned long long b) { int n = 0; for (int ss = 0; ss < SLOTS; ++ss) n += ((b >> (ss * G)) & GM) ? 1 : 0; return n; };
+                dbg[0] += dbg_vb == 0;
+                dbg[1] += dbg_vb != 0 && ab == 0;
+                dbg[2] += slots(dbg_vb);
+                dbg[3] += slots(ab);
+                dbg[4] += nm >= 4;
+                dbg[5] += nm >= 4 ? slots(ab) : 0;
+                dbg[6] += nm >= 4 ? slots(dbg_vb) : 0;
+                dbg[7] += (cacheable && (flags & kCached) && !(hv & 0)) ? 0 : 0;
+            }
+#endif
             int probe_slot = -1; // a child of this pass whose reach is probed (one call site)
             bool handled = false, pending = false;
             if (shallow && ab != vb) {
