@@ -1123,18 +1123,19 @@ __device__ __forceinline__ void item(const ScreenParams &p, uint32_t sidu, uint3
 }
 
 // The same item in two steps, so that the loads of several items are in flight together: address + loads, then value + test.
+// (What an item holds while its cell is on the way is what limits how many can be: the cell, the distance, the two subset ids
+// in one word; the position inside the cell is worked out again from the distance.)
 struct ItemLoad {
     float4 a, b;
-    float t, d;
-    uint32_t sidu, sidv;
+    float d;
+    uint32_t sids; // sidu | sidv << 16
 };
 __device__ __forceinline__ ItemLoad item_load(const ScreenParams &p, uint32_t sidu, uint32_t sidv, float d) {
     ItemLoad L;
     const float x = d * p.F.inv_h; // exact: inv_h is a power of two
     const int ci = min((int)x, (int)p.F.ncell - 1);
-    L.t = fminf(x - (float)ci, 1.0f);
     L.d = d;
-    L.sidu = sidu, L.sidv = sidv;
+    L.sids = sidu | (sidv << 16);
     const uint32_t off = (fn_index(p.F, sidu, sidv) * p.F.ncell + (uint32_t)ci) * 32u; // (the table is a few MB: 32 bits)
     const float4 *cell = reinterpret_cast<const float4 *>(reinterpret_cast<const unsigned char *>(p.F.cells) + off);
     L.a = cell[0];
@@ -1142,7 +1143,8 @@ __device__ __forceinline__ ItemLoad item_load(const ScreenParams &p, uint32_t si
     return L;
 }
 __device__ __forceinline__ void item_finish(const ScreenParams &p, const ItemLoad &L, float &acc, int &fails, uint32_t &n_exact) {
-    const float t = L.t;
+    const float x = L.d * p.F.inv_h;
+    const float t = fminf(x - (float)min((int)x, (int)p.F.ncell - 1), 1.0f);
     float v = __builtin_fmaf(t, L.b.y, L.b.x);
     v = __builtin_fmaf(t, v, L.a.w);
     v = __builtin_fmaf(t, v, L.a.z);
@@ -1150,7 +1152,7 @@ __device__ __forceinline__ void item_finish(const ScreenParams &p, const ItemLoa
     v = __builtin_fmaf(t, v, L.a.x);
     acc = acc + v;
     if (__builtin_expect(L.b.z != L.b.z, 0)) { // the pass set is not one interval inside this cell: count the terms
-        const uint64_t A = p.subnodes[L.sidu], B = p.subnodes[L.sidv];
+        const uint64_t A = p.subnodes[L.sids & 0xffffu], B = p.subnodes[L.sids >> 16];
         int np = 0;
         for (uint64_t am = A; am; am &= am - 1)
             for (uint64_t bm = B; bm; bm &= bm - 1) {
@@ -1376,49 +1378,10 @@ __device__ __forceinline__ void build_tables(const ScreenParams &p, unsigned cha
                 }
                 lds_sync();
                 const int npass = (int)__popcll(pbal);
-                for (int p0 = 0; p0 < npass; p0 += SLOTS) {
-                    const bool on = p0 + s < npass;
-                    const int e = eb + (int)plist[on ? p0 + s : p0];
+                // what is written for a finished entry: match_utils.py:71-74 (-1 unless num_fails <= L1 * L2 / 2), the row and its V mask
+                auto finish_entry = [&](int e, bool on, float acc, int fails) {
                     const int sa = (int)(((float)e + 0.5f) * inv_kj), sb = e - sa * kj;
-                    float acc = 0.f;
-                    int fails = 0;
-                    const int rowa = nci + sa * ni, rowb = ncj + sb * nj;
-                    if (EXACT) {
-                        for (int u = 0; u < ni; ++u) {
-                            const uint32_t ou = (uint32_t)((si + u) * 3 * C + cc);
-                            const float ux = xyz[ou], uy = xyz[ou + C], uz = xyz[ou + 2 * C];
-                            const uint32_t sidu = nc[rowa + u];
-                            for (int v = 0; v < nj; ++v) {
-                                const uint32_t ov = (uint32_t)((sj + v) * 3 * C + cc);
-                                const float d = norm3f(ux - xyz[ov], uy - xyz[ov + C], uz - xyz[ov + 2 * C]);
-                                item<EXACT, false>(p, sidu, nc[rowb + v], d, acc, fails, n_exact, n_exactv);
-                            }
-                        }
-                    } else {
-                        // the node pairs (u, v) in the reference's order (u outer), two at a time: coordinates, distances and cell loads
-                        // of the two go out together, then the values are added in order (an item past the end is the empty
-                        // subset pair: value 0, never a fail)
-                        constexpr int IB = PMX_ITEM_BATCH;
-                        const int npair = ni * nj;
-                        int uu = 0, vv = 0;
-                        for (int t0 = 0; t0 < npair; t0 += IB) {
-                            ItemLoad L[IB];
-#pragma unroll
-                            for (int q = 0; q < IB; ++q) {
-                                const bool in = t0 + q < npair;
-                                const int u1 = in ? uu : 0, v1 = in ? vv : 0;
-                                const uint32_t ou = (uint32_t)((si + u1) * 3 * C + cc), ov = (uint32_t)((sj + v1) * 3 * C + cc);
-                                const float d = norm3f(xyz[ou] - xyz[ov], xyz[ou + C] - xyz[ov + C], xyz[ou + 2 * C] - xyz[ov + 2 * C]);
-                                L[q] = item_load(p, in ? (uint32_t)nc[rowa + u1] : 0u, in ? (uint32_t)nc[rowb + v1] : 0u, d);
-                                if (++vv == nj) vv = 0, ++uu;
-                            }
-#pragma unroll
-                            for (int q = 0; q < IB; ++q) item_finish(p, L[q], acc, fails, n_exact);
-                        }
-                    }
-                    n_items += (uint32_t)(ni * nj);
                     const int L1 = lcnt[i * ws.kp + sa], L2 = lcnt[j * ws.kp + sb]; // graph_match.py:164-171
-                    // match_utils.py:71-74: -1 unless num_fails <= L1 * L2 / 2
                     const float value = 2 * fails <= L1 * L2 ? acc : -1.f;
                     if (on) Pt[(size_t)(pair_base + (uint32_t)e) * G + c] = value;
                     const unsigned long long pos = __ballot(on && value > 0.f);
@@ -1430,6 +1393,86 @@ __device__ __forceinline__ void build_tables(const ScreenParams &p, unsigned cha
                         else if (G == 32) *reinterpret_cast<uint32_t *>(ve) = (uint32_t)m;
                         else *reinterpret_cast<unsigned long long *>(ve) = m;
                     }
+                };
+                if (EXACT) {
+                    for (int p0 = 0; p0 < npass; p0 += SLOTS) {
+                        const bool on = p0 + s < npass;
+                        const int e = eb + (int)plist[on ? p0 + s : p0];
+                        const int sa = (int)(((float)e + 0.5f) * inv_kj), sb = e - sa * kj;
+                        float acc = 0.f;
+                        int fails = 0;
+                        const int rowa = nci + sa * ni, rowb = ncj + sb * nj;
+                        for (int u = 0; u < ni; ++u) {
+                            const uint32_t ou = (uint32_t)((si + u) * 3 * C + cc);
+                            const float ux = xyz[ou], uy = xyz[ou + C], uz = xyz[ou + 2 * C];
+                            const uint32_t sidu = nc[rowa + u];
+                            for (int v = 0; v < nj; ++v) {
+                                const uint32_t ov = (uint32_t)((sj + v) * 3 * C + cc);
+                                const float d = norm3f(ux - xyz[ov], uy - xyz[ov + C], uz - xyz[ov + 2 * C]);
+                                item<EXACT, false>(p, sidu, nc[rowb + v], d, acc, fails, n_exact, n_exactv);
+                            }
+                        }
+                        finish_entry(e, on, acc, fails);
+                    }
+                    n_items += (uint32_t)(((npass + SLOTS - 1) / SLOTS) * ni * nj);
+                } else {
+                    // The (entry, node pair) items of the chunk as ONE list per slot - slot s takes the passing entries s, s + SLOTS, ...
+                    // and every entry its node pairs (u, v) in the reference's order (u outer) - walked PMX_ITEM_BATCH items at a
+                    // time: coordinates, distances and cell loads of a batch go out together, whichever entries they belong to,
+                    // then the values are added in order and an entry is written when its last pair is in. (With a batch per
+                    // entry, entries of one or three node pairs - single-node clusters: most of a large model's - spent half
+                    // of every batch on padding, and at 32 / 64 conformer lanes, one entry per pass, nothing overlapped at all.)
+                    constexpr int IB = PMX_ITEM_BATCH;
+                    const int npair = ni * nj;
+                    const int nround = (npass + SLOTS - 1) / SLOTS;
+                    const int total = nround * npair;
+                    int lk = 0, lu = 0, lv = 0; // next item to load: entry round, node pair
+                    int fk = 0, fr = 0;         // next item to finish: entry round, pair number
+                    int rowa = 0, rowb = 0;     // node-candidate rows of this slot's entry of round lk
+                    auto slot_entry = [&](int k, bool &on) {
+                        on = k * SLOTS + s < npass;
+                        return eb + (int)plist[on ? k * SLOTS + s : k * SLOTS];
+                    };
+                    auto decode = [&](int k) {
+                        bool on;
+                        const int e = slot_entry(k, on);
+                        const int sa = (int)(((float)e + 0.5f) * inv_kj), sb = e - sa * kj;
+                        rowa = nci + sa * ni, rowb = ncj + sb * nj;
+                    };
+                    decode(0);
+                    float acc = 0.f;
+                    int fails = 0;
+                    for (int t0 = 0; t0 < total; t0 += IB) {
+                        ItemLoad L[IB];
+#pragma unroll
+                        for (int q = 0; q < IB; ++q) {
+                            const bool in = t0 + q < total; // (an item past the end is the empty subset pair: value 0, never a fail)
+                            const uint32_t ou = (uint32_t)((si + lu) * 3 * C + cc), ov = (uint32_t)((sj + lv) * 3 * C + cc);
+                            const float d = norm3f(xyz[ou] - xyz[ov], xyz[ou + C] - xyz[ov + C], xyz[ou + 2 * C] - xyz[ov + 2 * C]);
+                            L[q] = item_load(p, in ? (uint32_t)nc[rowa + lu] : 0u, in ? (uint32_t)nc[rowb + lv] : 0u, d);
+                            if (++lv == nj) {
+                                lv = 0;
+                                if (++lu == ni) {
+                                    lu = 0;
+                                    if (++lk < nround) decode(lk);
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (int q = 0; q < IB; ++q) {
+                            if (t0 + q < total) {
+                                item_finish(p, L[q], acc, fails, n_exact);
+                                if (++fr == npair) {
+                                    bool on;
+                                    const int e = slot_entry(fk, on);
+                                    finish_entry(e, on, acc, fails);
+                                    fr = 0, ++fk;
+                                    acc = 0.f, fails = 0;
+                                }
+                            }
+                        }
+                    }
+                    n_items += (uint32_t)total;
                 }
                 lds_sync(); // (the list is rewritten by the next chunk)
             }

@@ -21,4 +21,5 @@ for it in range(2):
     s = model.screen(lib).scores
     torch.cuda.synchronize(); dt = time.time() - t0
     stt = engine.last_score_stats()
-    print(f"{dt*1e3:.1f} ms  {len(lib)*64/dt/1e6:.2f} M conf/s", {k: stt[k] for k in ("ms_ligand", "ms_tasks", "n_frames", "n_passes", "n_items", "n_slice_overflow", "n_heavy", "n_tasks", "max_passes", "arena_bytes")})
+    print(f"{dt*1e3:.1f} ms  {len(lib)*64/dt/1e6:.2f} M conf/s", {k: stt[k] for k in ("ms_ligand", "ms_tasks", "n_frames", "n_passes", "n_items", "n_slice_overflow", "n_heavy", "n_tasks", "max_passes", "arena_bytes", "n_probes", "n_probe_passes")},
+          {k: round(stt["ticks_" + k] / max(stt["ticks_alive"], 1), 3) for k in ("scan", "tables", "bounds", "walk")})
