@@ -1017,15 +1017,31 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
             ++w.frames;
             continue;
         }
-        // return max_num_matches + matched (tree.py:102) to the parent frame
+        // return max_num_matches + matched (tree.py:102) to the parent frame - and straight through every ancestor that has
+        // nothing left to do: its candidates are done and it needs no skip child (it was entered for one of its children, so a
+        // child existed: the skip child is due only while num_matches + max_num_matches < 5, tree.py:98). A third of the
+        // walker's iterations used to be such returns, each a full trip round the loop.
         ret = mx + ((flags & kMatched) ? 1 : 0);
-        --f;
-        if (f < f0) break;
-        {
-            const int pc = rl(w.stC, f);
-            const int pmx = (pc >> 8) & 255;
-            if (ret > pmx) w.stC = wl(w.stC, f, (pc & ~0xff00) | (ret << 8));
+        bool out = false;
+        for (;;) {
+            --f;
+            if (f < f0) {
+                out = true;
+                break;
+            }
+            int pc = rl(w.stC, f);
+            int pmx = (pc >> 8) & 255;
+            if (ret > pmx) {
+                pmx = ret;
+                pc = (pc & ~0xff00) | (ret << 8);
+                w.stC = wl(w.stC, f, pc);
+            }
+            if ((pc & 255) < (rl(w.hk, f) & 255)) break;                                        // candidates left
+            const int pfl = (pc >> 16) & 255, pnm = (pc >> 24) & 255;
+            if (!(pfl & (int)kSkipped) && pnm + pmx < 5) break;                                  // its skip child is due
+            ret = pmx + ((pfl & (int)kMatched) ? 1 : 0);
         }
+        if (out) break;
     }
     flush_dbg();
     return ret;
