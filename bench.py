@@ -31,6 +31,7 @@ REPO = Path(__file__).resolve().parent
 sys.path.insert(0, str(REPO))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s HBM3E spec
+PROFILE_TAG = "r4"  # the committed rocprofv3 --pmc summaries (profiles/<tag>_*.json) the static blocks of the line are read from
 
 
 def log(*a):
@@ -144,7 +145,7 @@ def cpu_baseline(model, offsets, data, n_conf, budget_s=15.0):
 def issue_block(n_lig, pass_ms):
     """Scalar / vector wave-instructions per ligand (committed SQ counters) against the CU's issue rates at this run's pass time."""
     try:
-        sq = json.loads((REPO / "profiles" / "r3_pmc_sq_summary.json").read_text())["counters"]
+        sq = json.loads((REPO / "profiles" / (PROFILE_TAG + "_pmc_sq_summary.json")).read_text())["counters"]
         salu = sum(v["SQ_INSTS_SALU"] for v in sq.values()) / (2 * 200704)
         valu = sum(v["SQ_INSTS_VALU"] for v in sq.values()) / (2 * 200704)
     except Exception:
@@ -154,7 +155,8 @@ def issue_block(n_lig, pass_ms):
     vector_ms = valu * n_lig * 2 / (4 * cus) / clock_hz * 1e3  # a wave64 VALU instruction holds one of 4 SIMD-32s for 2 cycles
     return {"scalar_insts_per_ligand": salu, "vector_insts_per_ligand": valu, "scalar_unit_busy": scalar_ms / pass_ms,
             "vector_units_busy": vector_ms / pass_ms, "pass_ms": pass_ms,
-            "note": "counts from profiles/r3_pmc_sq_summary.json (rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_VALU, 2 passes over 200704 ligands)"}
+            "from_profile": f"profiles/{PROFILE_TAG}_pmc_sq_summary.json",
+            "note": "instruction counts are NOT measured in this run: they come from the committed rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_VALU pass of the same build (bench.py --ligands 200000 --steps 1 --warmup 0: the timed step + the profiled pass = 2 passes over 200 704 ligands), priced at this run's pass time"}
 
 
 def main():
@@ -273,7 +275,7 @@ def main():
         # rocprofv3 --pmc and corrected as MI355X_MICROARCH.md prescribes), scaled to this launch's ligands
         traffic = None
         try:
-            pmc = json.loads((REPO / "profiles" / "r3_hbm_traffic.json").read_text())
+            pmc = json.loads((REPO / "profiles" / (PROFILE_TAG + "_hbm_traffic.json")).read_text())
             key = "ligand_kernel" if dominant.startswith("ligand_kernel") else "task_kernel"
             if args.conformers == 8 and len(pockets) == 1:
                 traffic = pmc["kernels"][key]["hbm_bytes_per_ligand"] * ligands_per_launch
@@ -311,7 +313,8 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "traffic_note": "HBM bytes per launch of that kernel from profiles/r3_hbm_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, read side doubled per MI355X_MICROARCH.md); null if unavailable",
+                "traffic_from_profile": f"profiles/{PROFILE_TAG}_hbm_traffic.json",
+                "traffic_note": "NOT measured in this run: HBM bytes per ligand of that kernel from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same build (separate runs, read side doubled per MI355X_MICROARCH.md), scaled to this launch's ligands; null if unavailable",
                 "algorithmic_bytes_per_ligand": alg_bytes_per_ligand,
                 "ligands_per_launch": ligands_per_launch,
                 "kernel_ms_per_launch": kernels,
@@ -321,11 +324,11 @@ def main():
                         "the CU's scalar instruction issue, see `issue` (DESIGN.md section 4).",
             },
             # The resource that is busiest on this path: the CU's scalar unit, one wave-instruction per cycle.
-            # Instruction counts per ligand from the committed PMC pass (profiles/r3_pmc_sq_summary.json: 200 704 ligands, the
+            # Instruction counts per ligand from the committed PMC pass (profiles/<tag>_pmc_sq_summary.json: 200 704 ligands, the
             # timed step + the profiled pass = 2 passes), priced at this run's time per pass.
             "issue": issue_block(n_lig, prof["ms_total"]) if (args.conformers == 8 and len(pockets) == 1) else None,
             # what the kernels do per ligand, and how that compares with the CU's issue rate (one VALU and one SALU wave-instruction
-            # per cycle and CU: MI355X_MICROARCH.md); instruction counts from profiles/r3_pmc_sq.json
+            # per cycle and CU: MI355X_MICROARCH.md); instruction counts from the committed PMC pass
             "work": {
                 "tree_frames_per_ligand": prof["n_frames"] / max(n_lig, 1),
                 "walker_passes_per_ligand": prof["n_passes"] / max(n_lig, 1),

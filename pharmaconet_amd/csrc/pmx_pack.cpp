@@ -7,12 +7,16 @@
 // Python container semantics in the reference (dict insertion order and LIFO popitem, `atom_indices` keys where an int
 // and a 1-tuple differ) - so that records are byte-identical to the ones extracted from the reference's own LigandGraph
 // (tests/test_library.py on 708 fixture molecules).
+#include <sys/mman.h>
+
 #include <algorithm>
 #include <atomic>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <thread>
 #include <utility>
 #include <vector>
@@ -77,6 +81,18 @@ struct Scratch {
     std::vector<Node> pool; // node objects with their vectors' capacity kept
     std::vector<int> node_dict[PMX_NUM_TYPES];
     std::vector<std::pair<int, std::vector<int>>> keys; // (is_tuple, atom indices as given) of node i
+    // Everything below stands in for the dicts / lists / sets the reference builds per molecule. Nothing is allocated per
+    // molecule once the vectors have grown to the largest molecule seen: the packer runs on every host core at once, and with
+    // some sixty small allocations per molecule the threads did not speed each other up at all (one to eight threads: 1.2x).
+    std::vector<int> grp_first[2], grp_last[2]; // per atom: first / last node of the functional group keyed by that atom (H-bond | hydrophobic)
+    std::vector<int> grp_next[2];               // per node: next member of its group list
+    std::vector<std::pair<int, int>> entries;   // index_to_node: (atom, node) in insertion order
+    std::vector<char> alive;
+    std::vector<int> where;                     // per atom: position in `entries`, -1 = absent
+    std::vector<int> members, group_index;
+    std::vector<int> cl_first, cl_last, cl_size, cl_next; // clusters as linked lists of nodes (cl_next per node)
+    std::vector<int> ctype, founder, order;
+    std::vector<char> in_cluster;
 };
 
 int64_t pack_one(const Mol &m, uint8_t *out, uint64_t cap) {
@@ -129,14 +145,19 @@ int64_t pack_one(const Mol &m, uint8_t *out, uint64_t cap) {
     }
     auto heavy_nbrs = [&](int atom) { return std::make_pair(m.nbr + m.nbr_off[atom], m.nbr + m.nbr_off[atom + 1]); };
 
-    // __group_nodes, functional groups (ligand.py:158-192): atoms bonded to the same single heavy neighbour
+    // __group_nodes, functional groups (ligand.py:158-192): atoms bonded to the same single heavy neighbour. (The reference keeps
+    // a dict heavy neighbour -> member list per kind; only lookups by key are made, so per-atom list heads do.)
     {
-        std::map<int, std::vector<int>> hbond_groups, hydrop_groups;
+        for (int k = 0; k < 2; ++k) {
+            S.grp_first[k].assign((size_t)m.n_atoms, -1);
+            S.grp_last[k].assign((size_t)m.n_atoms, -1);
+            S.grp_next[k].assign((size_t)n, -1);
+        }
         for (int i = 0; i < n; ++i) {
             Node &nd = nodes[i];
-            std::map<int, std::vector<int>> *groups;
-            if (nd.types & T_HBOND) groups = &hbond_groups;
-            else if (nd.types & T_HYDROPHOBIC) groups = &hydrop_groups;
+            int kind;
+            if (nd.types & T_HBOND) kind = 0;
+            else if (nd.types & T_HYDROPHOBIC) kind = 1;
             else continue;
             const int atom = nd.atoms[0];
             auto nb = heavy_nbrs(atom);
@@ -147,53 +168,57 @@ int64_t pack_one(const Mol &m, uint8_t *out, uint64_t cap) {
                     only = *q;
                 }
             if (count == 1) {
-                std::vector<int> &members = (*groups)[only];
-                for (int other : members) {
+                for (int other = S.grp_first[kind][only]; other >= 0; other = S.grp_next[kind][other]) {
                     group_add(nd, other);
                     group_add(nodes[other], i);
                 }
-                members.push_back(i);
+                if (S.grp_last[kind][only] >= 0) S.grp_next[kind][S.grp_last[kind][only]] = i;
+                else S.grp_first[kind][only] = i;
+                S.grp_last[kind][only] = i;
             }
         }
     }
     // __group_nodes, hydrophobic flood over carbon-carbon bonds (ligand.py:194-213). index_to_node is a dict built from
     // node_dict["Hydrophobic"]: a repeated key keeps its first position and takes the last value; popitem() is LIFO.
     {
-        std::vector<std::pair<int, int>> entries; // (atom, node), insertion order
-        std::vector<char> alive;
-        std::map<int, int> where;
+        std::vector<std::pair<int, int>> &entries = S.entries; // (atom, node), insertion order
+        std::vector<char> &alive = S.alive;
+        std::vector<int> &where = S.where;
+        entries.clear();
+        alive.clear();
+        where.assign((size_t)m.n_atoms, -1);
         for (int ni : node_dict[0]) {
             const int atom = nodes[ni].atoms[0];
-            auto it = where.find(atom);
-            if (it == where.end()) {
-                where.emplace(atom, (int)entries.size());
+            if (where[atom] < 0) {
+                where[atom] = (int)entries.size();
                 entries.emplace_back(atom, ni);
                 alive.push_back(1);
             } else {
-                entries[it->second].second = ni;
+                entries[where[atom]].second = ni;
             }
         }
         int last = (int)entries.size() - 1;
+        std::vector<int> &members = S.members, &group_index = S.group_index;
         for (;;) {
             while (last >= 0 && !alive[last]) --last;
             if (last < 0) break;
             const int start = entries[last].second;
             alive[last] = 0;
-            where.erase(entries[last].first);
-            std::vector<int> members;
+            where[entries[last].first] = -1;
+            members.clear();
             members.push_back(start);
             for (int g : nodes[start].group) members.push_back(g);
-            std::vector<int> group_index;
+            group_index.clear();
             for (int mi : members) group_index.push_back(nodes[mi].atoms[0]);
             for (size_t gi = 0; gi < group_index.size(); ++gi) { // grows while iterating
                 auto nb = heavy_nbrs(group_index[gi]);
                 for (const int32_t *q = nb.first; q != nb.second; ++q) {
                     if (m.z[*q] != 6) continue;
-                    auto it = where.find(*q);
-                    if (it == where.end()) continue;
-                    const int reached = entries[it->second].second;
-                    alive[it->second] = 0;
-                    where.erase(it);
+                    const int at = where[*q];
+                    if (at < 0) continue;
+                    const int reached = entries[at].second;
+                    alive[at] = 0;
+                    where[*q] = -1;
                     group_index.push_back(*q);
                     for (int mi : members) {
                         group_add(nodes[mi], reached);
@@ -204,20 +229,30 @@ int64_t pack_one(const Mol &m, uint8_t *out, uint64_t cap) {
             }
         }
     }
-    // __setup_cluster (ligand.py:215-259)
-    std::vector<std::vector<int>> clusters;
-    std::vector<int> ctype;
-    std::vector<int> founder(n, -1); // node -> cluster it founded
-    std::vector<char> in_cluster(n, 0);
+    // __setup_cluster (ligand.py:215-259); a cluster is a list of nodes in the order they joined
+    std::vector<int> &cl_first = S.cl_first, &cl_last = S.cl_last, &cl_size = S.cl_size, &cl_next = S.cl_next;
+    std::vector<int> &ctype = S.ctype, &founder = S.founder; // founder: node -> cluster it founded
+    std::vector<char> &in_cluster = S.in_cluster;
+    cl_first.clear(), cl_last.clear(), cl_size.clear(), ctype.clear();
+    cl_next.assign((size_t)n, -1);
+    founder.assign((size_t)n, -1);
+    in_cluster.assign((size_t)n, 0);
+    auto new_cluster = [&](int ni, int type) {
+        cl_first.push_back(ni), cl_last.push_back(ni), cl_size.push_back(1), ctype.push_back(type);
+        founder[ni] = (int)cl_first.size() - 1;
+    };
+    auto join_cluster = [&](int ci, int ni) {
+        cl_next[cl_last[ci]] = ni;
+        cl_last[ci] = ni;
+        ++cl_size[ci];
+    };
     const int high_types[4] = {1, 2, 3, 6}; // Aromatic, Cation, Anion, Halogen
     const int high_ctype[4] = {C_AROMATIC, C_CATION, C_ANION, C_HALOGEN};
     for (int h = 0; h < 4; ++h)
         for (int ni : node_dict[high_types[h]]) {
             if (in_cluster[ni]) continue;
             in_cluster[ni] = 1;
-            clusters.push_back({ni});
-            ctype.push_back(high_ctype[h]);
-            founder[ni] = (int)clusters.size() - 1;
+            new_cluster(ni, high_ctype[h]);
         }
     const int low_types[3] = {0, 4, 5}; // Hydrophobic, HBond_donor, HBond_acceptor
     for (int l = 0; l < 3; ++l)
@@ -227,33 +262,36 @@ int64_t pack_one(const Mol &m, uint8_t *out, uint64_t cap) {
             Node &nd = nodes[ni];
             bool add_new = true;
             if (nd.min_dependence >= 0 && founder[nd.min_dependence] >= 0) { // (the reference would raise KeyError otherwise)
-                clusters[founder[nd.min_dependence]].push_back(ni);
+                join_cluster(founder[nd.min_dependence], ni);
                 add_new = false;
             } else if (nd.min_dependence >= 0) {
                 return -2; // a node that depends on a node without a cluster: the reference's builder raises KeyError (ligand.py:238-241)
             } else {
                 for (int g : nd.group)
                     if (founder[g] >= 0) {
-                        clusters[founder[g]].push_back(ni);
+                        join_cluster(founder[g], ni);
                         add_new = false;
                         break;
                     }
             }
-            if (add_new) {
-                clusters.push_back({ni});
-                ctype.push_back(l == 0 ? C_HYDROPHOBIC : C_HBOND);
-                founder[ni] = (int)clusters.size() - 1;
-            }
+            if (add_new) new_cluster(ni, l == 0 ? C_HYDROPHOBIC : C_HBOND);
         }
     // pack_clustered_ligand: stable sort by priority_fn (graph_match.py:43-60), nodes renumbered cluster by cluster
-    const int ncl = (int)clusters.size();
-    std::vector<int> order(ncl);
+    const int ncl = (int)cl_first.size();
+    std::vector<int> &order = S.order;
+    order.resize((size_t)ncl);
     for (int i = 0; i < ncl; ++i) order[i] = i;
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
-        const int ka[4] = {kPriorityGroup[ctype[a]], -(int)clusters[a].size(), kPrioritySub[ctype[a]], nodes[clusters[a][0]].atoms[0]};
-        const int kb[4] = {kPriorityGroup[ctype[b]], -(int)clusters[b].size(), kPrioritySub[ctype[b]], nodes[clusters[b][0]].atoms[0]};
+    auto before = [&](int a, int b) {
+        const int ka[4] = {kPriorityGroup[ctype[a]], -cl_size[a], kPrioritySub[ctype[a]], nodes[cl_first[a]].atoms[0]};
+        const int kb[4] = {kPriorityGroup[ctype[b]], -cl_size[b], kPrioritySub[ctype[b]], nodes[cl_first[b]].atoms[0]};
         return std::lexicographical_compare(ka, ka + 4, kb, kb + 4);
-    });
+    };
+    for (int i = 1; i < ncl; ++i) { // stable insertion sort (std::stable_sort allocates a buffer per call)
+        const int x = order[i];
+        int j = i;
+        for (; j > 0 && before(x, order[j - 1]); --j) order[j] = order[j - 1];
+        order[j] = x;
+    }
     if (n > PMX_MAX_LIGAND_NODES || ncl > PMX_MAX_LIGAND_CLUSTERS || m.n_conf < 1 || m.n_conf > PMX_MAX_CONFORMERS) return 0;
     const int C = m.n_conf;
     const uint64_t head = 8 + (uint64_t)n + (uint64_t)ncl;
@@ -267,7 +305,7 @@ int64_t pack_one(const Mol &m, uint8_t *out, uint64_t cap) {
     float *xyz = reinterpret_cast<float *>(out + ((head + 3) & ~3ull));
     int pos = 0;
     for (int ci = 0; ci < ncl; ++ci) {
-        for (int ni : clusters[order[ci]]) {
+        for (int ni = cl_first[order[ci]]; ni >= 0; ni = cl_next[ni]) {
             const Node &nd = nodes[ni];
             tm[pos] = (uint8_t)nd.types;
             float *dst = xyz + (size_t)pos * 3 * C; // [3][C]
@@ -323,6 +361,53 @@ static bool valid_molecule(const pmx_feature_batch *b, uint64_t i, const Mol &m)
 static int pack_features_impl(const pmx_feature_batch *b, int threads, uint64_t *offsets_out, uint8_t *data_out, uint64_t data_cap,
                               uint64_t *data_bytes, int32_t *status_out);
 
+// One cached staging buffer per process (the call that finds it in use allocates its own and frees it afterwards).
+namespace {
+struct StagingCache {
+    std::mutex mu;
+    uint8_t *mem = nullptr;
+    size_t bytes = 0;
+    bool busy = false;
+};
+StagingCache g_staging;
+constexpr size_t kHuge = (size_t)2 << 20;
+uint8_t *huge_alloc(size_t bytes) {
+    const size_t rounded = (bytes + kHuge - 1) & ~(kHuge - 1);
+    void *p = nullptr;
+    if (posix_memalign(&p, kHuge, rounded) != 0) return nullptr;
+    (void)madvise(p, rounded, MADV_HUGEPAGE);
+    return static_cast<uint8_t *>(p);
+}
+struct StagingArea {
+    uint8_t *own = nullptr;
+    bool cached = false;
+    uint8_t *acquire(size_t bytes) {
+        {
+            std::lock_guard<std::mutex> lock(g_staging.mu);
+            if (!g_staging.busy) {
+                if (g_staging.bytes < bytes) {
+                    std::free(g_staging.mem);
+                    g_staging.mem = huge_alloc(bytes);
+                    g_staging.bytes = g_staging.mem ? bytes : 0;
+                }
+                if (g_staging.mem) {
+                    g_staging.busy = cached = true;
+                    return g_staging.mem;
+                }
+            }
+        }
+        return own = huge_alloc(bytes);
+    }
+    ~StagingArea() {
+        if (cached) {
+            std::lock_guard<std::mutex> lock(g_staging.mu);
+            g_staging.busy = false;
+        }
+        std::free(own);
+    }
+};
+} // namespace
+
 extern "C" int pmx_pack_features(const pmx_feature_batch *b, int threads, uint64_t *offsets_out, uint8_t *data_out, uint64_t data_cap,
                                  uint64_t *data_bytes, int32_t *status_out) {
     try { // no exception crosses the C boundary
@@ -352,9 +437,13 @@ static int pack_features_impl(const pmx_feature_batch *b, int threads, uint64_t 
         *data_bytes = room[n];
         return PMX_OK;
     }
-    std::unique_ptr<uint8_t[]> scratch_mem(new (std::nothrow) uint8_t[room[n] + 16]); // not zero-filled: pack_one clears what it writes
-    if (!scratch_mem) return pmx_topk_fail(PMX_ERR_OOM, "pmx_pack_features: out of host memory");
-    uint8_t *scratch = scratch_mem.get();
+    // The staging area (worst-case room per molecule; not zero-filled: pack_one clears what it writes). A million molecules take
+    // gigabytes of it, and what the packer used to spend its time on was not packing but first-touch page faults of a fresh
+    // allocation per call (no speed-up at all from 1 to 8 threads: they queue on the address space lock): the area is kept
+    // from call to call, 2 MB aligned and advised as huge pages (512 times fewer faults where the kernel grants them).
+    StagingArea staging;
+    uint8_t *scratch = staging.acquire(room[n] + 16);
+    if (!scratch) return pmx_topk_fail(PMX_ERR_OOM, "pmx_pack_features: out of host memory");
     std::vector<int64_t> sizes(n, 0);
     std::atomic<uint64_t> next{0}, bad_input{0};
     auto work = [&]() {

@@ -18,7 +18,7 @@ import os
 
 REPO = Path(__file__).resolve().parents[1]
 PROF = REPO / "profiles"
-TAG = os.environ.get("PMX_PROFILE_TAG", "r3")  # file name prefix: the round the profiles belong to
+TAG = os.environ.get("PMX_PROFILE_TAG", "r4")  # file name prefix: the round the profiles belong to
 
 
 def short(name):

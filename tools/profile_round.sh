@@ -3,10 +3,10 @@
 # round's build; tools/collect_profiles.py then turns them into the tracked summaries under profiles/.
 #   gpurun -- 'bash tools/profile_round.sh'
 # then, in the repository (gpurun merges gpurun_out/ back, not profiles/):
-#   O=gpurun_out/prof_r3; python tools/collect_profiles.py $O/bench.json $O/stats/*kernel_stats.csv $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_SQ 200704
+#   O=gpurun_out/prof_r4; PMX_PROFILE_TAG=r4 python tools/collect_profiles.py $O/bench.json $O/stats/*kernel_stats.csv $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_SQ 200704
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-OUT=$ROOT/gpurun_out/prof_r3
+OUT=$ROOT/gpurun_out/prof_r4
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python $ROOT/bench.py --steps 5 --warmup 2 > $OUT/bench.json 2> $OUT/bench.err
@@ -16,4 +16,5 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES --output-format csv -d $OUT/pmc_SQ -o p -- python $ROOT/bench.py --ligands 200000 --steps 1 --warmup 0 --no-cpu-baseline --no-serial-leg > $OUT/pmc_SQ.log 2>&1
 python $ROOT/bench.py --pockets 16 --ligands 200000 --steps 1 --warmup 1 --no-cpu-baseline --no-serial-leg > $OUT/bench_pockets16.json 2> $OUT/bench_pockets16.err
+python $ROOT/tools/stress_shape.py 196 > $OUT/stress64.log 2>&1
 ls -R $OUT | head -40
