@@ -184,6 +184,19 @@ typedef struct {
 int pmx_pack_features(const pmx_feature_batch *batch, int threads, uint64_t *offsets_out, uint8_t *data_out, uint64_t data_cap,
                       uint64_t *data_bytes, int32_t *status_out);
 
+/*
+ * Conformer coordinates of an SD file in native code: the coordinate half of Ligand.load_from_file
+ * (src/pmnet/scoring/ligand.py:63-84), which has OpenBabel build a molecule object per record and copies
+ * `[atom.coords for atom in pbmol.atoms]` in a Python loop after removeh(). The features come from the first record alone
+ * (ligand.py:78-84), so the further records only contribute heavy-atom coordinates: element and float32 position of every
+ * atom that is not a hydrogen (H, D, T), in file order, record after record (MDL molfile V2000 and V3000, records separated
+ * by $$$$). `text` / `len`: the file's bytes. max_records: records to read (num_conformers; 0 = all). With atomic_num ==
+ * NULL and xyz == NULL the call only counts (*n_records, *n_atoms). A record that cannot be parsed fails the call with
+ * PMX_ERR_INVALID and leaves its index in *n_records.
+ */
+int pmx_sdf_heavy_atoms(const char *text, uint64_t len, uint64_t max_records, uint64_t cap_records, uint64_t cap_atoms,
+                        uint64_t *n_records, uint64_t *n_atoms, int32_t *atoms_per_record, uint8_t *atomic_num, float *xyz);
+
 /* Frees the scoring workspaces libpmx keeps between calls on `device` (synchronises the device first). */
 int pmx_release_workspaces(int device);
 

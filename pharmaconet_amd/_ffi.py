@@ -119,6 +119,11 @@ SIGNATURES = {
         ctypes.c_int,
         [ctypes.POINTER(FeatureBatch), ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64), ctypes.c_void_p],
     ),
+    "pmx_sdf_heavy_atoms": (
+        ctypes.c_int,
+        [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64),
+         ctypes.POINTER(ctypes.c_uint64), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p],
+    ),
     "pmx_score_stats_get": (ctypes.c_int, [ctypes.POINTER(ScoreStats)]),
     "pmx_set_profiling": (ctypes.c_int, [ctypes.c_int]),
 }
@@ -157,14 +162,15 @@ _pack_lib: ctypes.CDLL | None = None
 
 
 def load_packer() -> ctypes.CDLL:
-    """libpmx_pack.so: `pmx_pack_features` alone, for host processes that pack libraries (no torch, no HIP runtime)."""
+    """libpmx_pack.so: `pmx_pack_features` and the SD-file coordinate reader alone, for host processes that read and pack
+    libraries (no torch, no HIP runtime)."""
     global _pack_lib
     if _pack_lib is None:
         path = LIB_PATH.with_name("libpmx_pack.so")
         if not path.exists():
             raise PmxError(f"{path} is missing: build with `python -m pharmaconet_amd.build`")
         lib = ctypes.CDLL(str(path))
-        for name in ("pmx_pack_features", "pmx_last_error", "pmx_version"):
+        for name in ("pmx_pack_features", "pmx_sdf_heavy_atoms", "pmx_last_error", "pmx_version"):
             restype, argtypes = SIGNATURES[name]
             fn = getattr(lib, name)
             fn.restype = restype

@@ -41,6 +41,12 @@ def _openbabel():
     return pybel, ob
 
 
+def _ffi_error():
+    from ._ffi import PmxError
+
+    return PmxError
+
+
 def _neighbors(ob, atom):
     return list(ob.OBAtomAtomIter(atom))
 
@@ -142,6 +148,17 @@ class Ligand:
         if num_conformers is not None:
             assert num_conformers > 0
             reader = itertools.islice(reader, num_conformers)
+        if extension == ".sdf":
+            # Features come from the first record alone; of the others only heavy-atom coordinates are used. Those are read by the
+            # native SD reader (csrc/pmx_sdf.cpp) instead of one toolkit molecule + a Python loop over its atoms per record.
+            # Anything it does not accept - or records that disagree with the toolkit's view of the first one - goes the
+            # reference's way below.
+            fast = cls._from_sdf_fast(reader, filename, num_conformers)
+            if fast is not None:
+                return fast
+            reader = pybel.readfile(extension[1:], str(filename))
+            if num_conformers is not None:
+                reader = itertools.islice(reader, num_conformers)
         mols = list(reader)
         base = mols[0]
         base.removeh()
@@ -152,6 +169,22 @@ class Ligand:
             assert len(mol.atoms) == num_atoms
             positions.append([atom.coords for atom in mol.atoms])
         return cls(base, [np.asarray(p, dtype=np.float32) for p in positions], _unsafe=True)
+
+    @classmethod
+    def _from_sdf_fast(cls, reader, filename, num_conformers):
+        from .sdf import SdfError, conformer_positions
+
+        try:
+            z, pos = conformer_positions(filename, num_conformers)
+        except (SdfError, OSError, _ffi_error()):
+            return None
+        base = next(iter(reader), None)
+        if base is None:
+            return None
+        base.removeh()
+        if len(base.atoms) != len(z) or [a.GetAtomicNum() for a in _openbabel()[1].OBMolAtomIter(base.OBMol)] != [int(x) for x in z]:
+            return None
+        return cls(base, pos, conformer_axis=1, _unsafe=True)
 
     @classmethod
     def load_from_smiles(cls, smiles: str, num_conformers: int) -> "Ligand":

@@ -150,10 +150,55 @@ class Molecule:
         return [_PybelAtom(xyz[a._i] if a._i < heavy else xyz[self.OBMol._adj[a._i][0]]) for a in self.OBMol._atoms]
 
 
+SDF_DESCRIPTION_TAG = "pmx_description"
+
+
+def write_sdf(desc, path, extra_hydrogens=0, crlf=False):
+    """The described molecule as a real multi-record SD file (V2000): one record per conformer, heavy atoms in description
+    order with `extra_hydrogens` explicit hydrogens mixed into every atom block, and - as a data item of every record - the
+    description itself, which is all this stand-in can perceive chemistry from (`readfile` below). The atom blocks are what
+    pharmaconet_amd's native SD reader takes the coordinates from. Coordinates are written with four decimals, as SD files
+    hold them."""
+    eol = "\r\n" if crlf else "\n"
+    sym = {1: "H", 5: "B", 6: "C", 7: "N", 8: "O", 9: "F", 15: "P", 16: "S", 17: "Cl", 35: "Br", 53: "I"}
+    out = []
+    n = len(desc["z"])
+    for c, xyz in enumerate(desc["coords"]):
+        lines = [f"mol conformer {c}", "  fake_openbabel", ""]
+        atoms = [(sym[int(z)], xyz[i]) for i, z in enumerate(desc["z"])]
+        for h in range(extra_hydrogens):  # hydrogens anywhere in the block: removeh() / the native reader drop them
+            at = (h * 7 + c) % (len(atoms) + 1)
+            x, y, zc = xyz[(h * 3) % n]
+            atoms.insert(at, ("H", (x + 0.6, y - 0.4, zc + 0.3)))
+        bonds = desc["bonds"]
+        lines.append(f"{len(atoms):3d}{0:3d}  0  0  0  0  0  0  0  0999 V2000")
+        for s_, (x, y, zc) in atoms:
+            lines.append(f"{x:10.4f}{y:10.4f}{zc:10.4f} {s_:<3s} 0  0  0  0  0  0  0  0  0  0  0  0")
+        lines.append("M  END")
+        lines.append(f">  <{SDF_DESCRIPTION_TAG}>")
+        lines.append(json.dumps(desc))
+        lines.append("")
+        lines.append("$$$$")
+        out.append(eol.join(lines) + eol)
+    with open(path, "w", newline="") as f:
+        f.write("".join(out))
+
+
 def readfile(fmt, filename):
-    """A 'file' is the JSON of a description: every conformer becomes one record, as in a multi-record SDF."""
+    """A 'file' is the JSON of a description - every conformer becomes one record, as in a multi-record SDF - or a real SD
+    file written by `write_sdf`, whose records carry the description as a data item (the stand-in perceives nothing from
+    atom blocks; it reads the record count and the description)."""
     with open(filename) as f:
-        desc = json.load(f)
+        text = f.read()
+    try:
+        desc = json.loads(text)
+    except json.JSONDecodeError:
+        records = [r for r in text.replace("\r\n", "\n").split("$$$$\n") if r.strip()]
+        tag = f">  <{SDF_DESCRIPTION_TAG}>\n"
+        desc = json.loads(records[0].split(tag, 1)[1].split("\n", 1)[0])
+        for c in range(len(records)):
+            yield Molecule(desc, c)
+        return
     for c in range(len(desc["coords"])):
         yield Molecule(desc, c)
 
