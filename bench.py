@@ -74,8 +74,9 @@ def end_to_end(molecules, lib, data, ms_per_step, n_conf_total):
 
     from pharmaconet_amd.library import flatten_features, pack_features_native
 
-    cores = os.cpu_count() or 1
-    reps = max(1, 65536 // max(len(molecules), 1))
+    # (the packer is memory-bound beyond some 64 threads on the 256-core host: 14.0e6 ligands/s at 64, 11.3e6 at 256 [MI355X box])
+    cores = min(os.cpu_count() or 1, 64)
+    reps = max(1, 262144 // max(len(molecules), 1))
     flat = flatten_features(molecules * reps)
     pack_features_native(flat, threads=cores)  # warm
     t0 = time.perf_counter()
