@@ -79,9 +79,12 @@ def end_to_end(molecules, lib, data, ms_per_step, n_conf_total):
     reps = max(1, 262144 // max(len(molecules), 1))
     flat = flatten_features(molecules * reps)
     pack_features_native(flat, threads=cores)  # warm
-    t0 = time.perf_counter()
-    packed, _ = pack_features_native(flat, threads=cores)
-    pack_rate = len(packed) / (time.perf_counter() - t0)
+    pack_s = 1e9
+    for _ in range(3):  # best of three (the host is shared with whatever else the box runs)
+        t0 = time.perf_counter()
+        packed, _ = pack_features_native(flat, threads=cores)
+        pack_s = min(pack_s, time.perf_counter() - t0)
+    pack_rate = len(packed) / pack_s
     host = torch.empty(data.numel(), dtype=torch.uint8).pin_memory()
     host.copy_(data)
     torch.cuda.synchronize()

@@ -107,15 +107,22 @@ int pmx_library_destroy(pmx_library *lib);
  * (graph_match.py:32-40,81-83) in type-id order. scores_dev[count] receives the float32 value
  * of the float the reference returns (0 for ligands without clusters or candidates,
  * graph_match.py:95-99); status_dev[count] (may be NULL) receives PMX_LIGAND_*.
- * Everything is enqueued on `stream` and the call returns: no device-to-host read, no synchronisation, no helper thread
- * (a synchronisation happens only when a cached work buffer has to grow). Per super-chunk of ligands (PMX_SUPER): the
- * ligand kernel (score tables in per-wavefront slices + tree search within a pass budget), the same for ligands with
- * larger tables, a fixed number of task rounds for the subtrees of over-budget trees, finalize.
+ * Everything is enqueued and the call returns: no device-to-host read, no synchronisation, no helper thread (a
+ * synchronisation happens only when a cached work buffer has to grow). The work is ordered on `stream`: per chunk of ligands
+ * (PMX_SUPER) the ligand kernel (score tables in per-wavefront slices + tree search within a pass budget), the same for
+ * ligands with larger tables, a fixed number of task rounds for the subtrees of over-budget trees, finalize. With more than
+ * one chunk the rounds of a chunk run on a side stream that the workspace owns, beside the next chunk's ligand kernel: they
+ * start behind an event recorded on `stream` and `stream` waits for their last event before the call's work counts as done,
+ * so a caller sees one stream-ordered operation. Work buffers are kept per (device, stream), about 40 GB at the defaults
+ * (PMX_ARENA_MB, PMX_TASKQ_MB: per buffer set, two sets); the table arenas shrink when device memory is short - a smaller
+ * arena is slower, never wrong. PMX_LIGAND_TOO_LARGE is reported for a ligand whose tables exceed a whole arena; a ligand
+ * that merely found the arena full of other ligands' tables is taken again with the arena empty.
  */
 int pmx_score(const pmx_model *model, const pmx_library *lib, const float weights[PMX_NUM_TYPES], uint64_t first,
               uint64_t count, float *scores_dev, int32_t *status_dev, void *stream);
 
-/* The same for several models over one library, one pocket after the other on `stream`;
+/* The same for several models over one library: the pockets' chunks are one sequence of one call (one pocket after the other
+ * on `stream` by default; PMX_OVERLAP=2 lets a pocket's last task rounds run beside the next pocket's ligand kernel);
  * scores_dev is [n_models][count], status_dev[count] is written once. */
 int pmx_score_multi(const pmx_model *const *models, int n_models, const pmx_library *lib,
                     const float weights[PMX_NUM_TYPES], uint64_t first, uint64_t count, float *scores_dev,
@@ -213,7 +220,7 @@ typedef struct {
     uint64_t n_items;           /* table phase: (table entry, ligand node pair) evaluations per wavefront, i.e. / (64 / G) slots */
     uint64_t n_exact_cells;     /* items whose 2-sigma majority test was counted term by term (pass set not an interval), per lane */
     uint64_t n_heavy;           /* walks that ran over their budget (ligands and queued subtrees) */
-    uint64_t n_tasks;           /* subtrees taken from the task queue */
+    uint64_t n_tasks;           /* subtrees taken from the task queue (the empty records that pad a shard's end included) */
     uint64_t n_exported;        /* subtree records written to the task queue */
     uint64_t n_slice_overflow;  /* ligands whose tables did not fit a per-wavefront slice */
     uint64_t n_probes, n_probe_passes; /* reachability searches: subtrees below 5 matches that are handed over, or dropped by the bound test */

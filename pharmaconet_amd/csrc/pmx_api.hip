@@ -703,10 +703,18 @@ static int score_screen(const pmx_model *const *models, int n_models, const pmx_
     for (const PocketPlan &pl : plan) n_chunks += (count + pl.super - 1) / pl.super;
     // The rounds go to the side stream when there is something to run them next to. (Not when an arena pass may have to be
     // retried: the retry's ligand kernels use the large slices, as the next chunk's do.)
-    // [MI355X]: 4 M ligands of the bench library in 4 chunks 797 ms against 822 ms back to back; 16 pockets x 200 704 ligands
-    // 3.79 s against 3.70 s - successive pockets differ too much in what their two phases cost for a fixed split of the wave
-    // slots - so the default is: beside each other within a pocket, one after the other across pockets.
-    const bool overlap = n_chunks >= 2 && !retry_possible && env_long("PMX_OVERLAP", n_models == 1 ? 1 : 0) != 0;
+    // [MI355X]: 4 M ligands of the bench library in 4 chunks 797 ms against 822 ms back to back, 12.5 M in 12 chunks 2.39 s against
+    // 2.47 s; 16 pockets x 200 704 ligands with one pocket's rounds beside the next pocket's ligand kernel 3.79 s against 3.70 s -
+    // successive pockets differ too much in what their two phases cost for a fixed split of the wave slots. So PMX_OVERLAP = 1
+    // (default): beside each other within a pocket, one after the other across pockets; 2: across pockets as well; 0: never.
+    // And only chunks of half a million ligands or more (the 6OIM-like model's are 1 M): every chunk ends in a dozen rounds with
+    // a tail each, which half the wave slots stretch; 16 pockets at 1 253 376 ligands each in chunks of 80-260 k: 24.5 s with the
+    // rounds beside the next chunk of the same pocket, 22.2 s back to back.
+    const long overlap_mode = env_long("PMX_OVERLAP", 1);
+    uint32_t super_min = ~0u;
+    for (const PocketPlan &pl : plan) super_min = std::min(super_min, pl.super);
+    const bool overlap = n_chunks >= 2 && !retry_possible && overlap_mode != 0 && (overlap_mode >= 2 || super_min >= (1u << 19));
+    const bool overlap_pockets = overlap_mode >= 2;
     hipStream_t side = overlap ? ws.side : stream;
     const double lig_share = std::min(0.9, std::max(0.1, std::atof(std::getenv("PMX_LIG_SHARE") ? std::getenv("PMX_LIG_SHARE") : "0.5")));
 
@@ -721,7 +729,9 @@ static int score_screen(const pmx_model *const *models, int n_models, const pmx_
         const uint32_t full = pl.waves_per_cu;
         const uint32_t lig_waves = std::min(full - 1, std::max(1u, (uint32_t)(full * lig_share + 0.5)));
         for (uint64_t lo = 0; lo < count; lo += super, ++seq) {
-            const bool first_chunk = seq == 0, last_chunk = seq + 1 == n_chunks;
+            const bool last_of_call = seq + 1 == n_chunks;
+            // a chunk that has the device to itself: the call's first / last, or (by default) a pocket's first / last
+            const bool first_chunk = seq == 0 || (!overlap_pockets && lo == 0), last_chunk = last_of_call || (!overlap_pockets && lo + super >= count);
             ChunkSet &c = ws.set[seq & 1];
             const int ci = (int)(seq & 1);
             p.lo = (uint32_t)lo;
@@ -738,7 +748,9 @@ static int score_screen(const pmx_model *const *models, int n_models, const pmx_
             p.totbuf = ws.totbuf;
             // this set's last chunk (two chunks ago) has to be through its rounds
             if (overlap && c.pending) HIPCHECK(hipStreamWaitEvent(stream, c.tasks_done, 0));
-            if (g_profiling && last_chunk) HIPCHECK(hipEventRecord(ws.ev[1], stream));
+            if (overlap && !overlap_pockets && lo == 0 && seq > 0 && ws.set[(seq - 1) & 1].pending) // (the rounds of the pocket before)
+                HIPCHECK(hipStreamWaitEvent(stream, ws.set[(seq - 1) & 1].tasks_done, 0));
+            if (g_profiling && last_of_call) HIPCHECK(hipEventRecord(ws.ev[1], stream));
             ws.ligands_last = p.hi - p.lo;
             ctl_clear_kernel<<<dim3((sizeof(Ctl) / 4 + 255) / 256), dim3(256), 0, stream>>>(c.ctl, ws.ctl_used[ci] ? 0 : 1);
             ws.ctl_used[ci] = true;
@@ -765,12 +777,12 @@ static int score_screen(const pmx_model *const *models, int n_models, const pmx_
             p.retry_out = c.lists;
             p.retry_slot = 0;
             launch(2, std::min(pl.big_grid, lig_grid), stream);
-            if (g_profiling && last_chunk) HIPCHECK(hipEventRecord(ws.ev[2], stream));
+            if (g_profiling && last_of_call) HIPCHECK(hipEventRecord(ws.ev[2], stream));
             if (overlap) {
                 HIPCHECK(hipEventRecord(c.lig_done, stream));
                 HIPCHECK(hipStreamWaitEvent(side, c.lig_done, 0));
             }
-            if (g_profiling && last_chunk) HIPCHECK(hipEventRecord(ws.ev[4], side));
+            if (g_profiling && last_of_call) HIPCHECK(hipEventRecord(ws.ev[4], side));
             // the subtrees the over-budget walkers queued, and the ones those queue in turn: a fixed number of rounds, each a snapshot of
             // the queue and one persistent launch (an empty round exits at once); the last round walks everything to its end
             if (!totals_in_lds<G>()) p.totbuf = ws.totbuf + ws.totbuf_bytes / 2;
@@ -802,7 +814,7 @@ static int score_screen(const pmx_model *const *models, int n_models, const pmx_
                 }
                 p.retry_in = nullptr;
             }
-            if (g_profiling && last_chunk) HIPCHECK(hipEventRecord(ws.ev[5], side));
+            if (g_profiling && last_of_call) HIPCHECK(hipEventRecord(ws.ev[5], side));
             if (overlap) {
                 HIPCHECK(hipEventRecord(c.tasks_done, side));
                 c.pending = true;

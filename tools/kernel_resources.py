@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-kernel register / scratch / LDS table from the gfx950 code object of libpmx.
 
-    python tools/kernel_resources.py [--out profiles/r3_kernel_resources.json]
+    python tools/kernel_resources.py [--out profiles/r4_kernel_resources.json]
 
 Compiles csrc/pmx_api.hip device-only with the build's flags, unbundles the gfx950 code object and reads the
 AMDGPU metadata notes (llvm-readelf --notes)."""
