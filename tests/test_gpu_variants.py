@@ -350,7 +350,7 @@ def test_stress_config_at_full_size(oracle, monkeypatch):
         "zero_vs_nonzero_changes": int(((half > 0) != (f32 > 0)).sum()),
     }
     # PMX_WRITE_PROFILES names the directory the report goes to (gpurun_out/ on the GPU box, copied to profiles/ afterwards)
-    target = os.path.join(os.environ["PMX_WRITE_PROFILES"], "r2_fp16_sweep.json") if os.environ.get("PMX_WRITE_PROFILES") else tempfile.mktemp(suffix=".json")
+    target = os.path.join(os.environ["PMX_WRITE_PROFILES"], "r4_fp16_sweep.json") if os.environ.get("PMX_WRITE_PROFILES") else tempfile.mktemp(suffix=".json")
     with open(target, "w") as fh:
         json.dump(report, fh, indent=1)
     print(json.dumps(report))
