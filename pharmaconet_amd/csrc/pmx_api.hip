@@ -525,6 +525,8 @@ struct ScreenWs {
     size_t big_bytes = 0;
     uint8_t *totbuf = nullptr;
     size_t totbuf_bytes = 0;
+    uint8_t *pabuf = nullptr; // path_bound()'s pair sums: ligand kernel's wavefronts | task kernel's
+    size_t pabuf_bytes = 0;
     int num_cu = 0;
     hipStream_t side = nullptr; // the task rounds' stream
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // profiling: call start | last chunk: ligand kernels start, done | end | last chunk: rounds start, done
@@ -541,10 +543,10 @@ struct ScreenWs {
                 if (e) (void)hipEventDestroy(e);
             c = ChunkSet{};
         }
-        for (void *q : {(void *)slices, (void *)big, (void *)totbuf})
+        for (void *q : {(void *)slices, (void *)big, (void *)totbuf, (void *)pabuf})
             if (q) (void)hipFree(q);
-        slices = big = totbuf = nullptr;
-        slices_bytes = big_bytes = totbuf_bytes = 0;
+        slices = big = totbuf = pabuf = nullptr;
+        slices_bytes = big_bytes = totbuf_bytes = pabuf_bytes = 0;
         for (auto &e : ev) {
             if (e) (void)hipEventDestroy(e);
             e = nullptr;
@@ -600,6 +602,7 @@ struct PocketPlan {
     uint32_t slice_bytes = 0, big_bytes = 0, big_grid = 0;
     uint64_t worst_bytes = 0;
     uint32_t super = 0;
+    uint32_t pa_bytes = 0; // path_bound()'s buffer per wavefront
 };
 
 template <int G>
@@ -627,7 +630,7 @@ static int score_screen(const pmx_model *const *models, int n_models, const pmx_
 
     // ---- per pocket: parameters and launch shapes
     std::vector<PocketPlan> plan((size_t)n_models);
-    size_t slices_need = 0, big_need = 0, totbuf_need = 0;
+    size_t slices_need = 0, big_need = 0, totbuf_need = 0, pabuf_need = 0;
     uint32_t super_max = 0;
     bool retry_possible = false;
     for (int m = 0; m < n_models; ++m) {
@@ -654,10 +657,10 @@ static int score_screen(const pmx_model *const *models, int n_models, const pmx_
         pl.lds = shape.bytes;
         pl.waves_per_cu = (uint32_t)std::max<long>(2, std::min<long>({(long)(kLdsPerCu / shape.bytes), 4L * PMX_SCREEN_WAVES, env_long("PMX_WAVES_PER_CU", 32)}));
         const uint32_t grid = (uint32_t)ws.num_cu * pl.waves_per_cu;
-        // per-wavefront slice: 80 KB at 8 conformer lanes (every ligand of the bench library fits), scaled with the lanes
+        // per-wavefront slice: 112 KB at 8 conformer lanes (every ligand of the bench library fits, path_bound()'s table included), scaled with the lanes
         // (table bytes grow with the square of the model's cluster count: the 11-cluster 6OIM-like model is the reference point)
         const long k_scale = std::max(1L, std::min(16L, ((long)model->dm.K * model->dm.K + 60) / 121));
-        pl.slice_bytes = (uint32_t)std::max<long>(4, env_long("PMX_SLICE_KB", 80L * std::max(1, G / 8) * k_scale)) * 1024u;
+        pl.slice_bytes = (uint32_t)std::max<long>(4, env_long("PMX_SLICE_KB", (cand_bounds<G>() ? 112L : 80L) * std::max(1, G / 8) * k_scale)) * 1024u;
         slices_need = std::max(slices_need, (size_t)grid * pl.slice_bytes);
         // large slices for the ligands whose tables exceed a slice: as large as a table of this model and library can get, at most
         // PMX_BIG_SLICE_MB each, PMX_BIG_TOTAL_MB together (what is larger still goes to the arena)
@@ -672,6 +675,12 @@ static int score_screen(const pmx_model *const *models, int n_models, const pmx_
             pl.big_grid = (uint32_t)std::max<uint64_t>(16, std::min<uint64_t>(grid, total / pl.big_bytes));
         }
         big_need = std::max(big_need, (size_t)pl.big_grid * pl.big_bytes);
+        if (cand_bounds<G>()) { // float[matches <= levels][candidates of all levels][G], at most 1 MB per wavefront (larger jobs do without)
+            const uint64_t nlmax = (uint64_t)std::min<int>(PMX_MAX_LEVELS, std::max(1, lib->info.max_clusters));
+            const uint64_t need = (nlmax + 1) * nlmax * (uint64_t)std::max(1, model->dm.K) * G * 4;
+            pl.pa_bytes = (uint32_t)std::min<uint64_t>((need + 255) & ~255ull, 1u << 20);
+            pabuf_need = std::max(pabuf_need, (size_t)grid * pl.pa_bytes * 2u); // ligand kernel | task kernel
+        }
         retry_possible = retry_possible || pl.worst_bytes > pl.big_bytes;
         if (!totals_in_lds<G>()) totbuf_need = (size_t)ws.num_cu * 4u * std::max(PMX_SCREEN_WAVES, PMX_TASK_WAVES) * kTotBufBytes * 2u; // ligand kernel | task kernel
         // chunk: what the arena has to hold at a time are the tables of the chunk's split trees. (Cutting a pocket's pass into more
@@ -687,6 +696,10 @@ static int score_screen(const pmx_model *const *models, int n_models, const pmx_
     if (rc) return rc;
     if (totbuf_need) {
         rc = grow(&ws.totbuf, &ws.totbuf_bytes, totbuf_need, stream, ws.side);
+        if (rc) return rc;
+    }
+    if (pabuf_need) {
+        rc = grow(&ws.pabuf, &ws.pabuf_bytes, pabuf_need, stream, ws.side);
         if (rc) return rc;
     }
     for (ChunkSet &c : ws.set) {
@@ -746,6 +759,8 @@ static int score_screen(const pmx_model *const *models, int n_models, const pmx_
             p.queue = c.queue;
             p.qcap = (uint32_t)std::min<size_t>(c.queue_bytes / task_rec_bytes<G>() / kShards, 0x3fffffffu / kShards);
             p.totbuf = ws.totbuf;
+            p.pabuf = ws.pabuf;
+            p.pa_bytes = pl.pa_bytes;
             // this set's last chunk (two chunks ago) has to be through its rounds
             if (overlap && c.pending) HIPCHECK(hipStreamWaitEvent(stream, c.tasks_done, 0));
             if (overlap && !overlap_pockets && lo == 0 && seq > 0 && ws.set[(seq - 1) & 1].pending) // (the rounds of the pocket before)
@@ -786,6 +801,7 @@ static int score_screen(const pmx_model *const *models, int n_models, const pmx_
             // the subtrees the over-budget walkers queued, and the ones those queue in turn: a fixed number of rounds, each a snapshot of
             // the queue and one persistent launch (an empty round exits at once); the last round walks everything to its end
             if (!totals_in_lds<G>()) p.totbuf = ws.totbuf + ws.totbuf_bytes / 2;
+            if (ws.pabuf) p.pabuf = ws.pabuf + ws.pabuf_bytes / 2;
             auto rounds_and_finalize = [&]() {
                 p.budget = task_budget;
                 for (int r = 0; r < rounds; ++r) {
@@ -808,8 +824,10 @@ static int score_screen(const pmx_model *const *models, int n_models, const pmx_
                     p.retry_out = t == 0 ? c.lists + super : nullptr;
                     p.retry_slot = (uint32_t)(t + 1) & 1u;
                     p.totbuf = ws.totbuf;
+                    p.pabuf = ws.pabuf;
                     launch(3, std::min(pl.big_grid, lig_grid), side);
                     if (!totals_in_lds<G>()) p.totbuf = ws.totbuf + ws.totbuf_bytes / 2;
+                    if (ws.pabuf) p.pabuf = ws.pabuf + ws.pabuf_bytes / 2;
                     rounds_and_finalize();
                 }
                 p.retry_in = nullptr;
@@ -863,7 +881,9 @@ static int screen_stats(pmx_score_stats *out) {
     out->n_probe_passes = st[15];
     out->n_exported = st[14];
     out->n_exact_values = st[13];
-    for (int i = 0; i < 8; ++i) out->dbg[i] = st[16 + i];
+    for (int i = 0; i < 6; ++i) out->dbg[i] = st[16 + i];
+    out->n_path_bounds = st[22];
+    out->n_path_drops = st[23];
     out->ticks_scan = st[8], out->ticks_tables = st[9], out->ticks_bounds = st[10], out->ticks_walk = st[11], out->ticks_alive = st[12];
     out->ligands_last = w->ligands_last;
     if (w->ev_valid) {

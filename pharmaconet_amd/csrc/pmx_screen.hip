@@ -60,6 +60,10 @@ struct FnTable {
 
 // Header of one ligand's tables, in a wave's slice or in the arena:
 //   [RecHeader][best u64[G]][S float[ksumtot][G]][P float[T][G]][R double[nl + 1][G]][W double[ksumtot][G]][V mask[T]]
+//   [OB float[nl][ksumtot][G]][CI u32[ksumtot]]                                   (where per-candidate bounds exist)
+// OB[f][x] for a candidate x = (l, b') of a level l > f: S[l][b'] + sum_{f < j < l} max(0, max_a P[(j, a), (l, b')]), rounded up - what
+// (l, b') can add to a leaf total apart from its pair entries with the matches on the path down to level f (path_bound()).
+// CI[x] = l | k_l << 8 | ksum[l] << 16.
 // V[e] = the conformers c with P[e][c] > 0 (one bit per conformer, max(G, 8) / 8 bytes per entry): what decides which
 // children of a tree node exist (tree.py:78-84), read with the lanes spread over candidates.
 // Pair entry ((i, a), (j, b)), i < j: rowbase[i] + k[i] * (ksum[j] - ksum[i + 1]) + a * k[j] + b.
@@ -107,9 +111,18 @@ __host__ __device__ inline uint32_t rec_v_off(uint32_t ksumtot, uint32_t T, uint
     return rec_w_off<G>(ksumtot, T, nl) + (cand_bounds<G>() ? ksumtot * G * 8u : 0u);
 }
 template <int G>
+__host__ __device__ inline uint32_t rec_ob_off(uint32_t ksumtot, uint32_t T, uint32_t nl) {
+    return rec_v_off<G>(ksumtot, T, nl) + (uint32_t)round16((uint64_t)T * vmask_bytes<G>());
+}
+template <int G>
+__host__ __device__ inline uint32_t rec_ci_off(uint32_t ksumtot, uint32_t T, uint32_t nl) {
+    return rec_ob_off<G>(ksumtot, T, nl) + (cand_bounds<G>() ? nl * ksumtot * G * 4u : 0u);
+}
+template <int G>
 __host__ __device__ inline uint64_t rec_bytes(uint32_t ksumtot, uint32_t T, uint32_t nl) {
     return (uint64_t)rec_s_off<G>() + round16((uint64_t)ksumtot * G * 4) + round16((uint64_t)T * G * 4) + (uint64_t)(nl + 1) * G * 8 +
-           (cand_bounds<G>() ? (uint64_t)ksumtot * G * 8 : 0ull) + round16((uint64_t)T * vmask_bytes<G>());
+           (cand_bounds<G>() ? (uint64_t)ksumtot * G * 8 : 0ull) + round16((uint64_t)T * vmask_bytes<G>()) +
+           (cand_bounds<G>() ? (uint64_t)nl * ksumtot * G * 4 + round16((uint64_t)ksumtot * 4) : 0ull);
 }
 
 // A subtree handed to the task queue: its root has >= 5 matches (see walk()).
@@ -174,6 +187,8 @@ struct ScreenParams {
     uint32_t lo, hi;           // ligands [lo, hi) of the call (relative to first) are this super-chunk
     Ctl *ctl;
     uint8_t *totbuf;           // [waves][kTotBufBytes]: the path totals of the 32 / 64-lane shapes (LDS at fewer lanes)
+    uint8_t *pabuf;            // [waves][pa_bytes]: path_bound()'s pair sums of the matches on the path, float[matches][ksumtot][G]
+    uint32_t pa_bytes;
     uint8_t *slices;           // [waves][slice_bytes]
     uint32_t slice_bytes;
     uint8_t *arena;
@@ -238,6 +253,13 @@ __device__ inline void wave_sync() { // LDS / global hand-over between the lanes
 }
 // Hand-over through LDS only (does not wait for outstanding global stores)
 __device__ inline void lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// The smallest float32 that is not below x (NaN stays NaN).
+__device__ inline float float_up(double x) {
+    const float f = (float)x;
+    if (!((double)f < x)) return f;
+    const uint32_t b = __float_as_uint(f);
+    return __uint_as_float(f > 0.f ? b + 1u : (f < 0.f ? b - 1u : 1u));
+}
 __device__ inline float norm3f(float dx, float dy, float dz) { // np.linalg.norm of a float32 3-vector (ligand.py:349-351)
     float s = dx * dx;
     s = s + dy * dy;
@@ -340,7 +362,7 @@ __global__ void fn_build_kernel(DevModel M, Weights W, const uint64_t *subnodes,
 // Frames nl - 3 .. nl - 2 - kTcLevels keep their children's totals in LDS: when the walker comes back to such a frame the
 // remaining candidates are taken from there instead of being evaluated again (a third of all passes were re-evaluations).
 #ifndef PMX_TC_LEVELS
-#define PMX_TC_LEVELS 4
+#define PMX_TC_LEVELS 3
 #endif
 constexpr int kTcLevels = PMX_TC_LEVELS;
 static_assert(kTcLevels >= 1 && kTcLevels <= 8, "cache slot number is three bits of Walk::hk");
@@ -348,7 +370,7 @@ template <int G>
 struct WaveShape {
     uint32_t kp;     // candidates per level, padded
     uint32_t nc_cap; // node-candidate entries
-    uint32_t off_cand, off_lcnt, off_nc, off_tot, off_pool, off_stat, off_task, off_tch, off_tc, off_cb, bytes;
+    uint32_t off_cand, off_lcnt, off_nc, off_tot, off_pool, off_stat, off_task, off_tch, off_tc, off_cb, off_ub, bytes;
 };
 template <int G>
 __host__ __device__ inline WaveShape<G> wave_shape(int K, int max_nodes) {
@@ -377,8 +399,10 @@ __host__ __device__ inline WaveShape<G> wave_shape(int K, int max_nodes) {
     o += 64 * 8;
     w.off_tc = o; // the children's totals of the kTcLevels deepest unfused frames + their validity ballots
     if (totals_in_lds<G>()) o += kTcLevels * (64 * 8 + 8);
-    w.off_cb = o; // candidates of a filtered frame that are still to visit, one 64-bit set per level
-    o += PMX_MAX_LEVELS * 8;
+    w.off_cb = o; // candidates of a filtered frame that are still to visit, one 64-bit set per level (32 / 64 conformer lanes)
+    if (64 / G <= 2) o += PMX_MAX_LEVELS * 8;
+    w.off_ub = o; // path_bound(): the most a level can add, per conformer
+    if (cand_bounds<G>()) o += PMX_MAX_LEVELS * G * 4;
     w.bytes = o;
     return w;
 }
@@ -412,7 +436,7 @@ static_assert(kOffBits + 8 * PMX_MAX_LEVELS + 8 <= kOffPath && kOffPath + 2 * PM
 // existence. Scores and every skip decision stay what the reference computes.
 struct WaveStats { // lives in LDS, updated by lane 0
     unsigned long long frames, passes, over, items, exact, longest, tasks, overflow;
-    unsigned long long cyc_scan, cyc_tables, cyc_bounds, cyc_walk, exactv, spare, pad[2]; // s_memtime ticks per phase | self items evaluated term by term
+    unsigned long long cyc_scan, cyc_tables, cyc_bounds, cyc_walk, exactv, npath, pad[2]; // s_memtime ticks per phase | self items evaluated term by term
     unsigned long long dbg[8]; // instrumented builds (-DPMX_COUNTERS): see walk()
 };
 static_assert(sizeof(WaveStats) == 192, "WaveStats layout");
@@ -420,15 +444,17 @@ static_assert(sizeof(WaveStats) == 192, "WaveStats layout");
 template <int G>
 struct Walk {
     // tables of the job
-    const unsigned char *Sb, *Pb, *Rb, *Wb, *Vb;
+    const unsigned char *Sb, *Pb, *Rb, *Wb, *Vb, *OBb; // (CI follows OB)
     int nl;
+    uint32_t ksumtot;
+    bool path_on = false; // the job's tables fit the wave's path-sum buffer: path_bound() may be used
     int hk, hks, hrow; // lane l: k[l], ksum[l], rowbase[l]
     // path: lane q holds match q
     int matRB = 0, matKA = 0; // rowbase[j] - k_j * ksum[j + 1] | k_j | a << 8 | j << 16
     // stack: lane f holds frame f
     int stA = 0, stB = 0, stC = 0; // mask lo, mask hi, nb | mx << 8 | flags << 16 | nm << 24
     double best = 0.0, flushed = 0.0;
-    uint32_t frames = 0, passes = 0;
+    uint32_t frames = 0, passes = 0, npath = 0, ndrop = 0; // (npath / ndrop: path_bound() calls, children it dropped)
     // current frame (its state is in lane f of the stack like every other frame's; a walk can be interrupted and resumed, see kOverBudget)
     int f = 0, f0 = 0;
 };
@@ -441,8 +467,12 @@ __host__ __device__ constexpr uint64_t group_mask() {
 // per-level facts in bits 8.. of Walk::hk: the last level | its parent level with the children's leaves fused into its pass |
 // a level whose children's totals are cached (slot number in bits 12..14)
 constexpr int kLvLeaf = 256, kLvFuse = 512, kLvCache = 1024;
-constexpr unsigned kMatched = 1, kAny = 2, kSkipped = 4, kCached = 8, kFused = 16, kFiltered = 32;
-constexpr double kBoundSlack = 1.0 + 1e-9; // covers the float64 rounding of the sums the bound is compared with
+constexpr unsigned kMatched = 1, kAny = 2, kSkipped = 4, kCached = 8, kFused = 16, kFiltered = 32, kPath = 64; // kPath: the path sums of this frame's matches are in the wave's buffer
+constexpr double kBoundSlack = 1.0 + 1e-9;
+#ifndef PMX_PATH_MIN_LEVELS
+#define PMX_PATH_MIN_LEVELS 3
+#endif
+constexpr int kPathMinLevels = PMX_PATH_MIN_LEVELS; // path_bound() is asked where the frame's level and at least this many - 1 more lie below // covers the float64 rounding of the sums the bound is compared with
 
 
 // Row loops of the walker: `load(q)` for q = 0 .. n - 1 go out kRowBatch at a time and `use(value)` takes them in order; what is
@@ -579,9 +609,94 @@ __device__ __forceinline__ bool probe(Walk<G> &w, int f, int nm, int cand, uint6
     }
 }
 
+// Path-aware bound (round 4). W[(f, b)] bounds what the levels below f can add under a child Y = (f, b) with every level
+// above f at its *maximum* pair entry; with seven matches on the path that is far from what they do add. Here the deeper
+// candidates are priced with the pair entries of the matches actually on the path: for a candidate x = (l, b') of a level l > f
+//     v(x)[c] = OB[f][x][c] + sum_{q on the path, Y included} P[q -> x][c]        (left out unless every such entry is > 0)
+// (OB: x's self entry + the maxima of the levels between f and l, build_bounds), a level adds at most max(0, max_x v(x)), and
+// the subtree below Y at most the sum of that over the levels l > f: no leaf below Y exceeds total(Y) + that. Nothing else
+// changes - a child that fails is dropped exactly as one that fails the W test (see walk(): "exactness"). The pair sums of
+// the path are kept per match count in a buffer of the wave (pa[matches][candidate][conformer], float32: an upper bound needs
+// no more; the sums are of non-negative terms, so rounding to nearest loses at most 2^-24 per addition, which the final
+// factor covers) and extended by Y's entries here - they are the sums of Y's own frame when the walker goes there.
+// On the bench library the walker enters 4 times fewer frames with it (tests/bound_study: 272 -> 69 per ligand), 9-13 times
+// fewer on the fixture pockets.
+template <int G>
+__device__ __forceinline__ bool path_bound(const Walk<G> &w, const ScreenParams &p, float *pa, float *ub, const double *tch, const unsigned long long *pool,
+                                           int f, int nm, int bsel, uint64_t cmask) {
+    constexpr int SLOTS = 64 / G;
+    const int lane = lane_id();
+    const int s = lane / G, c = lane % G;
+    const int nl = w.nl;
+    const uint32_t ksumtot = w.ksumtot;
+    const uint32_t x0 = (uint32_t)rl(w.hks, f + 1); // first candidate of the levels below f
+    const uint32_t kf = (uint32_t)rl(w.hk, f) & 255u;
+    const uint32_t rb = (uint32_t)rl(w.hrow, f) - kf * x0; // entry(Y -> (l, b')) = rb + kf * ksum[l] + b * k_l + b'
+    const float *Pf = reinterpret_cast<const float *>(w.Pb);
+    const float *OB = reinterpret_cast<const float *>(w.OBb) + (size_t)f * ksumtot * G;
+    const uint32_t *CI = reinterpret_cast<const uint32_t *>(w.OBb + (size_t)nl * ksumtot * G * 4u);
+    const float *pin = pa + (size_t)nm * ksumtot * G;
+    float *pout = pa + (size_t)(nm + 1) * ksumtot * G;
+    for (int i = lane; i < (nl - f - 1) * G; i += 64) ub[(f + 1) * G + i] = 0.f;
+    lds_sync();
+    for (uint32_t x = x0; x < ksumtot; x += SLOTS) {
+        const bool on = x + (uint32_t)s < ksumtot;
+        const uint32_t xx = on ? x + (uint32_t)s : x0;
+        const uint32_t ci = CI[xx];
+        const uint32_t l = ci & 255u, kl = (ci >> 8) & 255u, ksl = ci >> 16;
+        const uint32_t e = rb + kf * ksl + (uint32_t)bsel * kl + (xx - ksl);
+        const float pv = Pf[(size_t)e * G + c];
+        const float ob = OB[(size_t)xx * G + c];
+        const float have = nm ? pin[(size_t)xx * G + c] : 0.f;
+        const float sum = pv > 0.f ? have + pv : -__builtin_inff(); // (-inf stays -inf: a candidate out for this conformer stays out)
+        if (on) {
+            pout[(size_t)xx * G + c] = sum;
+            const float v = fmaxf(sum + ob, 0.f); // (a NaN self entry - zero weights - can raise no maximum: 0)
+            atomicMax(reinterpret_cast<unsigned int *>(ub) + l * G + (uint32_t)c, __float_as_uint(v));
+        }
+    }
+    lds_sync();
+    float below = 0.f;
+    for (int l = f + 1; l < nl; ++l) below = below + ub[l * G + c];
+    const double bound = (double)below * (1.0 + 4e-6);
+    const double pooled = __longlong_as_double((long long)pool[c]);
+    const double bp = pooled > w.best ? pooled : w.best;
+    return __ballot(((cmask >> c) & 1ull) && (tch[c] + bound) * kBoundSlack > bp) != 0ull;
+}
+
+// The path sums of the wave's buffer for a job that starts with matches on its path (a queued subtree): the rows of match
+// after match, as path_bound() would have left them.
+template <int G>
+__device__ __forceinline__ void path_sums_of_root(const Walk<G> &w, float *pa, int nm0) {
+    constexpr int SLOTS = 64 / G;
+    const int lane = lane_id();
+    const int s = lane / G, c = lane % G;
+    const uint32_t ksumtot = w.ksumtot;
+    const float *Pf = reinterpret_cast<const float *>(w.Pb);
+    const uint32_t *CI = reinterpret_cast<const uint32_t *>(w.OBb + (size_t)w.nl * ksumtot * G * 4u);
+    for (int q = 0; q < nm0; ++q) {
+        const int ka = rl(w.matKA, q);
+        const uint32_t kq = (uint32_t)ka & 255u, aq = ((uint32_t)ka >> 8) & 255u, jq = ((uint32_t)ka >> 16) & 255u;
+        const uint32_t rb = (uint32_t)rl(w.matRB, q);
+        const uint32_t x0 = (uint32_t)rl(w.hks, (int)jq + 1);
+        const float *pin = pa + (size_t)q * ksumtot * G;
+        float *pout = pa + (size_t)(q + 1) * ksumtot * G;
+        for (uint32_t x = x0; x < ksumtot; x += SLOTS) {
+            const bool on = x + (uint32_t)s < ksumtot;
+            const uint32_t xx = on ? x + (uint32_t)s : x0;
+            const uint32_t ci = CI[xx];
+            const uint32_t kl = (ci >> 8) & 255u, ksl = ci >> 16;
+            const float pv = Pf[(size_t)(rb + kq * ksl + aq * kl + (xx - ksl)) * G + c];
+            const float have = q ? pin[(size_t)xx * G + c] : 0.f;
+            if (on) pout[(size_t)xx * G + c] = pv > 0.f ? have + pv : -__builtin_inff();
+        }
+        wave_sync(); // (the next match reads what this one wrote)
+    }
+}
+
 template <int G>
 __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *tot, unsigned long long *pool, uint16_t *pathbuf, double *tch, double *tc,
-                                    unsigned long long *cbl, uint32_t rec16 /* arena record of the job (exports refer to it) */, bool export_mode,
+                                    unsigned long long *cbl, float *pa, float *ub, uint32_t rec16 /* arena record of the job (exports refer to it) */, bool export_mode,
                                     unsigned long long budget, uint32_t wave_id, WaveStats *stat) {
     constexpr int SLOTS = 64 / G;
     constexpr int PSH = G == 1 ? 2 : G == 2 ? 3 : G == 4 ? 4 : G == 8 ? 5 : G == 16 ? 6 : G == 32 ? 7 : 8; // log2 bytes of an entry
@@ -609,10 +724,10 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
     uint32_t next_share = w.passes + kShareEvery;
 #ifdef PMX_COUNTERS
     uint32_t dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // fused passes | fused children | cached passes | leaf passes | other passes from the tables | descents | ancestors over table passes | shares
-#define PMX_COUNT(i, n) do { if (PMX_COUNTERS == 1) dbg[i] += (uint32_t)(n); } while (0)
+#define PMX_COUNT(i, n) do { if (PMX_COUNTERS == 1 && (i) < 6) dbg[i] += (uint32_t)(n); } while (0)
     auto flush_dbg = [&]() {
         if (lane == 0)
-            for (int i = 0; i < 8; ++i) stat->dbg[i] += dbg[i];
+            for (int i = 0; i < 6; ++i) stat->dbg[i] += dbg[i];
     };
 #else
 #define PMX_COUNT(i, n)
@@ -777,6 +892,7 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
             }
 #endif
             int probe_slot = -1; // a child of this pass whose reach is probed (one call site)
+            bool probe_rem_done = false;
             bool handled = false, pending = false;
             if (shallow && ab != vb) {
                 const bool slot_vb = ((vb >> (s * G)) & GM) != 0, slot_ab = ((ab >> (s * G)) & GM) != 0;
@@ -918,22 +1034,38 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
                 if (keep) {
                     // descend into the first surviving child (tree.py:94-97)
                     int ss;
+                    bool go = true;           // (false: the chosen child fails the path-aware bound test and is dropped)
+                    unsigned child_path = 0u; // kPath if the child's path sums are in the wave's buffer
                     if (ordered) {
                         const bool alive = (ab >> lane) & 1ull;
                         const float key = alive ? fmaxf((float)(t + rbound), 0.f) : -1.f; // (a NaN total orders as 0)
                         const float top = wave_max_f32(key);
                         ss = (__ffsll(__ballot(alive && key == top)) - 1) / G;
-                        if (vb != ab) mx = mx > 1 ? mx : 1; // (an existing child - visited, dropped or probed - returns at least 1)
+                        if (cand_bounds<G>() && (flags & kPath) && nl - f >= kPathMinLevels && !(p.flags & 1024)) {
+                            // the child with the largest W bound, against the bound its actual path gives (path_bound())
+                            if (s == ss) tch[c] = t;
+                            lds_sync();
+                            go = path_bound<G>(w, p, pa, ub, tch, pool, f, nm, rl(bvec, ss * G), (vb >> (ss * G)) & GM);
+                            child_path = kPath;
+                            ++w.npath;
+                            if (!go) ++w.ndrop;
+                        }
+                        if (vb != ab || !go) mx = mx > 1 ? mx : 1; // (an existing child - visited, dropped or probed - returns at least 1)
                         rem &= ~(1u << ss);
                         if (!(ab & ~(GM << (ss * G))) && !pending) { // no other survivor: the window ends with this child
                             nb += SLOTS;
                             rem = 0xffffffffu;
+                        }
+                        if (!go && nm < 4 && mx < 5 - nm) { // the frame still has to know whether the dropped child reaches 5 matches
+                            probe_slot = ss;
+                            probe_rem_done = true;
                         }
                     } else {
                         ss = (__ffsll(ab) - 1) / G;
                         const unsigned long long before = ss == 0 ? 0ull : (vb & ((1ull << (ss * G)) - 1ull));
                         if (before) mx = mx > 1 ? mx : 1; // existing children dropped by the bound test return at least 1
                     }
+                    if (go) {
                     const int bsel = rl(bvec, ss * G);
                     if (!ordered) nb = bsel + 1;
                     if (filt) { // what is left of the frame's candidates (the slots below ss were dropped)
@@ -944,7 +1076,7 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
                     const uint64_t cmask = (vb >> (ss * G)) & GM;
                     if (s == ss) tot[(nm + 1) * G + c] = t;
                     // this frame's state, then the child's: lane f + 1
-                    w.stC = wl(wl(w.stC, f, nb | (mx << 8) | ((int)flags << 16) | (nm << 24)), f + 1, ((int)kMatched << 16) | ((nm + 1) << 24));
+                    w.stC = wl(wl(w.stC, f, nb | (mx << 8) | ((int)flags << 16) | (nm << 24)), f + 1, ((int)(kMatched | child_path) << 16) | ((nm + 1) << 24));
                     w.stA = wl(w.stA, f + 1, (int)(uint32_t)cmask);
                     if (G > 32) w.stB = wl(w.stB, f + 1, (int)(uint32_t)(cmask >> 32));
                     if (ORD) w.stB = wl(wl(w.stB, f, (int)rem), f + 1, -1);
@@ -957,6 +1089,7 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
                     if (totals_in_lds<G>()) lds_sync(); // the child's total is read by all slots
                     else wave_sync();
                     continue;
+                    }
                 }
             } else { // every existing child of this pass was dropped (or none existed)
                 if (vb) mx = mx > 1 ? mx : 1;
@@ -975,8 +1108,11 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
                 }
                 mx = mx > 1 ? mx : 1;
                 if (reach) mx = mx > 5 - nm ? mx : 5 - nm;
-                if (ordered) rem &= ~(1u << probe_slot);
-                else nb = bp_ + 1;
+                if (ordered) {
+                    if (!probe_rem_done) rem &= ~(1u << probe_slot);
+                } else {
+                    nb = bp_ + 1;
+                }
                 cb &= ~((2ull << bp_) - 1ull);
             }
             if (filt) {
@@ -1009,7 +1145,7 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
         }
         if (!leaf_level && !(flags & kSkipped) && (!(flags & kAny) || nm + mx < 5)) { // skip child (tree.py:98-101)
             flags |= kSkipped;
-            w.stC = wl(wl(w.stC, f, nb | (mx << 8) | ((int)flags << 16) | (nm << 24)), f + 1, nm << 24);
+            w.stC = wl(wl(w.stC, f, nb | (mx << 8) | ((int)flags << 16) | (nm << 24)), f + 1, ((int)(flags & kPath) << 16) | (nm << 24)); // (same matches: same path sums)
             w.stA = wl(w.stA, f + 1, (int)(uint32_t)mask);
             if (G > 32) w.stB = wl(w.stB, f + 1, (int)(uint32_t)(mask >> 32));
             if (ORD) w.stB = wl(w.stB, f + 1, -1);
@@ -1513,6 +1649,8 @@ __device__ __forceinline__ void build_bounds(const ScreenParams &p, unsigned cha
     const float *Pt = reinterpret_cast<const float *>(rec + rec_p_off<G>(L.ksumtot));
     double *Rt = reinterpret_cast<double *>(rec + rec_r_off<G>(L.ksumtot, L.T));
     double *Wt = reinterpret_cast<double *>(rec + rec_w_off<G>(L.ksumtot, L.T, (uint32_t)L.nl));
+    float *OBt = reinterpret_cast<float *>(rec + rec_ob_off<G>(L.ksumtot, L.T, (uint32_t)L.nl));
+    uint32_t *CIt = reinterpret_cast<uint32_t *>(rec + rec_ci_off<G>(L.ksumtot, L.T, (uint32_t)L.nl));
     const int nl = L.nl;
     if (p.flags & 4) { // debug: nothing is ever dropped
         for (int l = s; l <= nl; l += SLOTS) Rt[(size_t)l * G + c] = __builtin_inf();
@@ -1526,8 +1664,11 @@ __device__ __forceinline__ void build_bounds(const ScreenParams &p, unsigned cha
         const int kl = uni(lk[l]), ksl = uni(ksum[l]);
         double u = 0.0;
         for (int b = s; b < kl; b += SLOTS) {
+            // the levels above l from the nearest one up: what has been added when level j is reached is what (l, b) can add
+            // apart from its pair entries with levels <= j - OB[j][(l, b)], path_bound()'s table
             double v = (double)St[(size_t)(ksl + b) * G + c];
-            for (int j = 0; j < l; ++j) {
+            for (int j = l - 1; j >= 0; --j) {
+                if (cand_bounds<G>()) OBt[((size_t)j * L.ksumtot + (size_t)(ksl + b)) * G + c] = float_up(v);
                 const int kj = uni(lk[j]);
                 const uint32_t e0 = (uint32_t)uni((int)rowbase[j]) + (uint32_t)kj * (uint32_t)(ksl - uni((int)ksum[j + 1])) + (uint32_t)b;
                 float m = 0.f;
@@ -1537,7 +1678,10 @@ __device__ __forceinline__ void build_bounds(const ScreenParams &p, unsigned cha
                 }
                 v += (double)m;
             }
-            if (cand_bounds<G>()) Wt[(size_t)(ksl + b) * G + c] = v; // base(l, b), replaced by the candidate's own bound below
+            if (cand_bounds<G>()) {
+                Wt[(size_t)(ksl + b) * G + c] = v; // base(l, b), replaced by the candidate's own bound below
+                if (c == 0) CIt[ksl + b] = (uint32_t)l | ((uint32_t)kl << 8) | ((uint32_t)ksl << 16);
+            }
             u = v > u ? v : u;
         }
 #pragma unroll
@@ -1754,7 +1898,11 @@ __device__ __forceinline__ bool prepare_walk(const ScreenParams &p, unsigned cha
     w.Rb = rec + rec_r_off<G>(ksumtot, T);
     w.Wb = rec + rec_w_off<G>(ksumtot, T, (uint32_t)nl);
     w.Vb = rec + rec_v_off<G>(ksumtot, T, (uint32_t)nl);
+    w.OBb = rec + rec_ob_off<G>(ksumtot, T, (uint32_t)nl);
     w.nl = nl;
+    w.ksumtot = ksumtot;
+    // path_bound() keeps a row of pair sums per candidate and match count in the wave's buffer: used when they fit
+    w.path_on = cand_bounds<G>() && !(p.flags & (4u | 1024u)) && (uint64_t)(nl + 1) * ksumtot * G * 4u <= (uint64_t)p.pa_bytes;
     {
         const int kl = lane < nl ? (int)H->k[lane] : 0, knext = lane + 1 < nl ? (int)H->k[lane + 1] : 0;
         const int tci = nl - 3 - lane;
@@ -1782,13 +1930,15 @@ __device__ __forceinline__ bool prepare_walk(const ScreenParams &p, unsigned cha
     w.stA = wl(w.stA, f0, (int)(uint32_t)mask0);
     if (G > 32) w.stB = wl(w.stB, f0, (int)(uint32_t)(mask0 >> 32));
     else w.stB = -1;
-    w.stC = wl(w.stC, f0, ((nm0 ? (int)kMatched : 0) << 16) | (nm0 << 24));
+    w.stC = wl(w.stC, f0, (((nm0 ? (int)kMatched : 0) | (w.path_on ? (int)kPath : 0)) << 16) | (nm0 << 24));
     wave_sync();
     if (!(p.flags & 4) && f0 < nl && nm0 >= 5) {
         const double r = *reinterpret_cast<const double *>(w.Rb + ((size_t)f0 * G + c) * 8);
         const double t = tot[nm0 * G + c];
-        return __ballot(((mask0 >> c) & 1ull) && (t + r) * kBoundSlack > __longlong_as_double((long long)pool[c])) != 0;
+        if (__ballot(((mask0 >> c) & 1ull) && (t + r) * kBoundSlack > __longlong_as_double((long long)pool[c])) == 0) return false;
     }
+    if (cand_bounds<G>() && w.path_on && nm0 > 0) // a queued subtree: the pair sums of the matches it starts with
+        path_sums_of_root<G>(w, reinterpret_cast<float *>(p.pabuf + (size_t)blockIdx.x * p.pa_bytes), nm0);
     return true;
 }
 
@@ -1807,11 +1957,13 @@ __device__ __forceinline__ void run_job(const ScreenParams &p, unsigned char *ld
     double *tch = reinterpret_cast<double *>(lds + ws.off_tch);
     double *tc = reinterpret_cast<double *>(lds + ws.off_tc);
     unsigned long long *cbl = reinterpret_cast<unsigned long long *>(lds + ws.off_cb);
+    float *pa = reinterpret_cast<float *>(p.pabuf + (size_t)blockIdx.x * p.pa_bytes);
+    float *ub = reinterpret_cast<float *>(lds + ws.off_ub);
     const unsigned long long t_d = __builtin_amdgcn_s_memtime();
     unsigned long long budget = ((p.flags & 2) || p.last_round) ? ~0ull : (unsigned long long)p.budget;
     bool export_mode = false, split = is_task;
     for (;;) {
-        const int rc = walk<G>(w, p, tot, pool, pathbuf, tch, tc, cbl, rec16, export_mode, budget, wave_id, stat);
+        const int rc = walk<G>(w, p, tot, pool, pathbuf, tch, tc, cbl, pa, ub, rec16, export_mode, budget, wave_id, stat);
         if (rc != kOverBudget) break;
         if (lane == 0) ++stat->over;
         budget = ~0ull;
@@ -1845,6 +1997,8 @@ __device__ __forceinline__ void run_job(const ScreenParams &p, unsigned char *ld
         stat->cyc_walk += __builtin_amdgcn_s_memtime() - t_d;
         stat->frames += w.frames;
         stat->passes += w.passes;
+        stat->npath += w.npath;
+        stat->dbg[7] += w.ndrop; // (the last word of the instrumented builds' counters is the product's: children dropped by path_bound())
         stat->longest = w.passes > stat->longest ? w.passes : stat->longest;
     }
     // ---- per-conformer maxima over the slots -> score
@@ -1884,8 +2038,10 @@ __device__ inline void flush_wave_stats(const ScreenParams &p, const WaveStats *
     atomicAdd(st + 11, stat->cyc_walk);
     atomicAdd(st + 12, alive);
     atomicAdd(st + 13, stat->exactv);
+    atomicAdd(st + 22, stat->npath);
+    atomicAdd(st + 23, stat->dbg[7]);
 #ifdef PMX_COUNTERS
-    for (int i = 0; i < 8; ++i) atomicAdd(st + 16 + i, stat->dbg[i]);
+    for (int i = 0; i < 6; ++i) atomicAdd(st + 16 + i, stat->dbg[i]);
 #endif
 }
 
