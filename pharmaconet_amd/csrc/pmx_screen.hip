@@ -60,10 +60,10 @@ struct FnTable {
 
 // Header of one ligand's tables, in a wave's slice or in the arena:
 //   [RecHeader][best u64[G]][S float[ksumtot][G]][P float[T][G]][R double[nl + 1][G]][W double[ksumtot][G]][V mask[T]]
-//   [OB float[nl][ksumtot][G]][CI u32[ksumtot]]                                   (where per-candidate bounds exist)
+//   [OB float[nl][ksumtot][G]][X u32[nl][ksumtot]]                                (where per-candidate bounds exist)
 // OB[f][x] for a candidate x = (l, b') of a level l > f: S[l][b'] + sum_{f < j < l} max(0, max_a P[(j, a), (l, b')]), rounded up - what
 // (l, b') can add to a leaf total apart from its pair entries with the matches on the path down to level f (path_bound()).
-// CI[x] = l | k_l << 8 | ksum[l] << 16.
+// X[f][x] = entry((f, 0) -> x) | k_l << 20 | l << 27: the pair entry of a candidate b of level f with x is X[f][x] + b * k_l.
 // V[e] = the conformers c with P[e][c] > 0 (one bit per conformer, max(G, 8) / 8 bytes per entry): what decides which
 // children of a tree node exist (tree.py:78-84), read with the lanes spread over candidates.
 // Pair entry ((i, a), (j, b)), i < j: rowbase[i] + k[i] * (ksum[j] - ksum[i + 1]) + a * k[j] + b.
@@ -122,7 +122,7 @@ template <int G>
 __host__ __device__ inline uint64_t rec_bytes(uint32_t ksumtot, uint32_t T, uint32_t nl) {
     return (uint64_t)rec_s_off<G>() + round16((uint64_t)ksumtot * G * 4) + round16((uint64_t)T * G * 4) + (uint64_t)(nl + 1) * G * 8 +
            (cand_bounds<G>() ? (uint64_t)ksumtot * G * 8 : 0ull) + round16((uint64_t)T * vmask_bytes<G>()) +
-           (cand_bounds<G>() ? (uint64_t)nl * ksumtot * G * 4 + round16((uint64_t)ksumtot * 4) : 0ull);
+           (cand_bounds<G>() ? (uint64_t)nl * ksumtot * G * 4 + round16((uint64_t)nl * ksumtot * 4) : 0ull);
 }
 
 // A subtree handed to the task queue: its root has >= 5 matches (see walk()).
@@ -630,29 +630,36 @@ __device__ __forceinline__ bool path_bound(const Walk<G> &w, const ScreenParams 
     const int nl = w.nl;
     const uint32_t ksumtot = w.ksumtot;
     const uint32_t x0 = (uint32_t)rl(w.hks, f + 1); // first candidate of the levels below f
-    const uint32_t kf = (uint32_t)rl(w.hk, f) & 255u;
-    const uint32_t rb = (uint32_t)rl(w.hrow, f) - kf * x0; // entry(Y -> (l, b')) = rb + kf * ksum[l] + b * k_l + b'
     const float *Pf = reinterpret_cast<const float *>(w.Pb);
     const float *OB = reinterpret_cast<const float *>(w.OBb) + (size_t)f * ksumtot * G;
-    const uint32_t *CI = reinterpret_cast<const uint32_t *>(w.OBb + (size_t)nl * ksumtot * G * 4u);
+    const uint32_t *X = reinterpret_cast<const uint32_t *>(w.OBb + (size_t)nl * ksumtot * G * 4u) + (size_t)f * ksumtot;
     const float *pin = pa + (size_t)nm * ksumtot * G;
     float *pout = pa + (size_t)(nm + 1) * ksumtot * G;
     for (int i = lane; i < (nl - f - 1) * G; i += 64) ub[(f + 1) * G + i] = 0.f;
     lds_sync();
-    for (uint32_t x = x0; x < ksumtot; x += SLOTS) {
-        const bool on = x + (uint32_t)s < ksumtot;
-        const uint32_t xx = on ? x + (uint32_t)s : x0;
-        const uint32_t ci = CI[xx];
-        const uint32_t l = ci & 255u, kl = (ci >> 8) & 255u, ksl = ci >> 16;
-        const uint32_t e = rb + kf * ksl + (uint32_t)bsel * kl + (xx - ksl);
-        const float pv = Pf[(size_t)e * G + c];
-        const float ob = OB[(size_t)xx * G + c];
-        const float have = nm ? pin[(size_t)xx * G + c] : 0.f;
-        const float sum = pv > 0.f ? have + pv : -__builtin_inff(); // (-inf stays -inf: a candidate out for this conformer stays out)
-        if (on) {
-            pout[(size_t)xx * G + c] = sum;
-            const float v = fmaxf(sum + ob, 0.f); // (a NaN self entry - zero weights - can raise no maximum: 0)
-            atomicMax(reinterpret_cast<unsigned int *>(ub) + l * G + (uint32_t)c, __float_as_uint(v));
+    // two windows of SLOTS candidates per trip: their table words, bounds and path sums go out together, then their pair rows
+    for (uint32_t x = x0; x < ksumtot; x += 2 * SLOTS) {
+        uint32_t xx[2], xw[2];
+        float ob[2], have[2], pv[2];
+        bool on[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            on[u] = x + (uint32_t)(u * SLOTS + s) < ksumtot;
+            xx[u] = on[u] ? x + (uint32_t)(u * SLOTS + s) : x0;
+            xw[u] = X[xx[u]];
+            ob[u] = OB[(size_t)xx[u] * G + c];
+            have[u] = nm ? pin[(size_t)xx[u] * G + c] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) pv[u] = Pf[(size_t)((xw[u] & 0xfffffu) + (uint32_t)bsel * ((xw[u] >> 20) & 127u)) * G + c];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const float sum = pv[u] > 0.f ? have[u] + pv[u] : -__builtin_inff(); // (-inf stays -inf: a candidate out for this conformer stays out)
+            if (on[u]) {
+                pout[(size_t)xx[u] * G + c] = sum;
+                const float v = fmaxf(sum + ob[u], 0.f); // (a NaN self entry - zero weights - can raise no maximum: 0)
+                atomicMax(reinterpret_cast<unsigned int *>(ub) + (xw[u] >> 27) * G + (uint32_t)c, __float_as_uint(v));
+            }
         }
     }
     lds_sync();
@@ -673,20 +680,19 @@ __device__ __forceinline__ void path_sums_of_root(const Walk<G> &w, float *pa, i
     const int s = lane / G, c = lane % G;
     const uint32_t ksumtot = w.ksumtot;
     const float *Pf = reinterpret_cast<const float *>(w.Pb);
-    const uint32_t *CI = reinterpret_cast<const uint32_t *>(w.OBb + (size_t)w.nl * ksumtot * G * 4u);
+    const uint32_t *Xall = reinterpret_cast<const uint32_t *>(w.OBb + (size_t)w.nl * ksumtot * G * 4u);
     for (int q = 0; q < nm0; ++q) {
         const int ka = rl(w.matKA, q);
-        const uint32_t kq = (uint32_t)ka & 255u, aq = ((uint32_t)ka >> 8) & 255u, jq = ((uint32_t)ka >> 16) & 255u;
-        const uint32_t rb = (uint32_t)rl(w.matRB, q);
+        const uint32_t aq = ((uint32_t)ka >> 8) & 255u, jq = ((uint32_t)ka >> 16) & 255u;
         const uint32_t x0 = (uint32_t)rl(w.hks, (int)jq + 1);
+        const uint32_t *X = Xall + (size_t)jq * ksumtot;
         const float *pin = pa + (size_t)q * ksumtot * G;
         float *pout = pa + (size_t)(q + 1) * ksumtot * G;
         for (uint32_t x = x0; x < ksumtot; x += SLOTS) {
             const bool on = x + (uint32_t)s < ksumtot;
             const uint32_t xx = on ? x + (uint32_t)s : x0;
-            const uint32_t ci = CI[xx];
-            const uint32_t kl = (ci >> 8) & 255u, ksl = ci >> 16;
-            const float pv = Pf[(size_t)(rb + kq * ksl + aq * kl + (xx - ksl)) * G + c];
+            const uint32_t xw = X[xx];
+            const float pv = Pf[(size_t)((xw & 0xfffffu) + aq * ((xw >> 20) & 127u)) * G + c];
             const float have = q ? pin[(size_t)xx * G + c] : 0.f;
             if (on) pout[(size_t)xx * G + c] = pv > 0.f ? have + pv : -__builtin_inff();
         }
@@ -1668,9 +1674,12 @@ __device__ __forceinline__ void build_bounds(const ScreenParams &p, unsigned cha
             // apart from its pair entries with levels <= j - OB[j][(l, b)], path_bound()'s table
             double v = (double)St[(size_t)(ksl + b) * G + c];
             for (int j = l - 1; j >= 0; --j) {
-                if (cand_bounds<G>()) OBt[((size_t)j * L.ksumtot + (size_t)(ksl + b)) * G + c] = float_up(v);
                 const int kj = uni(lk[j]);
                 const uint32_t e0 = (uint32_t)uni((int)rowbase[j]) + (uint32_t)kj * (uint32_t)(ksl - uni((int)ksum[j + 1])) + (uint32_t)b;
+                if (cand_bounds<G>()) {
+                    OBt[((size_t)j * L.ksumtot + (size_t)(ksl + b)) * G + c] = float_up(v);
+                    if (c == 0) CIt[(size_t)j * L.ksumtot + (size_t)(ksl + b)] = e0 | ((uint32_t)kl << 20) | ((uint32_t)l << 27);
+                }
                 float m = 0.f;
                 for (int a = 0; a < kj; ++a) {
                     const float pv = Pt[(size_t)(e0 + (uint32_t)a * (uint32_t)kl) * G + c];
@@ -1680,7 +1689,6 @@ __device__ __forceinline__ void build_bounds(const ScreenParams &p, unsigned cha
             }
             if (cand_bounds<G>()) {
                 Wt[(size_t)(ksl + b) * G + c] = v; // base(l, b), replaced by the candidate's own bound below
-                if (c == 0) CIt[ksl + b] = (uint32_t)l | ((uint32_t)kl << 8) | ((uint32_t)ksl << 16);
             }
             u = v > u ? v : u;
         }
