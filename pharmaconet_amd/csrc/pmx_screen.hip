@@ -1460,10 +1460,33 @@ __device__ __forceinline__ void build_tables(const ScreenParams &p, unsigned cha
     float *Pt = reinterpret_cast<float *>(rec + rec_p_off<G>(L.ksumtot));
     unsigned char *Vt = rec + rec_v_off<G>(L.ksumtot, L.T, (uint32_t)L.nl);
     const int nl = L.nl, K = p.M.K;
+    // Node distances of the cluster (pair) in work, once, in LDS: every table entry of the pair - k_i k_j of them - reads the
+    // distances of the same node pairs, and a distance from coordinates is six loads, each of which occupies the L1 for four
+    // cycles whether or not its lanes share an address. The table phase was bound by exactly that (rocprofv3: 0.86 L1 accesses
+    // per cycle and CU, 67 % of its wave cycles waiting on memory). The walker's LDS (children cache, level maxima) is idle
+    // in this phase and holds 68 node pairs at 8 lanes; larger pairs - and the 32 / 64-lane shapes, which keep nothing
+    // there - compute from the coordinates as before.
+    float *dl = reinterpret_cast<float *>(lds + ws.off_tc);
+    const int dcap = (int)((ws.bytes - ws.off_tc) / (uint32_t)(G * 4));
+    auto node_distance = [&](int a0, int u, int b0, int v) {
+        const uint32_t ou = (uint32_t)((a0 + u) * 3 * C + cc), ov = (uint32_t)((b0 + v) * 3 * C + cc);
+        return norm3f(xyz[ou] - xyz[ov], xyz[ou + C] - xyz[ov + C], xyz[ou + 2 * C] - xyz[ov + 2 * C]);
+    };
+    auto stage_distances = [&](int a0, int na, int b0, int nb) { // dl[(u * nb + v) * G + c] = |x_(a0 + u) - x_(b0 + v)|
+        lds_sync();                                              // (readers of the last pair's distances are done)
+        const float inv_nb = 1.0f / (float)nb;
+        for (int pr = s; pr < na * nb; pr += SLOTS) {
+            const int u = (int)(((float)pr + 0.5f) * inv_nb), v = pr - u * nb;
+            dl[pr * G + c] = node_distance(a0, u, b0, v);
+        }
+        lds_sync();
+    };
     uint32_t pair_base = 0;
     for (int i = 0; i < nl; ++i) {
         const int si = uni(lstart[i]), ni = uni(lend[i]) - si, ki = uni(lk[i]), nci = uni(ncoff[i]), ksi = uni(ksum[i]);
         // ---- self table S[i][a] (match_utils.py:77-122): node pairs u < v of the cluster
+        const bool self_staged = ni > 1 && ni * ni <= dcap;
+        if (self_staged) stage_distances(si, ni, si, ni);
         for (int q0 = 0; q0 < ki; q0 += SLOTS) {
             const int q = q0 + s;
             const bool on = q < ki;
@@ -1471,12 +1494,9 @@ __device__ __forceinline__ void build_tables(const ScreenParams &p, unsigned cha
             float acc = 0.f;
             int fails = 0;
             for (int u = 0; u + 1 < ni; ++u) {
-                const uint32_t ou = (uint32_t)((si + u) * 3 * C + cc);
-                const float ux = xyz[ou], uy = xyz[ou + C], uz = xyz[ou + 2 * C];
                 const uint32_t sidu = nc[row + u];
                 for (int v = u + 1; v < ni; ++v) {
-                    const uint32_t ov = (uint32_t)((si + v) * 3 * C + cc);
-                    const float d = norm3f(ux - xyz[ov], uy - xyz[ov + C], uz - xyz[ov + 2 * C]);
+                    const float d = self_staged ? dl[(u * ni + v) * G + c] : node_distance(si, u, si, v);
                     item<EXACT, true>(p, sidu, nc[row + v], d, acc, fails, n_exact, n_exactv);
                     ++n_items;
                 }
@@ -1505,7 +1525,9 @@ __device__ __forceinline__ void build_tables(const ScreenParams &p, unsigned cha
                 pf[c] = ldist;
                 pf[G + c] = lsize;
             }
-            lds_sync();
+            const bool staged = ni * nj <= dcap;
+            if (staged) stage_distances(si, ni, sj, nj);
+            else lds_sync();
             for (int eb = 0; eb < E; eb += 64) {
                 unsigned long long pbal;
                 {
@@ -1561,12 +1583,9 @@ __device__ __forceinline__ void build_tables(const ScreenParams &p, unsigned cha
                         int fails = 0;
                         const int rowa = nci + sa * ni, rowb = ncj + sb * nj;
                         for (int u = 0; u < ni; ++u) {
-                            const uint32_t ou = (uint32_t)((si + u) * 3 * C + cc);
-                            const float ux = xyz[ou], uy = xyz[ou + C], uz = xyz[ou + 2 * C];
                             const uint32_t sidu = nc[rowa + u];
                             for (int v = 0; v < nj; ++v) {
-                                const uint32_t ov = (uint32_t)((sj + v) * 3 * C + cc);
-                                const float d = norm3f(ux - xyz[ov], uy - xyz[ov + C], uz - xyz[ov + 2 * C]);
+                                const float d = staged ? dl[(u * nj + v) * G + c] : node_distance(si, u, sj, v);
                                 item<EXACT, false>(p, sidu, nc[rowb + v], d, acc, fails, n_exact, n_exactv);
                             }
                         }
@@ -1605,8 +1624,7 @@ __device__ __forceinline__ void build_tables(const ScreenParams &p, unsigned cha
 #pragma unroll
                         for (int q = 0; q < IB; ++q) {
                             const bool in = t0 + q < total; // (an item past the end is the empty subset pair: value 0, never a fail)
-                            const uint32_t ou = (uint32_t)((si + lu) * 3 * C + cc), ov = (uint32_t)((sj + lv) * 3 * C + cc);
-                            const float d = norm3f(xyz[ou] - xyz[ov], xyz[ou + C] - xyz[ov + C], xyz[ou + 2 * C] - xyz[ov + 2 * C]);
+                            const float d = staged ? dl[(lu * nj + lv) * G + c] : node_distance(si, lu, sj, lv);
                             L[q] = item_load(p, in ? (uint32_t)nc[rowa + lu] : 0u, in ? (uint32_t)nc[rowb + lv] : 0u, d);
                             if (++lv == nj) {
                                 lv = 0;
