@@ -623,7 +623,7 @@ static int score_screen(const pmx_model *const *models, int n_models, const pmx_
     }
     const uint32_t flags = (uint32_t)env_long("PMX_TREE_FLAGS", 0);
     const uint32_t max_nodes = (uint32_t)std::max(4, std::min(lib->info.max_nodes, PMX_MAX_LIGAND_NODES));
-    const uint32_t lig_budget = (uint32_t)std::max<long>(16, env_long("PMX_BUDGET", 512));
+    const uint32_t lig_budget = (uint32_t)std::max<long>(16, env_long("PMX_BUDGET", 384));
     const uint32_t task_budget = (uint32_t)std::max<long>(16, env_long("PMX_TASK_BUDGET", lig_budget)); // a queued subtree's own budget
     const int rounds = (int)std::max<long>(1, env_long("PMX_ROUNDS", 12));
     const bool exact = (flags & 8) != 0;
