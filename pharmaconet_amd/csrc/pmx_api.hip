@@ -282,6 +282,7 @@ static int pair_functions(pmx_model *m, const Weights &W, hipStream_t stream, Fn
     }
     hit->stamp = ++m->fn_stamp;
     out->cells = hit->cells;
+    out->plane16 = m->NF * m->ncell;
     out->NS = m->NS;
     out->tri = m->dm.symmetric != 0 ? 1u : 0u;
     out->ncell = m->ncell;

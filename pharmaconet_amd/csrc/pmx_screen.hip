@@ -51,7 +51,9 @@ struct FnCell {
 static_assert(sizeof(FnCell) == 32, "FnCell layout");
 
 struct FnTable {
-    const FnCell *cells; // [NS * NS][ncell]
+    const FnCell *cells; // two planes of float4[functions][ncell]: {c0, c1, c2, c3} | {c4, c5, lo, hi} (plane B = plane A + plane16 float4s):
+                         // the eight conformers of a slot read neighbouring cells, and 16 bytes per cell and plane keep them in one cache line
+    uint32_t plane16;
     uint32_t NS;         // node subsets (0 = empty)
     uint32_t ncell;
     float inv_h;
@@ -354,7 +356,9 @@ __global__ void fn_build_kernel(DevModel M, Weights W, const uint64_t *subnodes,
         const float2 w = win[(size_t)fid * ncell + i];
         c.lo = w.x;
         c.hi = w.y;
-        cells[(size_t)fid * ncell + i] = c;
+        float4 *planes = reinterpret_cast<float4 *>(cells);
+        planes[(size_t)fid * ncell + i] = make_float4(c.c[0], c.c[1], c.c[2], c.c[3]);
+        planes[(size_t)gridDim.x * ncell + (size_t)fid * ncell + i] = make_float4(c.c[4], c.c[5], c.lo, c.hi);
     }
 }
 
@@ -1240,8 +1244,8 @@ __device__ __forceinline__ void item(const ScreenParams &p, uint32_t sidu, uint3
         const float x = d * p.F.inv_h; // exact: inv_h is a power of two
         const int ci = min((int)x, (int)p.F.ncell - 1);
         const float t = fminf(x - (float)ci, 1.0f);
-        const float4 *cell = reinterpret_cast<const float4 *>(p.F.cells + (fn_index(p.F, sidu, sidv) * p.F.ncell + (uint32_t)ci));
-        const float4 a = cell[0], b = cell[1];
+        const float4 *cell = reinterpret_cast<const float4 *>(p.F.cells) + (fn_index(p.F, sidu, sidv) * p.F.ncell + (uint32_t)ci);
+        const float4 a = cell[0], b = cell[p.F.plane16];
         float v = __builtin_fmaf(t, b.y, b.x);
         v = __builtin_fmaf(t, v, a.w);
         v = __builtin_fmaf(t, v, a.z);
@@ -1294,10 +1298,10 @@ __device__ __forceinline__ ItemLoad item_load(const ScreenParams &p, uint32_t si
     const int ci = min((int)x, (int)p.F.ncell - 1);
     L.d = d;
     L.sids = sidu | (sidv << 16);
-    const uint32_t off = (fn_index(p.F, sidu, sidv) * p.F.ncell + (uint32_t)ci) * 32u; // (the table is a few MB: 32 bits)
+    const uint32_t off = (fn_index(p.F, sidu, sidv) * p.F.ncell + (uint32_t)ci) * 16u; // (the table is a few MB: 32 bits)
     const float4 *cell = reinterpret_cast<const float4 *>(reinterpret_cast<const unsigned char *>(p.F.cells) + off);
     L.a = cell[0];
-    L.b = cell[1];
+    L.b = cell[p.F.plane16];
     return L;
 }
 __device__ __forceinline__ void item_finish(const ScreenParams &p, const ItemLoad &L, float &acc, int &fails, uint32_t &n_exact) {
