@@ -679,7 +679,7 @@ static int score_screen(const pmx_model *const *models, int n_models, const pmx_
         if (cand_bounds<G>()) { // float[matches <= levels][candidates of all levels][G], at most 1 MB per wavefront (larger jobs do without)
             const uint64_t nlmax = (uint64_t)std::min<int>(PMX_MAX_LEVELS, std::max(1, lib->info.max_clusters));
             const uint64_t need = (nlmax + 1) * nlmax * (uint64_t)std::max(1, model->dm.K) * G * 4;
-            pl.pa_bytes = (uint32_t)std::min<uint64_t>((need + 255) & ~255ull, 1u << 20);
+            pl.pa_bytes = (uint32_t)std::min<uint64_t>((need + 255) & ~255ull, (uint64_t)std::max<long>(1, env_long("PMX_PATH_KB", 1024)) << 10);
             pabuf_need = std::max(pabuf_need, (size_t)grid * pl.pa_bytes * 2u); // ligand kernel | task kernel
         }
         retry_possible = retry_possible || pl.worst_bytes > pl.big_bytes;
@@ -717,14 +717,13 @@ static int score_screen(const pmx_model *const *models, int n_models, const pmx_
     for (const PocketPlan &pl : plan) n_chunks += (count + pl.super - 1) / pl.super;
     // The rounds go to the side stream when there is something to run them next to. (Not when an arena pass may have to be
     // retried: the retry's ligand kernels use the large slices, as the next chunk's do.)
-    // [MI355X]: 4 M ligands of the bench library in 4 chunks 797 ms against 822 ms back to back, 12.5 M in 12 chunks 2.39 s against
-    // 2.47 s; 16 pockets x 200 704 ligands with one pocket's rounds beside the next pocket's ligand kernel 3.79 s against 3.70 s -
-    // successive pockets differ too much in what their two phases cost for a fixed split of the wave slots. So PMX_OVERLAP = 1
-    // (default): beside each other within a pocket, one after the other across pockets; 2: across pockets as well; 0: never.
-    // And only chunks of half a million ligands or more (the 6OIM-like model's are 1 M): every chunk ends in a dozen rounds with
-    // a tail each, which half the wave slots stretch; 16 pockets at 1 253 376 ligands each in chunks of 80-260 k: 24.5 s with the
-    // rounds beside the next chunk of the same pocket, 22.2 s back to back.
-    const long overlap_mode = env_long("PMX_OVERLAP", 1);
+    // [MI355X] history of this switch. With the round-3 search (task rounds = 47 % of a pass, scalar-bound) the rounds beside the
+    // next chunk's ligand kernel gained 3.6 % on the 12.5 M-ligand shard (2.39 s against 2.47 s) and lost wherever chunks were
+    // small (16 pockets: 24.5 s against 22.2 s). With the path-aware bound the rounds are 22 % of a pass and mostly tail: the
+    // same shard takes 2.15 s with them beside the next ligand kernel (which then has half the wave slots) and 1.66 s back to
+    // back. So PMX_OVERLAP = 0 (default): everything on the caller's stream; 1: beside each other within a pocket whose chunks
+    // hold >= 2^19 ligands; 2: always, across pockets as well.
+    const long overlap_mode = env_long("PMX_OVERLAP", 0);
     uint32_t super_min = ~0u;
     for (const PocketPlan &pl : plan) super_min = std::min(super_min, pl.super);
     const bool overlap = n_chunks >= 2 && !retry_possible && overlap_mode != 0 && (overlap_mode >= 2 || super_min >= (1u << 19));

@@ -211,6 +211,8 @@ def test_scores_do_not_depend_on_how_the_work_is_cut(monkeypatch):
     assert stats_default["n_tasks"] > 0  # the default run does split trees
     for env in (
         {"PMX_SUPER": "4001"},                       # 8 super-chunks: control block, queue and arena restart eight times
+        {"PMX_SUPER": "4001", "PMX_OVERLAP": "2"},   # ... with every chunk's task rounds on the side stream beside the next chunk's ligand kernel
+        {"PMX_SUPER": "7000", "PMX_OVERLAP": "2", "PMX_LIG_SHARE": "0.3", "PMX_BUDGET": "32"},
         {"PMX_WAVES_PER_CU": "2"},                   # few persistent wavefronts: each builds and walks many ligands
         {"PMX_SLICE_KB": "8"},                       # most tables overflow the slices: large-slice pass
         {"PMX_SLICE_KB": "8", "PMX_BIG_SLICE_MB": "1", "PMX_BIG_TOTAL_MB": "64"},
@@ -227,7 +229,11 @@ def test_scores_do_not_depend_on_how_the_work_is_cut(monkeypatch):
         {"PMX_TREE_FLAGS": "8192"},                  # the walkers of a split ligand do not trade maxima while they run
         {"PMX_TREE_FLAGS": "4096"},                  # children with fewer than 5 matches are never bound-tested (walked, not probed)
         {"PMX_TREE_FLAGS": "2048"},                  # children visited first to last instead of largest bound first
-        {"PMX_TREE_FLAGS": "2048", "PMX_BUDGET": "16", "PMX_MIN_LEVELS": "0"},                   # children tested against the per-level bound instead of their own                   # a ligand's subtrees spread over the queue shards instead of kept in one
+        {"PMX_TREE_FLAGS": "2048", "PMX_BUDGET": "16", "PMX_MIN_LEVELS": "0"},
+        {"PMX_TREE_FLAGS": "1024"},                  # no path-aware bound test (children tested against their W bound only)
+        {"PMX_TREE_FLAGS": "1024", "PMX_BUDGET": "16", "PMX_MIN_LEVELS": "0"},
+        {"PMX_PATH_KB": "4"},                        # path sums of most ligands do not fit the wave's buffer: those do without the test
+        {"PMX_PATH_KB": "4", "PMX_BUDGET": "32"},                   # children tested against the per-level bound instead of their own                   # a ligand's subtrees spread over the queue shards instead of kept in one
     ):
         with monkeypatch.context() as mp:
             for k, v in env.items():
