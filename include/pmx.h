@@ -110,10 +110,10 @@ int pmx_library_destroy(pmx_library *lib);
  * Everything is enqueued and the call returns: no device-to-host read, no synchronisation, no helper thread (a
  * synchronisation happens only when a cached work buffer has to grow). The work is ordered on `stream`: per chunk of ligands
  * (PMX_SUPER) the ligand kernel (score tables in per-wavefront slices + tree search within a pass budget), the same for
- * ligands with larger tables, a fixed number of task rounds for the subtrees of over-budget trees, finalize. With more than
- * one chunk the rounds of a chunk run on a side stream that the workspace owns, beside the next chunk's ligand kernel: they
- * start behind an event recorded on `stream` and `stream` waits for their last event before the call's work counts as done,
- * so a caller sees one stream-ordered operation. Work buffers are kept per (device, stream), about 40 GB at the defaults
+ * ligands with larger tables, a fixed number of task rounds for the subtrees of over-budget trees, finalize. With
+ * PMX_OVERLAP set and more than one chunk, the rounds of a chunk run on a side stream that the workspace owns, beside the
+ * next chunk's ligand kernel: they start behind an event recorded on `stream` and `stream` waits for their last event before
+ * the call's work counts as done, so a caller sees one stream-ordered operation either way. Work buffers are kept per (device, stream), about 41 GB at the defaults
  * (PMX_ARENA_MB, PMX_TASKQ_MB: per buffer set, two sets); the table arenas shrink when device memory is short - a smaller
  * arena is slower, never wrong. PMX_LIGAND_TOO_LARGE is reported for a ligand whose tables exceed a whole arena; a ligand
  * that merely found the arena full of other ligands' tables is taken again with the arena empty.
