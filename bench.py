@@ -338,6 +338,9 @@ def main():
                 "walker_passes_per_ligand": prof["n_passes"] / max(n_lig, 1),
                 "table_items_per_ligand_conformer": prof["n_items"] * (64 // 8 if args.conformers == 8 else 1) / max(n_lig, 1),
                 "queued_subtrees_per_ligand": prof["n_tasks"] / max(n_lig, 1),
+                "path_bound_tests_per_ligand": prof["n_path_bounds"] / max(n_lig, 1),
+                "children_dropped_by_path_bound_per_ligand": prof["n_path_drops"] / max(n_lig, 1),
+                "probe_passes_per_ligand": prof["n_probe_passes"] / max(n_lig, 1),
                 "walks_over_budget_per_ligand": prof["n_heavy"] / max(n_lig, 1),
                 "ligands_with_tables_beyond_a_slice": prof["n_slice_overflow"],
                 "longest_walk_passes": prof["max_passes"],

@@ -1932,7 +1932,8 @@ __device__ __forceinline__ bool prepare_walk(const ScreenParams &p, unsigned cha
     w.nl = nl;
     w.ksumtot = ksumtot;
     // path_bound() keeps a row of pair sums per candidate and match count in the wave's buffer: used when they fit
-    w.path_on = cand_bounds<G>() && !(p.flags & (4u | 1024u)) && (uint64_t)(nl + 1) * ksumtot * G * 4u <= (uint64_t)p.pa_bytes;
+    // (and the table word X holds a pair entry number in 20 bits)
+    w.path_on = cand_bounds<G>() && !(p.flags & (4u | 1024u)) && (uint64_t)(nl + 1) * ksumtot * G * 4u <= (uint64_t)p.pa_bytes && T < (1u << 20);
     {
         const int kl = lane < nl ? (int)H->k[lane] : 0, knext = lane + 1 < nl ? (int)H->k[lane + 1] : 0;
         const int tci = nl - 3 - lane;

@@ -1,5 +1,6 @@
 #!/bin/bash
-OUT=gpurun_out/r4full
+# Run on the GPU box (gpurun -- bash tools/gpu_suite.sh): the whole -m gpu suite under time limits, the smoke entry, one bench line.
+OUT=gpurun_out/suite
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
