@@ -17,13 +17,17 @@
 //     169) Gaussian terms. The discrete part of match_utils.py - `num_pass < num_match * 0.5` (:61) - is NOT approximated:
 //     the set of distances where at least half of the model node pairs lie within 2 sigma is a union of float intervals
 //     computed exactly on the host when the model is created (pmx_api.hip, fn_windows) and stored with the cells; cells
-//     where that set is not one interval are flagged and counted term by term on the device.
+//     where that set is not one interval are flagged and counted term by term on the device. Cells whose polynomial is not
+//     accurate relative to the function's own (tail) value are flagged too, and evaluated term by term in self entries
+//     (FnCell, exact_value). The node distances of the cluster pair in work are staged once in LDS (build_tables).
 //   * tree phase: ONE depth-first walker per wavefront with wave-uniform control (scalar registers, scalar branches);
 //     a slot evaluates one candidate child of the current frame, so that a frame's children - their conformer
 //     masks, float64 totals and bound tests - are one pass of independent loads. The walker's stack lives in lane-indexed
-//     registers (v_readlane / v_writelane), the float64 path totals in 1.3 KB of LDS; nothing is spilled.
+//     registers (v_readlane / v_writelane), the float64 path totals in 1.3 KB of LDS. Children are tested against a
+//     per-candidate bound (build_bounds) and, before the walker enters one, against the bound its actual path gives
+//     (path_bound): 60 frames per ligand on the bench library where the reference's search has 11 300 nodes.
 //
-// Memory. The score tables of a ligand (S, P, search bounds R; 11 KB on average) are written to a per-wavefront slice of
+// Memory. The score tables of a ligand (S, P, search bounds R / W / OB; 15 KB on average) are written to a per-wavefront slice of
 // global memory and read back by the same wavefront: they stay in the CU's L1 / the XCD's L2 and are overwritten by the
 // wave's next ligand - there is no per-chunk table arena, no size pass, no host read. Ligands whose tables exceed the
 // slice, and trees that run over their budget, move to a bump-allocated arena: over-budget walkers append the open
