@@ -66,13 +66,15 @@ struct FnTable {
 
 // Header of one ligand's tables, in a wave's slice or in the arena:
 //   [RecHeader][best u64[G]][S float[ksumtot][G]][P float[T][G]][R double[nl + 1][G]][W double[ksumtot][G]][V mask[T]]
-//   [OB float[nl][ksumtot][G]][X u32[nl][ksumtot]]                                (where per-candidate bounds exist)
+//   [OB float[nl][ksumtot][G]][LV u8[ksumtot]]                                    (where per-candidate bounds exist)
 // OB[f][x] for a candidate x = (l, b') of a level l > f: S[l][b'] + sum_{f < j < l} max(0, max_a P[(j, a), (l, b')]), rounded up - what
 // (l, b') can add to a leaf total apart from its pair entries with the matches on the path down to level f (path_bound()).
-// X[f][x] = entry((f, 0) -> x) | k_l << 20 | l << 27: the pair entry of a candidate b of level f with x is X[f][x] + b * k_l.
+// LV[x] = the level of candidate x.
 // V[e] = the conformers c with P[e][c] > 0 (one bit per conformer, max(G, 8) / 8 bytes per entry): what decides which
 // children of a tree node exist (tree.py:78-84), read with the lanes spread over candidates.
-// Pair entry ((i, a), (j, b)), i < j: rowbase[i] + k[i] * (ksum[j] - ksum[i + 1]) + a * k[j] + b.
+// Pair entry of (i, a) with a candidate x = ksum[j] + b of a deeper level j: rowbase[i] + a * nd_i + (x - ksum[i + 1]), nd_i = ksumtot -
+// ksum[i + 1] the candidates below level i: the entries of (i, a) with ALL deeper candidates are one contiguous run, so the row of a
+// match on the path against any deeper candidate x is (a number fixed per match) + x - what the walker's passes and path_bound() read.
 struct RecHeader {
     uint32_t lig; // ligand index relative to the call's `first`
     uint32_t nl, T, ksumtot;
@@ -128,7 +130,7 @@ template <int G>
 __host__ __device__ inline uint64_t rec_bytes(uint32_t ksumtot, uint32_t T, uint32_t nl) {
     return (uint64_t)rec_s_off<G>() + round16((uint64_t)ksumtot * G * 4) + round16((uint64_t)T * G * 4) + (uint64_t)(nl + 1) * G * 8 +
            (cand_bounds<G>() ? (uint64_t)ksumtot * G * 8 : 0ull) + round16((uint64_t)T * vmask_bytes<G>()) +
-           (cand_bounds<G>() ? (uint64_t)nl * ksumtot * G * 4 + round16((uint64_t)nl * ksumtot * 4) : 0ull);
+           (cand_bounds<G>() ? (uint64_t)nl * ksumtot * G * 4 + round16((uint64_t)ksumtot) : 0ull);
 }
 
 // A subtree handed to the task queue: its root has >= 5 matches (see walk()).
@@ -458,7 +460,7 @@ struct Walk {
     bool path_on = false; // the job's tables fit the wave's path-sum buffer: path_bound() may be used
     int hk, hks, hrow; // lane l: k[l], ksum[l], rowbase[l]
     // path: lane q holds match q
-    int matRB = 0, matKA = 0; // rowbase[j] - k_j * ksum[j + 1] | k_j | a << 8 | j << 16
+    int matB = 0, matKA = 0; // entry(match, x) - x = rowbase[j] + a * nd_j - ksum[j + 1] | a << 8 | j << 16
     // stack: lane f holds frame f
     int stA = 0, stB = 0, stC = 0; // mask lo, mask hi, nb | mx << 8 | flags << 16 | nm << 24
     double best = 0.0, flushed = 0.0;
@@ -466,6 +468,12 @@ struct Walk {
     // current frame (its state is in lane f of the stack like every other frame's; a walk can be interrupted and resumed, see kOverBudget)
     int f = 0, f0 = 0;
 };
+// entry((f, b) -> x) - x for a match (f, b): what lane q of Walk::matB holds for match q
+template <int G>
+__device__ __forceinline__ int match_base(const Walk<G> &w, int f, int b) {
+    const int k1 = rl(w.hks, f + 1);
+    return rl(w.hrow, f) + b * ((int)w.ksumtot - k1) - k1;
+}
 constexpr int kOverBudget = -1;
 template <int G>
 __host__ __device__ constexpr uint64_t group_mask() {
@@ -533,11 +541,8 @@ __device__ __forceinline__ bool probe(Walk<G> &w, int f, int nm, int cand, uint6
     if (nm + 1 >= 5) return true;
     // enter the child
     const int fbase = f;
-    {
-        const int kf = rl(w.hk, f) & 255;
-        w.matRB = wl(w.matRB, nm, rl(w.hrow, f) - kf * rl(w.hks, f + 1));
-        w.matKA = wl(w.matKA, nm, kf | (cand << 8) | (f << 16));
-    }
+    w.matB = wl(w.matB, nm, match_base(w, f, cand));
+    w.matKA = wl(w.matKA, nm, (cand << 8) | (f << 16));
     ++f;
     ++nm;
     uint64_t mask = cmask;
@@ -551,7 +556,7 @@ __device__ __forceinline__ bool probe(Walk<G> &w, int f, int nm, int cand, uint6
             const int kf = rl(w.hk, f) & 255, ksf = rl(w.hks, f);
             bool descended = false;
             if (nb < kf) {
-                const int ebv = w.matRB + __mul24(w.matKA & 255, ksf) + __mul24((w.matKA >> 8) & 255, kf);
+                const int ebv = w.matB + ksf;
                 // every candidate of the level at once, lane l <-> candidate l: which exist as children - some conformer of
                 // the frame has every pair entry > 0 - is one AND of V masks per matched ancestor (no table row is read)
                 constexpr uint32_t VB = vmask_bytes<G>();
@@ -578,8 +583,8 @@ __device__ __forceinline__ bool probe(Walk<G> &w, int f, int nm, int cand, uint6
                     w.stA = wl(w.stA, f, (int)(uint32_t)mask);
                     if (G > 32) w.stB = wl(w.stB, f, (int)(uint32_t)(mask >> 32));
                     w.stC = wl(w.stC, f, nb | (mx << 8) | ((int)flags << 16) | (nm << 24));
-                    w.matRB = wl(w.matRB, nm, rl(w.hrow, f) - kf * rl(w.hks, f + 1));
-                    w.matKA = wl(w.matKA, nm, kf | (bsel << 8) | (f << 16));
+                    w.matB = wl(w.matB, nm, match_base(w, f, bsel));
+                    w.matKA = wl(w.matKA, nm, (bsel << 8) | (f << 16));
                     mask = (uint64_t)(uint32_t)rl((int)(uint32_t)m, bsel);
                     if (G > 32) mask |= (uint64_t)(uint32_t)rl((int)(uint32_t)(m >> 32), bsel) << 32;
                     ++f;
@@ -638,35 +643,35 @@ __device__ __forceinline__ bool path_bound(const Walk<G> &w, const ScreenParams 
     const int nl = w.nl;
     const uint32_t ksumtot = w.ksumtot;
     const uint32_t x0 = (uint32_t)rl(w.hks, f + 1); // first candidate of the levels below f
-    const float *Pf = reinterpret_cast<const float *>(w.Pb);
+    const float *Pf = reinterpret_cast<const float *>(w.Pb) + (long)match_base<G>(w, f, bsel) * G; // Y's entries: Pf[x * G + c] (the base may be negative, base + x is not)
     const float *OB = reinterpret_cast<const float *>(w.OBb) + (size_t)f * ksumtot * G;
-    const uint32_t *X = reinterpret_cast<const uint32_t *>(w.OBb + (size_t)nl * ksumtot * G * 4u) + (size_t)f * ksumtot;
+    const unsigned char *LV = w.OBb + (size_t)nl * ksumtot * G * 4u;
     const float *pin = pa + (size_t)nm * ksumtot * G;
     float *pout = pa + (size_t)(nm + 1) * ksumtot * G;
     for (int i = lane; i < (nl - f - 1) * G; i += 64) ub[(f + 1) * G + i] = 0.f;
     lds_sync();
-    // two windows of SLOTS candidates per trip: their table words, bounds and path sums go out together, then their pair rows
+    // two windows of SLOTS candidates per trip, everything of a window in one round of loads (the entries of Y with the deeper
+    // candidates are one contiguous run: no lookup in front of the pair rows)
     for (uint32_t x = x0; x < ksumtot; x += 2 * SLOTS) {
-        uint32_t xx[2], xw[2];
+        uint32_t xx[2], lv[2];
         float ob[2], have[2], pv[2];
         bool on[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             on[u] = x + (uint32_t)(u * SLOTS + s) < ksumtot;
             xx[u] = on[u] ? x + (uint32_t)(u * SLOTS + s) : x0;
-            xw[u] = X[xx[u]];
+            lv[u] = LV[xx[u]];
             ob[u] = OB[(size_t)xx[u] * G + c];
             have[u] = nm ? pin[(size_t)xx[u] * G + c] : 0.f;
+            pv[u] = Pf[(size_t)xx[u] * G + c];
         }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) pv[u] = Pf[(size_t)((xw[u] & 0xfffffu) + (uint32_t)bsel * ((xw[u] >> 20) & 127u)) * G + c];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const float sum = pv[u] > 0.f ? have[u] + pv[u] : -__builtin_inff(); // (-inf stays -inf: a candidate out for this conformer stays out)
             if (on[u]) {
                 pout[(size_t)xx[u] * G + c] = sum;
                 const float v = fmaxf(sum + ob[u], 0.f); // (a NaN self entry - zero weights - can raise no maximum: 0)
-                atomicMax(reinterpret_cast<unsigned int *>(ub) + (xw[u] >> 27) * G + (uint32_t)c, __float_as_uint(v));
+                atomicMax(reinterpret_cast<unsigned int *>(ub) + lv[u] * G + (uint32_t)c, __float_as_uint(v));
             }
         }
     }
@@ -687,20 +692,16 @@ __device__ __forceinline__ void path_sums_of_root(const Walk<G> &w, float *pa, i
     const int lane = lane_id();
     const int s = lane / G, c = lane % G;
     const uint32_t ksumtot = w.ksumtot;
-    const float *Pf = reinterpret_cast<const float *>(w.Pb);
-    const uint32_t *Xall = reinterpret_cast<const uint32_t *>(w.OBb + (size_t)w.nl * ksumtot * G * 4u);
     for (int q = 0; q < nm0; ++q) {
-        const int ka = rl(w.matKA, q);
-        const uint32_t aq = ((uint32_t)ka >> 8) & 255u, jq = ((uint32_t)ka >> 16) & 255u;
+        const uint32_t jq = ((uint32_t)rl(w.matKA, q) >> 16) & 255u;
         const uint32_t x0 = (uint32_t)rl(w.hks, (int)jq + 1);
-        const uint32_t *X = Xall + (size_t)jq * ksumtot;
+        const float *Pq = reinterpret_cast<const float *>(w.Pb) + (long)rl(w.matB, q) * G;
         const float *pin = pa + (size_t)q * ksumtot * G;
         float *pout = pa + (size_t)(q + 1) * ksumtot * G;
         for (uint32_t x = x0; x < ksumtot; x += SLOTS) {
             const bool on = x + (uint32_t)s < ksumtot;
             const uint32_t xx = on ? x + (uint32_t)s : x0;
-            const uint32_t xw = X[xx];
-            const float pv = Pf[(size_t)((xw & 0xfffffu) + aq * ((xw >> 20) & 127u)) * G + c];
+            const float pv = Pq[(size_t)xx * G + c];
             const float have = q ? pin[(size_t)xx * G + c] : 0.f;
             if (on) pout[(size_t)xx * G + c] = pv > 0.f ? have + pv : -__builtin_inff();
         }
@@ -789,7 +790,7 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
             double pooled = 0.0;
             if (bounded || ordered0) pooled = __longlong_as_double((long long)pool[c]);
             // pair-table rows of the matched ancestors against level f: lane q
-            const int ebv = w.matRB + __mul24(w.matKA & 255, ksf) + __mul24((w.matKA >> 8) & 255, kf);
+            const int ebv = w.matB + ksf;
             // A frame with more candidates than slots is *filtered* first: which candidates exist as children - some conformer of
             // the frame has every pair entry > 0 - is read off the V masks with the lanes spread over candidates, and the passes
             // then take the existing candidates only, SLOTS at a time (most candidates do not exist: without this a frame of a
@@ -937,7 +938,7 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
                     PMX_COUNT(0, 1);
                     const int f1 = f + 1, k1 = rl(w.hk, f1) & 255, ks1 = rl(w.hks, f1);
                     tch[lane] = t; // the children's totals, read back per child by every slot
-                    const int ebv1 = w.matRB + __mul24(w.matKA & 255, ks1) + __mul24((w.matKA >> 8) & 255, k1);
+                    const int ebv1 = w.matB + ks1;
                     const bool on1 = s < k1;
                     const uint32_t bo1 = on1 ? lane_off : (uint32_t)c * 4u;
                     const float self1 = *reinterpret_cast<const float *>(Sb + (((uint32_t)ks1 << PSH) + bo1));
@@ -950,7 +951,7 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
                             base_sum += (double)v;
                         });
                     // entry((f, b) -> (f + 1, b')) = rowbase[f] + b * k1 + b'
-                    const uint32_t row_f = (uint32_t)rl(w.hrow, f);
+                    const uint32_t row_f = (uint32_t)rl(w.hrow, f), nd_f = w.ksumtot - (uint32_t)ks1; // entry((f, b) -> (f + 1, b')) = rowbase[f] + b * nd_f + b'
                     lds_sync();
                     unsigned long long left = ab;
                     while (left) {
@@ -958,7 +959,7 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
                         left &= ~(GM << (sb * G));
                         const uint64_t cm = (vb >> (sb * G)) & GM;
                         const double tb = tch[sb * G + c];
-                        const float pfb = *reinterpret_cast<const float *>(Pb + ((row_f + (uint32_t)rl(bvec, sb * G) * (uint32_t)k1) << PSH) + bo1);
+                        const float pfb = *reinterpret_cast<const float *>(Pb + ((row_f + (uint32_t)rl(bvec, sb * G) * nd_f) << PSH) + bo1);
                         const bool v1 = base_valid && pfb > 0.f && ((cm >> c) & 1ull);
                         const double t1 = (tb + (double)self1) + (base_sum + (double)pfb);
                         const bool any1 = __ballot(v1) != 0;
@@ -1094,9 +1095,8 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
                     w.stA = wl(w.stA, f + 1, (int)(uint32_t)cmask);
                     if (G > 32) w.stB = wl(w.stB, f + 1, (int)(uint32_t)(cmask >> 32));
                     if (ORD) w.stB = wl(wl(w.stB, f, (int)rem), f + 1, -1);
-                    // entry(this match, level f', b') = rowbase[f] + k_f * (ksum[f'] - ksum[f + 1]) + b * k_f' + b'
-                    w.matRB = wl(w.matRB, nm, rl(w.hrow, f) - kf * rl(w.hks, f + 1));
-                    w.matKA = wl(w.matKA, nm, kf | (bsel << 8) | (f << 16));
+                    w.matB = wl(w.matB, nm, match_base(w, f, bsel));
+                    w.matKA = wl(w.matKA, nm, (bsel << 8) | (f << 16));
                     ++f;
                     ++w.frames;
                     PMX_COUNT(5, 1);
@@ -1463,6 +1463,7 @@ __device__ __forceinline__ void build_tables(const ScreenParams &p, unsigned cha
     const uint16_t *ksum = reinterpret_cast<const uint16_t *>(lds + kOffKsum), *ncoff = reinterpret_cast<const uint16_t *>(lds + kOffNcoff);
     const uint8_t *cand = lds + ws.off_cand, *lcnt = lds + ws.off_lcnt;
     const uint16_t *nc = reinterpret_cast<const uint16_t *>(lds + ws.off_nc);
+    const uint32_t *rowbase_l = reinterpret_cast<const uint32_t *>(lds + kOffRow);
     GlobalFloats xyz = (GlobalFloats)uniptr(r.xyz);
     float *St = reinterpret_cast<float *>(rec + rec_s_off<G>());
     float *Pt = reinterpret_cast<float *>(rec + rec_p_off<G>(L.ksumtot));
@@ -1489,9 +1490,9 @@ __device__ __forceinline__ void build_tables(const ScreenParams &p, unsigned cha
         }
         lds_sync();
     };
-    uint32_t pair_base = 0;
     for (int i = 0; i < nl; ++i) {
         const int si = uni(lstart[i]), ni = uni(lend[i]) - si, ki = uni(lk[i]), nci = uni(ncoff[i]), ksi = uni(ksum[i]);
+        const uint32_t row_i = (uint32_t)uni((int)rowbase_l[i]), nd_i = L.ksumtot - (uint32_t)uni(ksum[i + 1]);
         // ---- self table S[i][a] (match_utils.py:77-122): node pairs u < v of the cluster
         const bool self_staged = ni > 1 && ni * ni <= dcap;
         if (self_staged) stage_distances(si, ni, si, ni);
@@ -1523,6 +1524,7 @@ __device__ __forceinline__ void build_tables(const ScreenParams &p, unsigned cha
             const float lsize = size_i + size_j;                                                  // :241
             const int E = ki * kj;
             const float inv_kj = 1.0f / (float)kj;
+            const uint32_t off_j = (uint32_t)(uni(ksum[j]) - uni(ksum[i + 1])); // (j's candidates inside the run of (i, a)'s entries)
             // Which entries pass the cluster-distance prefilter (graph_match.py:263-268: an entry is computed if some conformer
             // passes) is settled first, 64 entries at a time with the lanes spread over *entries* - for a model of 30-40 clusters
             // most of the k_i k_j entries of a level pair fail, and walking them eight at a time was most of the table phase.
@@ -1549,14 +1551,14 @@ __device__ __forceinline__ void build_tables(const ScreenParams &p, unsigned cha
                     pass = pass && in;
                     pbal = __ballot(pass);
                     if (in && !pass) {
-                        float *row = Pt + (size_t)(pair_base + (uint32_t)e) * G;
+                        float *row = Pt + (size_t)(row_i + (uint32_t)sa * nd_i + off_j + (uint32_t)sb) * G;
                         if (G >= 4) {
 #pragma unroll
                             for (int g = 0; g < G; g += 4) *reinterpret_cast<float4 *>(row + g) = make_float4(-1.f, -1.f, -1.f, -1.f);
                         } else {
                             for (int g = 0; g < G; ++g) row[g] = -1.f;
                         }
-                        unsigned char *ve = Vt + (size_t)(pair_base + (uint32_t)e) * vmask_bytes<G>();
+                        unsigned char *ve = Vt + (size_t)(row_i + (uint32_t)sa * nd_i + off_j + (uint32_t)sb) * vmask_bytes<G>();
                         for (uint32_t g = 0; g < vmask_bytes<G>(); ++g) ve[g] = 0;
                     }
                     if (pass) {
@@ -1571,11 +1573,12 @@ __device__ __forceinline__ void build_tables(const ScreenParams &p, unsigned cha
                     const int sa = (int)(((float)e + 0.5f) * inv_kj), sb = e - sa * kj;
                     const int L1 = lcnt[i * ws.kp + sa], L2 = lcnt[j * ws.kp + sb]; // graph_match.py:164-171
                     const float value = 2 * fails <= L1 * L2 ? acc : -1.f;
-                    if (on) Pt[(size_t)(pair_base + (uint32_t)e) * G + c] = value;
+                    const uint32_t pe = row_i + (uint32_t)sa * nd_i + off_j + (uint32_t)sb; // entry((i, sa) -> (j, sb))
+                    if (on) Pt[(size_t)pe * G + c] = value;
                     const unsigned long long pos = __ballot(on && value > 0.f);
                     if (on && c == 0) {
                         const unsigned long long m = (pos >> (s * G)) & GM;
-                        unsigned char *ve = Vt + (size_t)(pair_base + (uint32_t)e) * vmask_bytes<G>();
+                        unsigned char *ve = Vt + (size_t)pe * vmask_bytes<G>();
                         if (G <= 8) *ve = (unsigned char)m;
                         else if (G == 16) *reinterpret_cast<uint16_t *>(ve) = (uint16_t)m;
                         else if (G == 32) *reinterpret_cast<uint32_t *>(ve) = (uint32_t)m;
@@ -1660,7 +1663,6 @@ __device__ __forceinline__ void build_tables(const ScreenParams &p, unsigned cha
                 }
                 lds_sync(); // (the list is rewritten by the next chunk)
             }
-            pair_base += (uint32_t)E;
         }
     }
 }
@@ -1682,7 +1684,7 @@ __device__ __forceinline__ void build_bounds(const ScreenParams &p, unsigned cha
     double *Rt = reinterpret_cast<double *>(rec + rec_r_off<G>(L.ksumtot, L.T));
     double *Wt = reinterpret_cast<double *>(rec + rec_w_off<G>(L.ksumtot, L.T, (uint32_t)L.nl));
     float *OBt = reinterpret_cast<float *>(rec + rec_ob_off<G>(L.ksumtot, L.T, (uint32_t)L.nl));
-    uint32_t *CIt = reinterpret_cast<uint32_t *>(rec + rec_ci_off<G>(L.ksumtot, L.T, (uint32_t)L.nl));
+    unsigned char *LVt = rec + rec_ci_off<G>(L.ksumtot, L.T, (uint32_t)L.nl);
     const int nl = L.nl;
     if (p.flags & 4) { // debug: nothing is ever dropped
         for (int l = s; l <= nl; l += SLOTS) Rt[(size_t)l * G + c] = __builtin_inf();
@@ -1701,20 +1703,19 @@ __device__ __forceinline__ void build_bounds(const ScreenParams &p, unsigned cha
             double v = (double)St[(size_t)(ksl + b) * G + c];
             for (int j = l - 1; j >= 0; --j) {
                 const int kj = uni(lk[j]);
-                const uint32_t e0 = (uint32_t)uni((int)rowbase[j]) + (uint32_t)kj * (uint32_t)(ksl - uni((int)ksum[j + 1])) + (uint32_t)b;
-                if (cand_bounds<G>()) {
-                    OBt[((size_t)j * L.ksumtot + (size_t)(ksl + b)) * G + c] = float_up(v);
-                    if (c == 0) CIt[(size_t)j * L.ksumtot + (size_t)(ksl + b)] = e0 | ((uint32_t)kl << 20) | ((uint32_t)l << 27);
-                }
+                const uint32_t nd_j = L.ksumtot - (uint32_t)uni((int)ksum[j + 1]);
+                const uint32_t e0 = (uint32_t)uni((int)rowbase[j]) + (uint32_t)(ksl - uni((int)ksum[j + 1])) + (uint32_t)b; // entry((j, 0) -> (l, b))
+                if (cand_bounds<G>()) OBt[((size_t)j * L.ksumtot + (size_t)(ksl + b)) * G + c] = float_up(v);
                 float m = 0.f;
                 for (int a = 0; a < kj; ++a) {
-                    const float pv = Pt[(size_t)(e0 + (uint32_t)a * (uint32_t)kl) * G + c];
+                    const float pv = Pt[(size_t)(e0 + (uint32_t)a * nd_j) * G + c];
                     m = pv > m ? pv : m;
                 }
                 v += (double)m;
             }
             if (cand_bounds<G>()) {
                 Wt[(size_t)(ksl + b) * G + c] = v; // base(l, b), replaced by the candidate's own bound below
+                if (c == 0) LVt[ksl + b] = (unsigned char)l;
             }
             u = v > u ? v : u;
         }
@@ -1755,7 +1756,8 @@ __device__ __forceinline__ void build_bounds(const ScreenParams &p, unsigned cha
             double acc = 0.0;
             for (int l = f + 1; l < nl; ++l) {
                 const int kl = uni(lk[l]), ksl = uni(ksum[l]);
-                const uint32_t e_fl = (uint32_t)uni((int)rowbase[f]) + (uint32_t)kf * (uint32_t)(ksl - uni((int)ksum[f + 1]));
+                const uint32_t nd_f = L.ksumtot - (uint32_t)uni((int)ksum[f + 1]);
+                const uint32_t e_fl = (uint32_t)uni((int)rowbase[f]) + (uint32_t)(ksl - uni((int)ksum[f + 1])); // entry((f, 0) -> (l, 0))
                 double u = 0.0;
                 for (int b1 = 0; b1 < kl; ++b1) {
                     const double base = Wt[(size_t)(ksl + b1) * G + c];
@@ -1764,7 +1766,7 @@ __device__ __forceinline__ void build_bounds(const ScreenParams &p, unsigned cha
                     float mf = 0.f, pb = 0.f;
                     for (int a0 = 0; a0 < kf; a0 += SLOTS) {
                         const int a = a0 + s;
-                        const float pv = a < kf ? Pt[(size_t)(e_fl + (uint32_t)a * (uint32_t)kl + (uint32_t)b1) * G + c] : 0.f;
+                        const float pv = a < kf ? Pt[(size_t)(e_fl + (uint32_t)a * nd_f + (uint32_t)b1) * G + c] : 0.f;
                         mf = pv > mf ? pv : mf;
                         pb = a0 == b0 ? pv : pb;
                     }
@@ -1951,9 +1953,8 @@ __device__ __forceinline__ bool prepare_walk(const ScreenParams &p, unsigned cha
     const int nm0 = uni((int)th->nm), f0 = uni((int)th->f0);
     if (lane < nm0) {
         const int j = th->path[2 * lane], a = th->path[2 * lane + 1];
-        const int kj = H->k[j];
-        w.matRB = (int)H->rowbase[j] - kj * (int)H->ksum[j + 1];
-        w.matKA = kj | (a << 8) | (j << 16);
+        w.matB = (int)H->rowbase[j] + a * ((int)ksumtot - (int)H->ksum[j + 1]) - (int)H->ksum[j + 1];
+        w.matKA = (a << 8) | (j << 16);
     }
     const unsigned long long *gbest = reinterpret_cast<const unsigned long long *>(rec + sizeof(RecHeader));
     if (s == 0) {
