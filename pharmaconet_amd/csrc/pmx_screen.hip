@@ -488,7 +488,11 @@ constexpr double kBoundSlack = 1.0 + 1e-9;
 #ifndef PMX_PATH_MIN_LEVELS
 #define PMX_PATH_MIN_LEVELS 3
 #endif
-constexpr int kPathMinLevels = PMX_PATH_MIN_LEVELS; // path_bound() is asked where the frame's level and at least this many - 1 more lie below // covers the float64 rounding of the sums the bound is compared with
+constexpr int kPathMinLevels = PMX_PATH_MIN_LEVELS;
+#ifndef PMX_PATH_WINDOWS
+#define PMX_PATH_WINDOWS 2
+#endif
+constexpr int kPathWindows = PMX_PATH_WINDOWS; // windows of 64 / G candidates whose loads go out together in path_bound() // path_bound() is asked where the frame's level and at least this many - 1 more lie below // covers the float64 rounding of the sums the bound is compared with
 
 
 // Row loops of the walker: `load(q)` for q = 0 .. n - 1 go out kRowBatch at a time and `use(value)` takes them in order; what is
@@ -650,14 +654,14 @@ __device__ __forceinline__ bool path_bound(const Walk<G> &w, const ScreenParams 
     float *pout = pa + (size_t)(nm + 1) * ksumtot * G;
     for (int i = lane; i < (nl - f - 1) * G; i += 64) ub[(f + 1) * G + i] = 0.f;
     lds_sync();
-    // two windows of SLOTS candidates per trip, everything of a window in one round of loads (the entries of Y with the deeper
+    // kPathWindows windows of SLOTS candidates per trip, everything of a window in one round of loads (the entries of Y with the deeper
     // candidates are one contiguous run: no lookup in front of the pair rows)
-    for (uint32_t x = x0; x < ksumtot; x += 2 * SLOTS) {
-        uint32_t xx[2], lv[2];
-        float ob[2], have[2], pv[2];
-        bool on[2];
+    for (uint32_t x = x0; x < ksumtot; x += kPathWindows * SLOTS) {
+        uint32_t xx[kPathWindows], lv[kPathWindows];
+        float ob[kPathWindows], have[kPathWindows], pv[kPathWindows];
+        bool on[kPathWindows];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < kPathWindows; ++u) {
             on[u] = x + (uint32_t)(u * SLOTS + s) < ksumtot;
             xx[u] = on[u] ? x + (uint32_t)(u * SLOTS + s) : x0;
             lv[u] = LV[xx[u]];
@@ -666,7 +670,7 @@ __device__ __forceinline__ bool path_bound(const Walk<G> &w, const ScreenParams 
             pv[u] = Pf[(size_t)xx[u] * G + c];
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < kPathWindows; ++u) {
             const float sum = pv[u] > 0.f ? have[u] + pv[u] : -__builtin_inff(); // (-inf stays -inf: a candidate out for this conformer stays out)
             if (on[u]) {
                 pout[(size_t)xx[u] * G + c] = sum;
