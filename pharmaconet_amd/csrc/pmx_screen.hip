@@ -66,10 +66,12 @@ struct FnTable {
 
 // Header of one ligand's tables, in a wave's slice or in the arena:
 //   [RecHeader][best u64[G]][S float[ksumtot][G]][P float[T][G]][R double[nl + 1][G]][W double[ksumtot][G]][V mask[T]]
-//   [OB float[nl][ksumtot][G]][LV u8[ksumtot]]                                    (where per-candidate bounds exist)
+//   [OB float[nl][ksumtot][G]][LV u8[ksumtot]][DP u8[ksumtot]]                    (where per-candidate bounds exist)
 // OB[f][x] for a candidate x = (l, b') of a level l > f: S[l][b'] + sum_{f < j < l} max(0, max_a P[(j, a), (l, b')]), rounded up - what
 // (l, b') can add to a leaf total apart from its pair entries with the matches on the path down to level f (path_bound()).
 // LV[x] = the level of candidate x.
+// DP[x] = the longest chain of candidates of ascending levels that starts with x and in which every candidate has an entry
+// with some conformer > 0 against the one before it (V != 0): no path through x holds more matches from x on (probe()).
 // V[e] = the conformers c with P[e][c] > 0 (one bit per conformer, max(G, 8) / 8 bytes per entry): what decides which
 // children of a tree node exist (tree.py:78-84), read with the lanes spread over candidates.
 // Pair entry of (i, a) with a candidate x = ksum[j] + b of a deeper level j: rowbase[i] + a * nd_i + (x - ksum[i + 1]), nd_i = ksumtot -
@@ -130,7 +132,12 @@ template <int G>
 __host__ __device__ inline uint64_t rec_bytes(uint32_t ksumtot, uint32_t T, uint32_t nl) {
     return (uint64_t)rec_s_off<G>() + round16((uint64_t)ksumtot * G * 4) + round16((uint64_t)T * G * 4) + (uint64_t)(nl + 1) * G * 8 +
            (cand_bounds<G>() ? (uint64_t)ksumtot * G * 8 : 0ull) + round16((uint64_t)T * vmask_bytes<G>()) +
-           (cand_bounds<G>() ? (uint64_t)nl * ksumtot * G * 4 + round16((uint64_t)ksumtot) : 0ull);
+           (cand_bounds<G>() ? (uint64_t)nl * ksumtot * G * 4 + 2 * round16((uint64_t)ksumtot) : 0ull);
+}
+// (DP u8[ksumtot] follows LV: rec_ci_off + round16(ksumtot))
+template <int G>
+__host__ __device__ inline uint32_t rec_dp_off(uint32_t ksumtot, uint32_t T, uint32_t nl) {
+    return rec_ci_off<G>(ksumtot, T, nl) + (uint32_t)round16((uint64_t)ksumtot);
 }
 
 // A subtree handed to the task queue: its root has >= 5 matches (see walk()).
@@ -207,7 +214,7 @@ struct ScreenParams {
     uint32_t qcap;             // records per shard
     uint32_t budget;           // passes after which a walker starts handing subtrees to the queue
     uint32_t min_levels;       // only subtrees with at least this many levels below their root are queued
-    uint32_t flags;            // 2: never queue, 4: no bound test, 8: exact Gaussian terms instead of the tabulated functions
+    uint32_t flags;            // 2: never queue, 4: no bound test, 8: exact Gaussian terms instead of the tabulated functions, 32768: no chain lengths (probe())
     uint32_t max_nodes;        // of the library (sizes the LDS node tables)
     uint32_t last_round;       // task_kernel: never queue (walk every subtree to its end)
     uint32_t bound_cost; // per-candidate bounds are built when their cost estimate stays below this (build_bounds)
@@ -543,6 +550,14 @@ __device__ __forceinline__ bool probe(Walk<G> &w, int f, int nm, int cand, uint6
     const int nl = w.nl;
     const unsigned char *Vb = w.Vb;
     if (nm + 1 >= 5) return true;
+    // DP[x]: no chain of pairwise compatible candidates that starts with x holds more than DP[x] of them (chain_lengths()), so a
+    // node with 5 matches lies below a path of nm matches through x only if DP[x] >= 5 - nm. The child itself first, then every
+    // candidate the search would try: what they rule out is not there to find.
+    const unsigned char *DP = nullptr;
+    if constexpr (cand_bounds<G>()) {
+        DP = w.OBb + ((size_t)nl * w.ksumtot * G * 4u + (size_t)round16((uint64_t)w.ksumtot));
+        if (uni((int)DP[rl(w.hks, f) + cand]) < 5 - nm) return false;
+    }
     // enter the child
     const int fbase = f;
     w.matB = wl(w.matB, nm, match_base(w, f, cand));
@@ -564,8 +579,10 @@ __device__ __forceinline__ bool probe(Walk<G> &w, int f, int nm, int cand, uint6
                 // every candidate of the level at once, lane l <-> candidate l: which exist as children - some conformer of
                 // the frame has every pair entry > 0 - is one AND of V masks per matched ancestor (no table row is read)
                 constexpr uint32_t VB = vmask_bytes<G>();
-                const bool in = lane >= nb && lane < kf;
+                bool in = lane >= nb && lane < kf;
                 const uint32_t lo_ = (uint32_t)(lane < kf ? lane : 0) * VB;
+                int reach = 255;
+                if constexpr (cand_bounds<G>()) reach = DP[(uint32_t)ksf + (lane < kf ? (uint32_t)lane : 0u)];
                 auto vload = [&](int q) -> unsigned long long {
                     const unsigned char *ve = Vb + (uint32_t)rl(ebv, q) * VB + lo_;
                     if (G <= 8) return *ve;
@@ -575,6 +592,7 @@ __device__ __forceinline__ bool probe(Walk<G> &w, int f, int nm, int cand, uint6
                 };
                 unsigned long long m = mask;
                 for_rows(nm, vload, [&](unsigned long long v) { m &= v; });
+                in = in && reach >= 5 - nm;
                 const unsigned long long ex = __ballot(in && m != 0ull);
                 ++passes;
                 if (!ex) {
@@ -1671,12 +1689,51 @@ __device__ __forceinline__ void build_tables(const ScreenParams &p, unsigned cha
     }
 }
 
+// DP[x] of the record (see its layout): levels from the last one up, the entries of a level's candidates with all deeper
+// candidates - one contiguous run of V masks - read with the lanes spread over entries, the maxima taken in LDS (the walker's
+// children cache is idle here). A ligand with more candidates than that holds gets 255 everywhere: nothing is ruled out.
+template <int G>
+__device__ __forceinline__ void chain_lengths(const ScreenParams &p, unsigned char *lds, const WaveShape<G> &ws, const LevelInfo &L, unsigned char *rec) {
+    const int lane = lane_id();
+    const uint8_t *lk = lds + kOffK;
+    const uint16_t *ksum = reinterpret_cast<const uint16_t *>(lds + kOffKsum);
+    const uint32_t *rowbase = reinterpret_cast<const uint32_t *>(lds + kOffRow);
+    const unsigned char *Vt = rec + rec_v_off<G>(L.ksumtot, L.T, (uint32_t)L.nl);
+    unsigned char *DPt = rec + rec_dp_off<G>(L.ksumtot, L.T, (uint32_t)L.nl);
+    uint32_t *dpl = reinterpret_cast<uint32_t *>(lds + ws.off_tch);
+    const uint32_t cap = (ws.bytes - ws.off_tch) / 4u;
+    if (L.ksumtot > cap || (p.flags & (4u | 32768u))) {
+        for (uint32_t x = (uint32_t)lane; x < L.ksumtot; x += 64u) DPt[x] = 255;
+        return;
+    }
+    lds_sync();
+    for (uint32_t x = (uint32_t)lane; x < L.ksumtot; x += 64u) dpl[x] = 1u;
+    constexpr uint32_t VB = vmask_bytes<G>();
+    for (int j = L.nl - 2; j >= 0; --j) {
+        lds_sync(); // (the deeper levels' lengths are final)
+        const uint32_t kj = (uint32_t)uni(lk[j]), ksj = (uint32_t)uni((int)ksum[j]), ks1 = (uint32_t)uni((int)ksum[j + 1]);
+        const uint32_t nd = L.ksumtot - ks1, row = (uint32_t)uni((int)rowbase[j]);
+        const float inv_nd = 1.0f / (float)nd;
+        for (uint32_t e = (uint32_t)lane; e < kj * nd; e += 64u) {
+            const uint32_t a = (uint32_t)(((float)e + 0.5f) * inv_nd), xo = e - a * nd;
+            const unsigned char *ve = Vt + (size_t)(row + e) * VB;
+            uint32_t v;
+            if (VB == 1) v = *ve;
+            else v = *reinterpret_cast<const uint16_t *>(ve);
+            if (v) atomicMax(&dpl[ksj + a], dpl[ks1 + xo] + 1u);
+        }
+    }
+    lds_sync();
+    for (uint32_t x = (uint32_t)lane; x < L.ksumtot; x += 64u) DPt[x] = (unsigned char)dpl[x];
+    lds_sync();
+}
+
 // Upper bounds for the tree search: level l can add at most
 //   U[l][c] = max(0, max_b (S[l][b][c] + sum_{j < l} max(0, max_a P[(j, a), (l, b)][c])))
 // to a conformer's total whatever is picked on the other levels, so R[f][c] = sum_{l >= f} U[l][c] bounds everything the
 // levels f.. add. (The reported score only needs the per-conformer maximum over leaves, graph_match.py:103-109.)
 template <int G>
-__device__ __forceinline__ void build_bounds(const ScreenParams &p, unsigned char *lds, const LevelInfo &L, unsigned char *rec) {
+__device__ __forceinline__ void build_bounds(const ScreenParams &p, unsigned char *lds, const WaveShape<G> &ws, const LevelInfo &L, unsigned char *rec) {
     constexpr int SLOTS = 64 / G;
     const int lane = lane_id();
     const int s = lane / G, c = lane % G;
@@ -1690,6 +1747,7 @@ __device__ __forceinline__ void build_bounds(const ScreenParams &p, unsigned cha
     float *OBt = reinterpret_cast<float *>(rec + rec_ob_off<G>(L.ksumtot, L.T, (uint32_t)L.nl));
     unsigned char *LVt = rec + rec_ci_off<G>(L.ksumtot, L.T, (uint32_t)L.nl);
     const int nl = L.nl;
+    if (cand_bounds<G>()) chain_lengths<G>(p, lds, ws, L, rec);
     if (p.flags & 4) { // debug: nothing is ever dropped
         for (int l = s; l <= nl; l += SLOTS) Rt[(size_t)l * G + c] = __builtin_inf();
         if (cand_bounds<G>())
@@ -1896,7 +1954,7 @@ __device__ __forceinline__ unsigned char *prepare_ligand(const ScreenParams &p, 
     build_tables<G, EXACT>(p, lds, ws, r, L, rec, n_items, n_exact, n_exactv);
     wave_sync();
     const unsigned long long t_c = __builtin_amdgcn_s_memtime();
-    build_bounds<G>(p, lds, L, rec);
+    build_bounds<G>(p, lds, ws, L, rec);
     // ---- the root as a subtree record (in LDS): frame 0, no matches, every conformer, totals 0
     {
         unsigned char *tr = lds + ws.off_task;
