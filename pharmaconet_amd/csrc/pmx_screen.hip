@@ -1082,7 +1082,13 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
                             // the child with the largest W bound, against the bound its actual path gives (path_bound())
                             if (s == ss) tch[c] = t;
                             lds_sync();
+#ifdef PMX_WALK_TICKS // instrumented builds: s_memtime ticks inside path_bound() and probe() in WaveStats::dbg[0], [1]
+                            const unsigned long long tk0 = __builtin_amdgcn_s_memtime();
+#endif
                             go = path_bound<G>(w, p, pa, ub, tch, pool, f, nm, rl(bvec, ss * G), (vb >> (ss * G)) & GM);
+#ifdef PMX_WALK_TICKS
+                            if (lane == 0) stat->dbg[0] += __builtin_amdgcn_s_memtime() - tk0;
+#endif
                             child_path = kPath;
                             ++w.npath;
                             if (!go) ++w.ndrop;
@@ -1136,7 +1142,13 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
             if (probe_slot >= 0) { // (handed over, or dropped by the bound test: either way the walker does not go there)
                 uint32_t pp = 0;
                 const int bp_ = rl(bvec, probe_slot * G);
+#ifdef PMX_WALK_TICKS
+                const unsigned long long tk1 = __builtin_amdgcn_s_memtime();
+#endif
                 const bool reach = probe<G>(w, f, nm, bp_, (vb >> (probe_slot * G)) & GM, pp);
+#ifdef PMX_WALK_TICKS
+                if (lane == 0) stat->dbg[1] += __builtin_amdgcn_s_memtime() - tk1;
+#endif
                 if (lane == 0) {
                     stat->pad[0] += pp;
                     stat->pad[1] += 1;
@@ -1315,24 +1327,28 @@ __device__ __forceinline__ void item(const ScreenParams &p, uint32_t sidu, uint3
 // in one word; the position inside the cell is worked out again from the distance.)
 struct ItemLoad {
     float4 a, b;
-    float d;
+    float d, cell; // the distance and the number of its cell (as a float: the position inside the cell is d / h - cell)
     uint32_t sids; // sidu | sidv << 16
 };
-__device__ __forceinline__ ItemLoad item_load(const ScreenParams &p, uint32_t sidu, uint32_t sidv, float d) {
+// the cell of a distance: min(floor(d / h), ncell - 1)
+__device__ __forceinline__ float cell_of(const ScreenParams &p, float d) {
+    return (float)min((int)(d * p.F.inv_h), (int)p.F.ncell - 1); // (d * inv_h is exact: inv_h is a power of two)
+}
+__device__ __forceinline__ ItemLoad item_load(const ScreenParams &p, uint32_t sidu, uint32_t sidv, float d, float cell) {
     ItemLoad L;
-    const float x = d * p.F.inv_h; // exact: inv_h is a power of two
-    const int ci = min((int)x, (int)p.F.ncell - 1);
     L.d = d;
+    L.cell = cell;
     L.sids = sidu | (sidv << 16);
-    const uint32_t off = (fn_index(p.F, sidu, sidv) * p.F.ncell + (uint32_t)ci) * 16u; // (the table is a few MB: 32 bits)
-    const float4 *cell = reinterpret_cast<const float4 *>(reinterpret_cast<const unsigned char *>(p.F.cells) + off);
-    L.a = cell[0];
-    L.b = cell[p.F.plane16];
+    // (functions x cells < 2^27 - the table is addressed with 32 bits - and a function has hundreds of cells: 24-bit factors)
+    const uint32_t off = (__umul24(fn_index(p.F, sidu, sidv), p.F.ncell) + (uint32_t)(int)cell) << 4;
+    const unsigned char *pa = reinterpret_cast<const unsigned char *>(p.F.cells);
+    const unsigned char *pb = pa + (size_t)p.F.plane16 * 16u; // (both planes: uniform base + 32-bit lane offset)
+    L.a = *reinterpret_cast<const float4 *>(pa + off);
+    L.b = *reinterpret_cast<const float4 *>(pb + off);
     return L;
 }
 __device__ __forceinline__ void item_finish(const ScreenParams &p, const ItemLoad &L, float &acc, int &fails, uint32_t &n_exact) {
-    const float x = L.d * p.F.inv_h;
-    const float t = fminf(x - (float)min((int)x, (int)p.F.ncell - 1), 1.0f);
+    const float t = fminf(__builtin_fmaf(L.d, p.F.inv_h, -L.cell), 1.0f); // (= d / h - cell exactly: the product is exact)
     float v = __builtin_fmaf(t, L.b.y, L.b.x);
     v = __builtin_fmaf(t, v, L.a.w);
     v = __builtin_fmaf(t, v, L.a.z);
@@ -1495,10 +1511,21 @@ __device__ __forceinline__ void build_tables(const ScreenParams &p, unsigned cha
     // distances of the same node pairs, and a distance from coordinates is six loads, each of which occupies the L1 for four
     // cycles whether or not its lanes share an address. The table phase was bound by exactly that (rocprofv3: 0.86 L1 accesses
     // per cycle and CU, 67 % of its wave cycles waiting on memory). The walker's LDS (children cache, level maxima) is idle
-    // in this phase and holds 68 node pairs at 8 lanes; larger pairs - and the 32 / 64-lane shapes, which keep nothing
-    // there - compute from the coordinates as before.
-    float *dl = reinterpret_cast<float *>(lds + ws.off_tc);
-    const int dcap = (int)((ws.bytes - ws.off_tc) / (uint32_t)(G * 4));
+    // in this phase and holds 82 node pairs at 8 lanes; larger pairs - and the 32 / 64-lane shapes, which keep nothing
+    // there - compute from the coordinates as before. (The cell of the distance staged with it - the same for every entry
+    // too - halves what fits and costs more than it saves: measured.)
+    constexpr uint32_t kPfBytes = 2u * G * 4u; // (the cluster distance and size sum of the level pair, below, come first)
+    // At 32 / 64 lanes the wave's buffer of path totals in global memory (idle until the walk) takes their place: one coalesced
+    // load per item instead of six and the square root.
+    constexpr bool kStageLds = totals_in_lds<G>();
+    float *dl = kStageLds ? reinterpret_cast<float *>(lds + ws.off_tch + kPfBytes) : reinterpret_cast<float *>(p.totbuf + (size_t)blockIdx.x * kTotBufBytes);
+    const int dcap = kStageLds ? (int)((ws.bytes - ws.off_tch - kPfBytes) / (uint32_t)(G * 4)) : (int)(kTotBufBytes / (uint32_t)(G * 4));
+#ifdef PMX_TABLE_TICKS // instrumented builds: s_memtime ticks of the parts of this phase in WaveStats::dbg - [0] self tables [1] centres of a level pair [2] its node distances [3] prefilter and the rows of failing entries [4] items [5] chain lengths (build_bounds)
+    unsigned long long tick_ = __builtin_amdgcn_s_memtime();
+#define PMX_TICK(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) reinterpret_cast<WaveStats *>(lds + ws.off_stat)->dbg[i] += t_ - tick_; tick_ = t_; } while (0)
+#else
+#define PMX_TICK(i)
+#endif
     auto node_distance = [&](int a0, int u, int b0, int v) {
         const uint32_t ou = (uint32_t)((a0 + u) * 3 * C + cc), ov = (uint32_t)((b0 + v) * 3 * C + cc);
         return norm3f(xyz[ou] - xyz[ov], xyz[ou + C] - xyz[ov + C], xyz[ou + 2 * C] - xyz[ov + 2 * C]);
@@ -1510,7 +1537,8 @@ __device__ __forceinline__ void build_tables(const ScreenParams &p, unsigned cha
             const int u = (int)(((float)pr + 0.5f) * inv_nb), v = pr - u * nb;
             dl[pr * G + c] = node_distance(a0, u, b0, v);
         }
-        lds_sync();
+        if (kStageLds) lds_sync();
+        else wave_sync();
     };
     for (int i = 0; i < nl; ++i) {
         const int si = uni(lstart[i]), ni = uni(lend[i]) - si, ki = uni(lk[i]), nci = uni(ncoff[i]), ksi = uni(ksum[i]);
@@ -1534,6 +1562,7 @@ __device__ __forceinline__ void build_tables(const ScreenParams &p, unsigned cha
             }
             if (on) St[(size_t)(ksi + q) * G + c] = acc;
         }
+        PMX_TICK(0);
         Pos3 ctr_i;
         float size_i;
         center_size(xyz, C, si, si + ni, cc, ctr_i, size_i);
@@ -1558,8 +1587,10 @@ __device__ __forceinline__ void build_tables(const ScreenParams &p, unsigned cha
                 pf[G + c] = lsize;
             }
             const bool staged = ni * nj <= dcap;
+            PMX_TICK(1);
             if (staged) stage_distances(si, ni, sj, nj);
             else lds_sync();
+            PMX_TICK(2);
             for (int eb = 0; eb < E; eb += 64) {
                 unsigned long long pbal;
                 {
@@ -1589,6 +1620,7 @@ __device__ __forceinline__ void build_tables(const ScreenParams &p, unsigned cha
                     }
                 }
                 lds_sync();
+                PMX_TICK(3);
                 const int npass = (int)__popcll(pbal);
                 // what is written for a finished entry: match_utils.py:71-74 (-1 unless num_fails <= L1 * L2 / 2), the row and its V mask
                 auto finish_entry = [&](int e, bool on, float acc, int fails) {
@@ -1658,7 +1690,7 @@ __device__ __forceinline__ void build_tables(const ScreenParams &p, unsigned cha
                         for (int q = 0; q < IB; ++q) {
                             const bool in = t0 + q < total; // (an item past the end is the empty subset pair: value 0, never a fail)
                             const float d = staged ? dl[(lu * nj + lv) * G + c] : node_distance(si, lu, sj, lv);
-                            L[q] = item_load(p, in ? (uint32_t)nc[rowa + lu] : 0u, in ? (uint32_t)nc[rowb + lv] : 0u, d);
+                            L[q] = item_load(p, in ? (uint32_t)nc[rowa + lu] : 0u, in ? (uint32_t)nc[rowb + lv] : 0u, d, cell_of(p, d));
                             if (++lv == nj) {
                                 lv = 0;
                                 if (++lu == ni) {
@@ -1682,8 +1714,15 @@ __device__ __forceinline__ void build_tables(const ScreenParams &p, unsigned cha
                         }
                     }
                     n_items += (uint32_t)total;
+#ifdef PMX_TABLE_FILL // instrumented builds: [1] wave-iterations of the pair items, [5] slot-items of them that belong to an entry
+                    if (lane == 0) {
+                        reinterpret_cast<WaveStats *>(lds + ws.off_stat)->dbg[1] += (unsigned long long)total;
+                        reinterpret_cast<WaveStats *>(lds + ws.off_stat)->dbg[5] += (unsigned long long)(npass * npair);
+                    }
+#endif
                 }
                 lds_sync(); // (the list is rewritten by the next chunk)
+                PMX_TICK(4);
             }
         }
     }
@@ -1747,7 +1786,11 @@ __device__ __forceinline__ void build_bounds(const ScreenParams &p, unsigned cha
     float *OBt = reinterpret_cast<float *>(rec + rec_ob_off<G>(L.ksumtot, L.T, (uint32_t)L.nl));
     unsigned char *LVt = rec + rec_ci_off<G>(L.ksumtot, L.T, (uint32_t)L.nl);
     const int nl = L.nl;
+#ifdef PMX_TABLE_TICKS
+    unsigned long long tick_ = __builtin_amdgcn_s_memtime();
+#endif
     if (cand_bounds<G>()) chain_lengths<G>(p, lds, ws, L, rec);
+    PMX_TICK(5);
     if (p.flags & 4) { // debug: nothing is ever dropped
         for (int l = s; l <= nl; l += SLOTS) Rt[(size_t)l * G + c] = __builtin_inf();
         if (cand_bounds<G>())
@@ -2138,7 +2181,7 @@ __device__ inline void flush_wave_stats(const ScreenParams &p, const WaveStats *
     atomicAdd(st + 13, stat->exactv);
     atomicAdd(st + 22, stat->npath);
     atomicAdd(st + 23, stat->dbg[7]);
-#ifdef PMX_COUNTERS
+#if defined(PMX_COUNTERS) || defined(PMX_TABLE_TICKS) || defined(PMX_TABLE_FILL) || defined(PMX_WALK_TICKS)
     for (int i = 0; i < 6; ++i) atomicAdd(st + 16 + i, stat->dbg[i]);
 #endif
 }
