@@ -1,6 +1,8 @@
 /* bound_study.c - how many tree frames a branch-and-bound walker enters under different bounds. ANALYSIS TOOL (test side):
  * it includes the CPU oracle's source for the score tables and runs its own searches on them; nothing in the product uses it.
  *   A: the engine's bound - per-candidate W[(f,b)] (csrc/pmx_screen.hip build_bounds), children visited best first
+ *   modes 4-6: what the engine does at 32 / 64 conformer lanes (level bound R under >= 5 matches, candidates in index order), and
+ *      the per-candidate bound in that order with and without the test on children with fewer than 5 matches
  *   B: a path-aware bound - for every deeper level the best candidate given the ACTUAL matches on the path (their pair
  *      entries instead of the levels' maxima, candidates incompatible with any of them left out)
  * Both walk the reference's tree semantics (tree.py:55-104) with the engine's dropping rule; scores must agree with the oracle. */
@@ -10,11 +12,12 @@
 typedef struct {
     ctx_t *X;
     int C, nl;
-    int mode; /* 0 = A, 1 = B, 2 = B for children with >= 5 matches (A below), 3 = B where >= 2 levels lie below the child's */
+    int mode; /* 0 = A, 1 = B, 2 = B for children with >= 5 matches (A below), 3 = B where >= 2 levels lie below the child's, 4 = R under >= 5 matches in index order, 5 = W everywhere in index order, 6 = W under >= 5 matches in index order */
     double best[MAX_C];
     double *base[MAX_LEVELS];  /* [k_l][C]  S + sum_{j<l} maxP_j */
     double *maxP[MAX_LEVELS][MAX_LEVELS]; /* [j][l]: [k_l][C] max(0, max_a P[(j,a),(l,b')]) */
     double *W[MAX_LEVELS];     /* [k_f][C] */
+    double *R; /* [nl+1][C] */
     int64_t frames, bound_evals, rows;
     int sel[MAX_LEVELS];
 } study_t;
@@ -45,6 +48,13 @@ static void build_static(study_t *S) {
                 S->base[l][(size_t)b * C + c] = v;
             }
     }
+    S->R = (double *)calloc((size_t)(nl + 1) * C, sizeof(double));
+    for (int l = nl - 1; l >= 0; --l)
+        for (int c = 0; c < C; ++c) {
+            double u = 0.0;
+            for (int b = 0; b < X->k[l]; ++b) if (S->base[l][(size_t)b * C + c] > u) u = S->base[l][(size_t)b * C + c];
+            S->R[(size_t)l * C + c] = S->R[(size_t)(l + 1) * C + c] + u;
+        }
     for (int f = 0; f < nl; ++f) {
         S->W[f] = (double *)calloc((size_t)X->k[f] * C, sizeof(double));
         for (int b = 0; b < X->k[f]; ++b)
@@ -170,6 +180,7 @@ static int walk(study_t *S, int level, int matched, int nm, const uint8_t *alive
                     double v = ct[b][c] + S->W[f][(size_t)b * C + c];
                     if (v > key) key = v;
                 }
+            if (S->mode >= 4) { pick = b; break; } /* index order */
             if (key > pk) pk = key, pick = b;
         }
         if (pick < 0) break;
@@ -178,9 +189,10 @@ static int walk(study_t *S, int level, int matched, int nm, const uint8_t *alive
         S->sel[f] = b;
         for (int c = 0; c < C; ++c) {
             if (!ca[b][c]) continue;
-            bnd[c] = S->W[f][(size_t)b * C + c];
+            bnd[c] = S->mode == 4 ? S->R[(size_t)(f + 1) * C + c] : S->W[f][(size_t)b * C + c];
             if ((ct[b][c] + bnd[c]) * (1.0 + 1e-9) > S->best[c]) improve = 1;
         }
+        if ((S->mode == 4 || S->mode == 6) && nm < 4) improve = 1; /* no test on children with fewer than 5 matches */
         const int use_path = S->mode == 1 || (S->mode == 2 && nm + 1 >= 5) || (S->mode == 3 && S->nl - f >= 3);
         if (improve && use_path) {
             improve = 0;
@@ -208,7 +220,7 @@ static int walk(study_t *S, int level, int matched, int nm, const uint8_t *alive
     return max_num + matched;
 }
 
-/* out[i] = {oracle tree nodes, frames A, frames B, bound evaluations B, score mismatch flag} */
+/* out[i][16] = {oracle tree nodes, (frames, path-bound evaluations) of modes 0 .. 6, score mismatch flags} */
 int bound_study(const oracle_model *M, const uint64_t *offsets, const uint8_t *data, uint64_t first, uint64_t count, const float weights[7],
                 int64_t *out) {
     for (uint64_t i = 0; i < count; ++i) {
@@ -239,15 +251,15 @@ int bound_study(const oracle_model *M, const uint64_t *offsets, const uint8_t *d
             X->k[X->nl] = k;
             X->nl++;
         }
-        int64_t *o = out + 10 * i;
-        memset(o, 0, 80);
+        int64_t *o = out + 16 * i;
+        memset(o, 0, 128);
         o[0] = R.n_tree;
         if (X->nl == 0) continue;
         oracle_result R2;
         memset(&R2, 0, sizeof(R2));
         build_node_matches(X, weights);
         build_tables(X, &R2);
-        for (int mode = 0; mode < 4; ++mode) {
+        for (int mode = 0; mode < 7; ++mode) {
             study_t S;
             memset(&S, 0, sizeof(S));
             S.X = X, S.C = L->C, S.nl = X->nl, S.mode = mode;
@@ -258,13 +270,14 @@ int bound_study(const oracle_model *M, const uint64_t *offsets, const uint8_t *d
             walk(&S, -1, 0, 0, alive, total);
             double sum = 0.0;
             for (int c = 0; c < L->C; ++c) sum += S.best[c];
-            if (sum / L->C != R.score) o[9] |= 1 << mode;
+            if (sum / L->C != R.score) o[15] |= 1 << mode;
             o[1 + 2 * mode] = S.frames;
             o[2 + 2 * mode] = S.bound_evals;
             for (int l = 0; l < S.nl; ++l) {
                 free(S.base[l]), free(S.W[l]);
                 for (int j = 0; j < l; ++j) free(S.maxP[j][l]);
             }
+            free(S.R);
         }
         arena_reset();
     }
