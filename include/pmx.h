@@ -204,6 +204,15 @@ int pmx_pack_features(const pmx_feature_batch *batch, int threads, uint64_t *off
 int pmx_sdf_heavy_atoms(const char *text, uint64_t len, uint64_t max_records, uint64_t cap_records, uint64_t cap_atoms,
                         uint64_t *n_records, uint64_t *n_atoms, int32_t *atoms_per_record, uint8_t *atomic_num, float *xyz);
 
+/*
+ * The same for a Tripos mol2 file (`pybel.readfile("mol2", ...)` in ligand.py:72): every @<TRIPOS>MOLECULE record's
+ * @<TRIPOS>ATOM section, the element taken from the SYBYL atom type in front of its dot, hydrogens dropped. An atom type that
+ * names no element (Du, LP, Any ...) fails the call with PMX_ERR_INVALID like any record it cannot parse: the caller then
+ * reads the file the reference's way.
+ */
+int pmx_mol2_heavy_atoms(const char *text, uint64_t len, uint64_t max_records, uint64_t cap_records, uint64_t cap_atoms,
+                         uint64_t *n_records, uint64_t *n_atoms, int32_t *atoms_per_record, uint8_t *atomic_num, float *xyz);
+
 /* Frees the scoring workspaces libpmx keeps between calls on `device` (synchronises the device first). */
 int pmx_release_workspaces(int device);
 

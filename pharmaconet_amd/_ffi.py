@@ -124,6 +124,11 @@ SIGNATURES = {
         [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64),
          ctypes.POINTER(ctypes.c_uint64), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p],
     ),
+    "pmx_mol2_heavy_atoms": (
+        ctypes.c_int,
+        [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64),
+         ctypes.POINTER(ctypes.c_uint64), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p],
+    ),
     "pmx_score_stats_get": (ctypes.c_int, [ctypes.POINTER(ScoreStats)]),
     "pmx_set_profiling": (ctypes.c_int, [ctypes.c_int]),
 }
@@ -170,7 +175,7 @@ def load_packer() -> ctypes.CDLL:
         if not path.exists():
             raise PmxError(f"{path} is missing: build with `python -m pharmaconet_amd.build`")
         lib = ctypes.CDLL(str(path))
-        for name in ("pmx_pack_features", "pmx_sdf_heavy_atoms", "pmx_last_error", "pmx_version"):
+        for name in ("pmx_pack_features", "pmx_sdf_heavy_atoms", "pmx_mol2_heavy_atoms", "pmx_last_error", "pmx_version"):
             restype, argtypes = SIGNATURES[name]
             fn = getattr(lib, name)
             fn.restype = restype

@@ -1,4 +1,5 @@
-// pmx_sdf.cpp - conformer coordinates of an SD file (MDL molfile V2000 / V3000 records separated by $$$$) in native code.
+// pmx_sdf.cpp - conformer coordinates of an SD file (MDL molfile V2000 / V3000 records separated by $$$$) or a Tripos mol2 file
+// (@<TRIPOS>MOLECULE records) in native code.
 //
 // What it stands in for: the coordinate half of Ligand.load_from_file (src/pmnet/scoring/ligand.py:63-84) - the reference has
 // OpenBabel parse every record of a multi-conformer file into a molecule object and then copies `[atom.coords for atom in
@@ -201,6 +202,81 @@ extern "C" int pmx_sdf_heavy_atoms(const char *text, uint64_t len, uint64_t max_
             }
         if (!ended) break;
     }
+    *n_records = rec;
+    *n_atoms = total;
+    return PMX_OK;
+}
+
+// The same for a Tripos mol2 file: every @<TRIPOS>MOLECULE record's @<TRIPOS>ATOM section (`atom_id atom_name x y z atom_type ...`,
+// blank-separated), hydrogens dropped. The element is the part of the SYBYL atom type in front of the dot ("C.ar" -> C, "Cl" ->
+// Cl, "H.spc" -> H). A type that names no element (Du, LP, Any, Hal, Het, Hev ...) makes the record one this reader does not
+// understand - PMX_ERR_INVALID, and the caller goes the toolkit's way - rather than guess what the toolkit would make of it.
+extern "C" int pmx_mol2_heavy_atoms(const char *text, uint64_t len, uint64_t max_records, uint64_t cap_records, uint64_t cap_atoms, uint64_t *n_records,
+                                    uint64_t *n_atoms, int32_t *atoms_per_record, uint8_t *atomic_num, float *xyz) {
+    if (!text || !n_records || !n_atoms) return pmx_topk_fail(PMX_ERR_INVALID, "pmx_mol2_heavy_atoms: null argument");
+    const bool store = atomic_num != nullptr || xyz != nullptr;
+    Cursor cur{text, text + len};
+    uint64_t rec = 0, total = 0;
+    bool open = false, in_atoms = false, limit = false;
+    int32_t heavy = 0;
+    Line l;
+    auto fail_here = [&]() {
+        *n_records = rec; // (the record in work)
+        *n_atoms = total;
+        return pmx_topk_fail(PMX_ERR_INVALID, "pmx_mol2_heavy_atoms: malformed record");
+    };
+    auto close_record = [&]() -> int {
+        if (!open) return PMX_OK;
+        if (store && atoms_per_record) {
+            if (rec >= cap_records) return pmx_topk_fail(PMX_ERR_INVALID, "pmx_mol2_heavy_atoms: record capacity too small");
+            atoms_per_record[rec] = heavy;
+        }
+        ++rec;
+        open = false;
+        return PMX_OK;
+    };
+    while (!limit && cur.next(l)) {
+        const char *p = l.p, *e = l.p + l.n;
+        while (p < e && std::isspace((unsigned char)*p)) ++p;
+        if (p == e || *p == '#') continue; // blank and comment lines
+        if (*p == '@') {
+            const size_t n = (size_t)(e - p);
+            in_atoms = false;
+            if (n >= 17 && !std::memcmp(p, "@<TRIPOS>MOLECULE", 17)) {
+                if (const int rc = close_record()) return rc;
+                if (max_records && rec >= max_records) {
+                    limit = true;
+                    break;
+                }
+                open = true;
+                heavy = 0;
+            } else if (n >= 13 && !std::memcmp(p, "@<TRIPOS>ATOM", 13) && (n == 13 || std::isspace((unsigned char)p[13]))) {
+                if (!open) return fail_here();
+                in_atoms = true;
+            }
+            continue;
+        }
+        if (!in_atoms) continue;
+        const char *t;
+        size_t tn;
+        double v[3];
+        if (!token(p, e, t, tn) || !token(p, e, t, tn)) return fail_here(); // atom_id, atom_name
+        for (int k = 0; k < 3; ++k)
+            if (!token(p, e, t, tn) || !parse_double(t, tn, v[k])) return fail_here();
+        if (!token(p, e, t, tn)) return fail_here(); // atom_type
+        size_t en = 0;
+        while (en < tn && t[en] != '.') ++en;
+        const int el = atomic_number(t, en);
+        if (el <= 0) return fail_here(); // no element: not for this reader
+        if (el == 1) continue;           // hydrogens are removed (Ligand.__init__: pbmol.removeh(), ligand.py:38)
+        if (store) {
+            if (total >= cap_atoms) return pmx_topk_fail(PMX_ERR_INVALID, "pmx_mol2_heavy_atoms: atom capacity too small");
+            if (atomic_num) atomic_num[total] = (uint8_t)el;
+            if (xyz) xyz[3 * total] = (float)v[0], xyz[3 * total + 1] = (float)v[1], xyz[3 * total + 2] = (float)v[2];
+        }
+        ++total, ++heavy;
+    }
+    if (const int rc = close_record()) return rc;
     *n_records = rec;
     *n_atoms = total;
     return PMX_OK;

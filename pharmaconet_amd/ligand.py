@@ -148,9 +148,9 @@ class Ligand:
         if num_conformers is not None:
             assert num_conformers > 0
             reader = itertools.islice(reader, num_conformers)
-        if extension == ".sdf":
+        if extension in (".sdf", ".mol2"):
             # Features come from the first record alone; of the others only heavy-atom coordinates are used. Those are read by the
-            # native SD reader (csrc/pmx_sdf.cpp) instead of one toolkit molecule + a Python loop over its atoms per record.
+            # native SD / mol2 reader (csrc/pmx_sdf.cpp) instead of one toolkit molecule + a Python loop over its atoms per record.
             # Anything it does not accept - or records that disagree with the toolkit's view of the first one - goes the
             # reference's way below.
             fast = cls._from_sdf_fast(reader, filename, num_conformers)

@@ -184,6 +184,30 @@ def write_sdf(desc, path, extra_hydrogens=0, crlf=False):
         f.write("".join(out))
 
 
+def write_mol2(desc, path, extra_hydrogens=0, crlf=False):
+    """The described molecule as a multi-record Tripos mol2 file: one @<TRIPOS>MOLECULE record per conformer, heavy atoms in
+    description order with `extra_hydrogens` hydrogens mixed into every atom section, SYBYL-style atom types (`C.3`, `N.ar`,
+    `Cl` ...), and the description as an @<TRIPOS>COMMENT section of every record (what `readfile` perceives chemistry from)."""
+    eol = "\r\n" if crlf else "\n"
+    typ = {1: "H", 5: "B", 6: "C.3", 7: "N.am", 8: "O.co2", 9: "F", 15: "P.3", 16: "S.o2", 17: "Cl", 35: "Br", 53: "I"}
+    out = []
+    n = len(desc["z"])
+    for c, xyz in enumerate(desc["coords"]):
+        atoms = [(typ[int(z)], xyz[i]) for i, z in enumerate(desc["z"])]
+        for h in range(extra_hydrogens):
+            at = (h * 7 + c) % (len(atoms) + 1)
+            x, y, zc = xyz[(h * 3) % n]
+            atoms.insert(at, ("H" if h % 2 else "H.spc", (x + 0.6, y - 0.4, zc + 0.3)))
+        lines = ["# written by fake_openbabel", "@<TRIPOS>MOLECULE", f"conformer {c}", f" {len(atoms)} 0 1 0 0", "SMALL", "NO_CHARGES", "",
+                 "@<TRIPOS>ATOM"]
+        for k, (t, (x, y, zc)) in enumerate(atoms):
+            lines.append(f"{k + 1:7d} {t.split('.')[0]}{k + 1:<6d} {x:10.4f} {y:10.4f} {zc:10.4f} {t:<7s} 1  LIG1  0.0000")
+        lines += ["@<TRIPOS>BOND", "@<TRIPOS>COMMENT", f"{SDF_DESCRIPTION_TAG} " + json.dumps(desc), ""]
+        out.append(eol.join(lines) + eol)
+    with open(path, "w", newline="") as f:
+        f.write("".join(out))
+
+
 def readfile(fmt, filename):
     """A 'file' is the JSON of a description - every conformer becomes one record, as in a multi-record SDF - or a real SD
     file written by `write_sdf`, whose records carry the description as a data item (the stand-in perceives nothing from
@@ -193,6 +217,12 @@ def readfile(fmt, filename):
     try:
         desc = json.loads(text)
     except json.JSONDecodeError:
+        if "@<TRIPOS>MOLECULE" in text:  # a mol2 file written by `write_mol2`
+            records = text.replace("\r\n", "\n").split("@<TRIPOS>MOLECULE")[1:]
+            desc = json.loads(records[0].split(SDF_DESCRIPTION_TAG + " ", 1)[1].split("\n", 1)[0])
+            for c in range(len(records)):
+                yield Molecule(desc, c)
+            return
         records = [r for r in text.replace("\r\n", "\n").split("$$$$\n") if r.strip()]
         tag = f">  <{SDF_DESCRIPTION_TAG}>\n"
         desc = json.loads(records[0].split(tag, 1)[1].split("\n", 1)[0])

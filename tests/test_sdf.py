@@ -1,4 +1,4 @@
-"""The native SD-file coordinate reader (`pmx_sdf_heavy_atoms`, csrc/pmx_sdf.cpp; `pharmaconet_amd/sdf.py`): what
+"""The native SD / mol2 coordinate readers (`pmx_sdf_heavy_atoms`, `pmx_mol2_heavy_atoms`, csrc/pmx_sdf.cpp; `pharmaconet_amd/sdf.py`): what
 `Ligand.load_from_file` (reference `src/pmnet/scoring/ligand.py:63-84`) takes from every record but the first - the heavy
 atoms' coordinates - read without a chemistry toolkit. Held to a plain-Python parse of generated V2000 / V3000 files and,
 through the OpenBabel stand-in, to the all-toolkit path of `load_from_file` on the described molecules of the perception
@@ -86,6 +86,66 @@ def test_reader_matches_a_plain_parse(variant):
         assert first[0].tolist() == [want[0][0]] and np.array_equal(first[2], want[2][: want[0][0]])
 
 
+MOL2_TYPES = {1: ["H", "H.spc", "H.t3p"], 6: ["C.3", "C.2", "C.ar", "C.cat", "C.1"], 7: ["N.3", "N.am", "N.pl3", "N.ar", "N.4"], 8: ["O.3", "O.2", "O.co2"],
+              9: ["F"], 15: ["P.3"], 16: ["S.3", "S.o2", "S.O"], 17: ["Cl", "CL"], 35: ["Br"], 53: ["I"]}
+
+
+def _mol2(z, recs, rng, eol="\n"):
+    out = []
+    for c, xyz in enumerate(recs):
+        lines = ["# a comment", "@<TRIPOS>MOLECULE", f"mol {c}", f" {len(z)} {max(len(z) - 1, 0)} 1 0 0", "SMALL", "GASTEIGER", "", "@<TRIPOS>ATOM"]
+        for i, (el, (x, y, w)) in enumerate(zip(z, xyz)):
+            t = MOL2_TYPES[el][int(rng.integers(len(MOL2_TYPES[el])))]
+            lines.append(f"{i + 1:7d} {SYMBOLS[el]}{i + 1:<5d} {x:10.4f} {y:10.4f} {w:10.4f} {t:<6s} 1 LIG1 {0.01 * i:8.4f}")
+        lines.append("@<TRIPOS>BOND")
+        for b in range(len(z) - 1):
+            lines.append(f"{b + 1:6d}{b + 1:6d}{b + 2:6d}    1")
+        lines += ["@<TRIPOS>SUBSTRUCTURE", "     1 LIG1        1 TEMP              0 ****  ****    0 ROOT", ""]
+        out.append(eol.join(lines) + eol)
+    return "".join(out).encode()
+
+
+@pytest.mark.parametrize("eol", ["\n", "\r\n"])
+def test_mol2_reader_matches_a_plain_parse(eol, tmp_path):
+    from pharmaconet_amd.sdf import SdfError, conformer_positions, read_heavy_atoms
+
+    rng = np.random.default_rng(20250931)
+    for trial in range(40):
+        z, recs = _random_records(rng, int(rng.integers(1, 9)), int(rng.integers(1, 40)))
+        text = _mol2(z, recs, rng, eol)
+        per, zz, xyz = read_heavy_atoms(text, fmt="mol2")
+        want = _expect(z, recs)
+        assert np.array_equal(per, want[0]) and np.array_equal(zz, want[1])
+        assert np.array_equal(xyz, want[2]), f"trial {trial}"
+        first = read_heavy_atoms(text, max_records=1, fmt="mol2")
+        assert first[0].tolist() == [want[0][0]] and np.array_equal(first[2], want[2][: want[0][0]])
+    path = tmp_path / "confs.mol2"
+    path.write_bytes(text)
+    zz2, pos = conformer_positions(path)  # the extension picks the reader
+    assert pos.shape[1] == len(recs) and zz2.tolist() == want[1][: want[0][0]].tolist()
+    # atom types that name no element, a coordinate that is not a number, an atom section outside a record
+    lines = text.decode().replace("\r\n", "\n").split("\n")
+    k = lines.index("@<TRIPOS>ATOM") + 1
+    for bad_type in ("Du", "LP", "Any", "Du.C"):
+        bad = list(lines)
+        f = bad[k].split()
+        f[5] = bad_type
+        bad[k] = " ".join(f)
+        with pytest.raises(SdfError, match="record 0"):
+            read_heavy_atoms("\n".join(bad).encode(), fmt="mol2")
+    bad = list(lines)
+    f = bad[k].split()
+    f[3] = "1.2.3"
+    bad[k] = " ".join(f)
+    with pytest.raises(SdfError):
+        read_heavy_atoms("\n".join(bad).encode(), fmt="mol2")
+    with pytest.raises(SdfError):
+        read_heavy_atoms(b"@<TRIPOS>ATOM\n 1 C1 0 0 0 C.3\n", fmt="mol2")
+    assert read_heavy_atoms(b"", fmt="mol2")[0].size == 0
+    with pytest.raises(ValueError):
+        read_heavy_atoms(b"", fmt="pdb")
+
+
 def test_conformers_of_one_molecule_and_what_is_refused(tmp_path):
     from pharmaconet_amd.sdf import SdfError, conformer_positions, read_heavy_atoms
 
@@ -162,6 +222,14 @@ def test_load_from_file_reads_sd_coordinates_natively(tmp_path, monkeypatch, _op
         assert bytes(pack_ligand(fast.features)) == bytes(pack_ligand(slow.features))
         if len(desc["coords"]) > 1:
             assert Ligand.load_from_file(sdf, num_conformers=1).num_conformers == 1
+        if i % 3 == 0:  # the same molecule as a multi-record mol2 file
+            mol2 = tmp_path / f"m{i}.mol2"
+            fake_openbabel.write_mol2(desc, mol2, extra_hydrogens=i % 4, crlf=i % 5 == 0)
+            del asked[:]
+            fast2 = Ligand.load_from_file(mol2)
+            assert asked == [0]
+            assert np.array_equal(fast2.atom_positions, slow.atom_positions)
+            assert bytes(pack_ligand(fast2.features)) == bytes(pack_ligand(slow.features))
         checked += 1
     assert checked == 120
     assert ligand_mod is not None
