@@ -241,6 +241,8 @@ typedef struct {
                                    to the function's own (tail) value there, per lane */
     uint64_t dbg[8];            /* walker counters of instrumented builds (-DPMX_COUNTERS, see csrc/pmx_screen.hip walk()); 0 otherwise */
     uint64_t n_path_bounds, n_path_drops; /* children tested against the bound their actual path gives (path_bound()), and dropped by it */
+    uint64_t n_dead_entries;    /* pair-table entries settled as -1 without computing their items: more than half of their node pairs lie
+                                   outside every 2-sigma window of the two model clusters, for every conformer */
 } pmx_score_stats;
 int pmx_score_stats_get(pmx_score_stats *out);
 int pmx_set_profiling(int enabled); /* when enabled pmx_score records HIP events around its phases (no synchronisation) */

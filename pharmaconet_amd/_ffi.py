@@ -79,7 +79,8 @@ class ScoreStats(ctypes.Structure):
             "ligands_last", "n_frames", "n_passes", "n_items", "n_exact_cells", "n_heavy", "n_tasks", "n_exported",
             "n_slice_overflow", "n_probes", "n_probe_passes", "max_passes", "queue_overflow", "arena_bytes",
             "ticks_scan", "ticks_tables", "ticks_bounds", "ticks_walk", "ticks_alive", "n_exact_values")]
-        + [("dbg", ctypes.c_uint64 * 8), ("n_path_bounds", ctypes.c_uint64), ("n_path_drops", ctypes.c_uint64)]
+        + [("dbg", ctypes.c_uint64 * 8), ("n_path_bounds", ctypes.c_uint64), ("n_path_drops", ctypes.c_uint64),
+           ("n_dead_entries", ctypes.c_uint64)]
     )
 
 

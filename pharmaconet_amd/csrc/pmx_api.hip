@@ -306,7 +306,8 @@ extern "C" int pmx_model_create(const pmx_model_desc *d, int device, pmx_model *
     const size_t off_tnodes = off_cnodes + 64 * 8;
     const size_t off_tclus = off_tnodes + 128 * 8;
     const size_t off_cpair = off_tclus + 128 * 8;
-    const size_t total = off_cpair + round16(n_pair * sizeof(float2)) + 16;
+    const size_t off_cwin = off_cpair + round16(n_pair * sizeof(float2));
+    const size_t total = off_cwin + round16(n_pair * sizeof(float2)) + 16;
     std::vector<unsigned char> host(total, 0);
     float4 *edge = reinterpret_cast<float4 *>(host.data() + off_edge);
     uint8_t *ntype = host.data() + off_type;
@@ -314,6 +315,7 @@ extern "C" int pmx_model_create(const pmx_model_desc *d, int device, pmx_model *
     uint64_t *tnodes = reinterpret_cast<uint64_t *>(host.data() + off_tnodes);
     uint64_t *tclus = reinterpret_cast<uint64_t *>(host.data() + off_tclus);
     float2 *cpair = reinterpret_cast<float2 *>(host.data() + off_cpair);
+    float2 *cwin = reinterpret_cast<float2 *>(host.data() + off_cwin);
 
     const double s_const = std::sqrt(0.5 * 1.4426950408889634074); // sqrt(0.5 * log2(e))
     for (size_t i = 0; i < n_edge; ++i) {
@@ -343,6 +345,24 @@ extern "C" int pmx_model_create(const pmx_model_desc *d, int device, pmx_model *
                                           (ca[2] - cb[2]) * (ca[2] - cb[2])); // graph_match.py:263-264
             cpair[a * K + b] = make_float2((float)dist, (float)(d->cluster_size[a] + d->cluster_size[b])); // :265
         }
+    // hull of the exact 2-sigma windows of a cluster pair's node pairs (the dead-entry test of build_tables)
+    {
+        std::vector<float> wlo(n_edge), whi(n_edge);
+        std::vector<uint8_t> wok(n_edge);
+        for (size_t i = 0; i < n_edge; ++i) wok[i] = edge_window(d->edge_mean[i], pass_threshold(d->edge_std[i]), wlo[i], whi[i]) ? 1 : 0;
+        for (int a = 0; a < K; ++a)
+            for (int b = 0; b < K; ++b) {
+                float lo = INFINITY, hi = -INFINITY;
+                for (uint64_t am = d->cluster_nodes[a]; am; am &= am - 1)
+                    for (uint64_t bm = d->cluster_nodes[b]; bm; bm &= bm - 1) {
+                        const size_t e = (size_t)__builtin_ctzll(am) * Nm + __builtin_ctzll(bm);
+                        if (!wok[e]) continue;
+                        lo = std::min(lo, wlo[e]);
+                        hi = std::max(hi, whi[e]);
+                    }
+                cwin[a * K + b] = make_float2(lo, hi);
+            }
+    }
 
     void *blob = nullptr;
     HIPCHECK(hipMalloc(&blob, total));
@@ -372,6 +392,7 @@ extern "C" int pmx_model_create(const pmx_model_desc *d, int device, pmx_model *
     m->dm.tnodes = reinterpret_cast<const uint64_t *>(b8 + off_tnodes);
     m->dm.tclus = reinterpret_cast<const uint64_t *>(b8 + off_tclus);
     m->dm.cpair = reinterpret_cast<const float2 *>(b8 + off_cpair);
+    m->dm.cwin = reinterpret_cast<const float2 *>(b8 + off_cwin);
     {
         std::vector<uint64_t> cn(cnodes, cnodes + 64);
         const int rc = build_pair_functions(m, d, cn, tnodes);
@@ -652,6 +673,7 @@ static int score_screen(const pmx_model *const *models, int n_models, const pmx_
         p.budget = lig_budget;
         p.min_levels = (uint32_t)std::max<long>(0, env_long("PMX_MIN_LEVELS", 3));
         p.bound_cost = (uint32_t)std::max<long>(0, env_long("PMX_BOUND_COST", 8192));
+        p.dead_min_entries = (uint32_t)std::max<long>(1, env_long("PMX_DEAD_MIN_ENTRIES", 32));
         p.scores = scores_dev + (size_t)m * count;
         p.status = m == 0 ? status_dev : nullptr;
         const WaveShape<G> shape = wave_shape<G>(model->dm.K, (int)max_nodes);
@@ -884,6 +906,7 @@ static int screen_stats(pmx_score_stats *out) {
     for (int i = 0; i < 6; ++i) out->dbg[i] = st[16 + i];
     out->n_path_bounds = st[22];
     out->n_path_drops = st[23];
+    out->n_dead_entries = st[24];
     out->ticks_scan = st[8], out->ticks_tables = st[9], out->ticks_bounds = st[10], out->ticks_walk = st[11], out->ticks_alive = st[12];
     out->ligands_last = w->ligands_last;
     if (w->ev_valid) {

@@ -22,6 +22,9 @@ struct DevModel {
     const uint64_t *tnodes;   // [128]  ligand node type mask -> model nodes of any of those types
     const uint64_t *tclus;    // [128]  ligand cluster type mask -> model clusters sharing a type (graph_match.py:130-134)
     const float2 *cpair;      // [K * K] {float32(|center_a - center_b|), float32(size_a + size_b)}  (graph_match.py:263-265)
+    const float2 *cwin;       // [K * K] {lo, hi}: the hull of the 2-sigma pass windows of every node pair (m in a, n in b) - a ligand
+                              // node pair at a distance outside it fails the majority test of match_utils.py:55-61 against every
+                              // pair of node subsets of the two clusters (exact float ends, as `T` above; {+inf, -inf}: no window)
 };
 
 struct DevLibrary {

@@ -157,7 +157,7 @@ __host__ __device__ constexpr uint32_t task_rec_bytes() {
 }
 
 constexpr int kShards = 64; // task queue shards (= the wave size: a task wave finds its record with one scan over the shards)
-constexpr int kStatWords = 24;
+constexpr int kStatWords = 26;
 constexpr int kScreenStatShards = 64;
 
 // Device-side control block of one call (zeroed by ctl_clear_kernel at the start of every super-chunk).
@@ -214,10 +214,11 @@ struct ScreenParams {
     uint32_t qcap;             // records per shard
     uint32_t budget;           // passes after which a walker starts handing subtrees to the queue
     uint32_t min_levels;       // only subtrees with at least this many levels below their root are queued
-    uint32_t flags;            // 2: never queue, 4: no bound test, 8: exact Gaussian terms instead of the tabulated functions, 32768: no chain lengths (probe())
+    uint32_t flags;            // 2: never queue, 4: no bound test, 8: exact Gaussian terms instead of the tabulated functions, 32768: no chain lengths (probe()), 65536: no dead-entry test (build_tables)
     uint32_t max_nodes;        // of the library (sizes the LDS node tables)
     uint32_t last_round;       // task_kernel: never queue (walk every subtree to its end)
     uint32_t bound_cost; // per-candidate bounds are built when their cost estimate stays below this (build_bounds)
+    uint32_t dead_min_entries; // the dead-entry test (build_tables) runs for level pairs with at least this many entries
     float *scores;
     int32_t *status;
     int mode;                  // 0: slice pass over [lo, hi); 1: large-slice pass over ovf_list; 2: arena pass over carry_list; 3: arena pass over retry_in
@@ -408,7 +409,7 @@ __host__ __device__ inline WaveShape<G> wave_shape(int K, int max_nodes) {
     w.off_pool = o;
     o += G * 8;
     w.off_stat = o; // the wave's statistics (kept out of the registers)
-    o += 192; // sizeof(WaveStats)
+    o += 208; // sizeof(WaveStats)
     w.off_task = o; // subtree record of the root of the ligand in work
     o += task_rec_bytes<G>();
     o = (o + 15u) & ~15u;
@@ -455,8 +456,9 @@ struct WaveStats { // lives in LDS, updated by lane 0
     unsigned long long frames, passes, over, items, exact, longest, tasks, overflow;
     unsigned long long cyc_scan, cyc_tables, cyc_bounds, cyc_walk, exactv, npath, pad[2]; // s_memtime ticks per phase | self items evaluated term by term
     unsigned long long dbg[8]; // instrumented builds (-DPMX_COUNTERS): see walk()
+    unsigned long long dead, pad3; // pair entries the dead-entry test of build_tables settled without computing them
 };
-static_assert(sizeof(WaveStats) == 192, "WaveStats layout");
+static_assert(sizeof(WaveStats) == 208, "WaveStats layout");
 
 template <int G>
 struct Walk {
@@ -1491,7 +1493,7 @@ __device__ __forceinline__ void center_size(GlobalFloats xyz, int C, int start, 
 // The self / pair score tables of match_utils.py for the ligand whose levels are in LDS, into `rec`.
 template <int G, bool EXACT>
 __device__ __forceinline__ void build_tables(const ScreenParams &p, unsigned char *lds, const WaveShape<G> &ws, const Record &r, const LevelInfo &L,
-                                             unsigned char *rec, uint32_t &n_items, uint32_t &n_exact, uint32_t &n_exactv) {
+                                             unsigned char *rec, uint32_t &n_items, uint32_t &n_exact, uint32_t &n_exactv, uint32_t &n_dead) {
     constexpr int SLOTS = 64 / G;
     constexpr uint64_t GM = group_mask<G>();
     const int lane = lane_id();
@@ -1587,6 +1589,7 @@ __device__ __forceinline__ void build_tables(const ScreenParams &p, unsigned cha
                 pf[G + c] = lsize;
             }
             const bool staged = ni * nj <= dcap;
+            const bool dead_test = staged && ni <= 64 && nj <= 64 && !(p.flags & 65536u);
             PMX_TICK(1);
             if (staged) stage_distances(si, ni, sj, nj);
             else lds_sync();
@@ -1602,6 +1605,48 @@ __device__ __forceinline__ void build_tables(const ScreenParams &p, unsigned cha
                     bool pass = false;
                     for (int k = 0; k < C; ++k) pass = pass || !((fabsf(pf[k] - mp.x) - pf[G + k]) > mp.y);
                     pass = pass && in;
+                    // Dead entries. An entry that passes the prefilter is still -1 for every conformer when more than half of
+                    // its counted node pairs fail the 2-sigma majority test (match_utils.py:55-61, :71-74) - for a pocket of 20-40
+                    // clusters that is every second entry and every second item. A node pair whose distance lies outside the
+                    // hull of the windows of ALL model node pairs of the two clusters (DevModel::cwin, exact float ends) passes no
+                    // term, whatever the node subsets: it certainly fails. Counting those - two compares on a staged distance,
+                    // no function cell - gives a lower bound cf on an entry's fails per conformer, and 2 cf > L1 L2 for every
+                    // conformer settles the entry: its row is -1 and its mask empty, exactly what the items would have given.
+                    // (Lanes over entries like the prefilter: C x pairs trips per 64 entries against pairs x 64 / SLOTS item trips.)
+                    if (dead_test && E >= (int)p.dead_min_entries) {
+                        const float2 w = p.M.cwin[cand[i * ws.kp + sa] * K + cand[j * ws.kp + sb]];
+                        unsigned long long mu = 0ull, mv = 0ull; // nodes with a non-empty subset under the candidate (graph_match.py:164-171)
+                        if (pass) {
+                            const int rowa = nci + sa * ni, rowb = ncj + sb * nj;
+                            for (int u = 0; u < ni; ++u) mu |= (unsigned long long)(nc[rowa + u] != 0 ? 1 : 0) << u;
+                            for (int v = 0; v < nj; ++v) mv |= (unsigned long long)(nc[rowb + v] != 0 ? 1 : 0) << v;
+                        }
+                        const int L1L2 = (int)__popcll(mu) * (int)__popcll(mv);
+                        bool dead = pass && L1L2 > 0;
+                        constexpr int KB = G < 8 ? G : 8; // conformers per trip: their distances of a node pair are one batch of loads
+                        for (int k0 = 0; k0 < C; k0 += KB) {
+                            if (__ballot(dead) == 0ull) break;
+                            int cf[KB];
+#pragma unroll
+                            for (int kk = 0; kk < KB; ++kk) cf[kk] = 0;
+                            for (int u = 0; u < ni; ++u) {
+                                const int bu = (int)(mu >> u) & 1;
+                                for (int v = 0; v < nj; ++v) {
+                                    const int on_uv = bu & (int)(mv >> v);
+                                    const float *dp = dl + (u * nj + v) * G + k0; // (lanes of a slot past C hold copies of conformer C - 1)
+#pragma unroll
+                                    for (int kk = 0; kk < KB; ++kk) {
+                                        const float d = dp[kk];
+                                        cf[kk] += (on_uv & ((d < w.x || d > w.y) ? 1 : 0));
+                                    }
+                                }
+                            }
+#pragma unroll
+                            for (int kk = 0; kk < KB; ++kk) dead = dead && 2 * cf[kk] > L1L2;
+                        }
+                        n_dead += (uint32_t)__popcll(__ballot(dead));
+                        pass = pass && !dead;
+                    }
                     pbal = __ballot(pass);
                     if (in && !pass) {
                         float *row = Pt + (size_t)(row_i + (uint32_t)sa * nd_i + off_j + (uint32_t)sb) * G;
@@ -1992,9 +2037,9 @@ __device__ __forceinline__ unsigned char *prepare_ligand(const ScreenParams &p, 
     }
     if (lane <= L.nl) H->ksum[lane] = ksum[lane];
     if (lane < G) reinterpret_cast<unsigned long long *>(rec + sizeof(RecHeader))[lane] = 0ull;
-    uint32_t n_items = 0, n_exact = 0, n_exactv = 0;
+    uint32_t n_items = 0, n_exact = 0, n_exactv = 0, n_dead = 0;
     const unsigned long long t_b = __builtin_amdgcn_s_memtime();
-    build_tables<G, EXACT>(p, lds, ws, r, L, rec, n_items, n_exact, n_exactv);
+    build_tables<G, EXACT>(p, lds, ws, r, L, rec, n_items, n_exact, n_exactv, n_dead);
     wave_sync();
     const unsigned long long t_c = __builtin_amdgcn_s_memtime();
     build_bounds<G>(p, lds, ws, L, rec);
@@ -2016,6 +2061,7 @@ __device__ __forceinline__ unsigned char *prepare_ligand(const ScreenParams &p, 
     if (lane == 0) {
         stat->cyc_scan += t_b - t_a, stat->cyc_tables += t_c - t_b, stat->cyc_bounds += t_d - t_c;
         stat->items += n_items;
+        stat->dead += n_dead;
     }
     if (n_exact) atomicAdd(&stat->exact, (unsigned long long)n_exact);
     if (n_exactv) atomicAdd(&stat->exactv, (unsigned long long)n_exactv);
@@ -2181,6 +2227,7 @@ __device__ inline void flush_wave_stats(const ScreenParams &p, const WaveStats *
     atomicAdd(st + 13, stat->exactv);
     atomicAdd(st + 22, stat->npath);
     atomicAdd(st + 23, stat->dbg[7]);
+    atomicAdd(st + 24, stat->dead);
 #if defined(PMX_COUNTERS) || defined(PMX_TABLE_TICKS) || defined(PMX_TABLE_FILL) || defined(PMX_WALK_TICKS)
     for (int i = 0; i < 6; ++i) atomicAdd(st + 16 + i, stat->dbg[i]);
 #endif

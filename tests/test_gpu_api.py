@@ -234,6 +234,9 @@ def test_scores_do_not_depend_on_how_the_work_is_cut(monkeypatch):
         {"PMX_TREE_FLAGS": "1024", "PMX_BUDGET": "16", "PMX_MIN_LEVELS": "0"},
         {"PMX_TREE_FLAGS": "32768"},                 # probes search without the chain lengths (every dropped child is searched, every candidate tried)
         {"PMX_TREE_FLAGS": "32768", "PMX_BUDGET": "16", "PMX_MIN_LEVELS": "0"},
+        {"PMX_TREE_FLAGS": "65536"},                 # no dead-entry test in the table phase: every entry that passes the prefilter is computed
+        {"PMX_DEAD_MIN_ENTRIES": "1"},               # ... and the test on every level pair, however few entries it has
+        {"PMX_DEAD_MIN_ENTRIES": "1", "PMX_SLICE_KB": "8"},
         {"PMX_PATH_KB": "4"},                        # path sums of most ligands do not fit the wave's buffer: those do without the test
         {"PMX_PATH_KB": "4", "PMX_BUDGET": "32"},                   # children tested against the per-level bound instead of their own                   # a ligand's subtrees spread over the queue shards instead of kept in one
     ):
@@ -249,6 +252,10 @@ def test_scores_do_not_depend_on_how_the_work_is_cut(monkeypatch):
             assert stats["n_tasks"] == 0
         if env.get("PMX_TREE_FLAGS") == "32768" and "PMX_BUDGET" not in env:
             assert stats["n_probe_passes"] > 4 * stats_default["n_probe_passes"]  # what the chain lengths keep the probes from
+        if env.get("PMX_TREE_FLAGS") == "65536":
+            assert stats["n_dead_entries"] == 0 and stats["n_items"] >= stats_default["n_items"]
+        if env.get("PMX_DEAD_MIN_ENTRIES") == "1" and "PMX_SLICE_KB" not in env:
+            assert stats["n_dead_entries"] > 0 and stats["n_items"] < stats_default["n_items"]
         if env.get("PMX_TREE_FLAGS") == "4":
             assert stats["n_frames"] > 2 * stats_default["n_frames"]  # the bound test is what keeps the trees small
 

@@ -73,9 +73,10 @@ def test_zero_type_weight_matches_oracle(oracle):
 
 @pytest.mark.parametrize("env", [{"PMX_TREE_FLAGS": "8"}, {"PMX_TREE_FLAGS": "4"}, {"PMX_BUDGET": "16", "PMX_MIN_LEVELS": "0"},
                                  {"PMX_SLICE_KB": "4"}, {"PMX_SLICE_KB": "4", "PMX_ARENA_MB": "16", "PMX_BUDGET": "64"},
-                                 {"PMX_TREE_FLAGS": "128"}, {"PMX_TREE_FLAGS": "1024"}, {"PMX_PATH_KB": "2"}, {"PMX_TREE_FLAGS": "32768"}],
+                                 {"PMX_TREE_FLAGS": "128"}, {"PMX_TREE_FLAGS": "1024"}, {"PMX_PATH_KB": "2"}, {"PMX_TREE_FLAGS": "32768"},
+                                 {"PMX_TREE_FLAGS": "65536"}, {"PMX_DEAD_MIN_ENTRIES": "1"}],
                          ids=["exact-terms", "no-bound-test", "tiny-budget", "tiny-slices", "tiny-slices-and-arena", "no-candidate-filter",
-                              "no-path-bound", "tiny-path-buffer", "no-chain-lengths"])
+                              "no-path-bound", "tiny-path-buffer", "no-chain-lengths", "no-dead-entry-test", "dead-entry-test-everywhere"])
 @pytest.mark.parametrize("name", GOLDEN_SETS)
 def test_engine_settings_match_reference_golden(name, env, monkeypatch):
     """The golden sets under settings that force the rarely taken paths of the engine: Gaussian terms evaluated one by
@@ -236,6 +237,37 @@ def test_sixteen_pockets_one_library():
     assert np.all(got[zero] == 0.0)
     assert rel_err(got[~zero], ref[~zero]).max() < RTOL + 6e-8
     assert np.count_nonzero(ref) > ref.size // 2
+
+
+def test_dead_entry_test_changes_no_score(monkeypatch):
+    """The table phase settles a pair entry as -1 without computing its items when more than half of its node pairs lie outside
+    every 2-sigma window of the two model clusters for every conformer (build_tables, DevModel::cwin) - which is what the items
+    would have given (match_utils.py:55-61, :71-74). Sixteen pockets x 3 000 ligands (8 conformers) and the 64-node model x 64
+    conformers: the same bits with the test off, at its default and on every level pair; and it does settle entries."""
+    import torch
+
+    from pharmaconet_amd import PharmacophoreModel, engine
+    from pharmaconet_amd.engine import DeviceLibrary
+    from pharmaconet_amd.synthetic import synthetic_library
+
+    model8, _, _, _ = load_golden("set_6oim_c8")
+    lib8 = DeviceLibrary(synthetic_library(3000, num_conformers=8, model_nodes=_model_nodes(model8), active_fraction=0.3, seed=777))
+    model64, _, _, _ = load_golden("set_s64_c64")
+    lib64 = DeviceLibrary(synthetic_library(300, num_conformers=64, model_nodes=_model_nodes(model64), active_fraction=0.3, seed=778,
+                                            conformer_noise=0.0))
+    cases = [(PharmacophoreModel.load(GOLDEN / "pockets16" / f"model_{k:02d}.pm"), lib8) for k in range(16)] + [(model64, lib64)]
+    for model, lib in cases:
+        got, dead, items = {}, {}, {}
+        for tag, env in (("off", {"PMX_TREE_FLAGS": "65536"}), ("default", {}), ("everywhere", {"PMX_DEAD_MIN_ENTRIES": "1"})):
+            with monkeypatch.context() as mp:
+                for k, v in env.items():
+                    mp.setenv(k, v)
+                got[tag] = model.screen(lib).scores
+                st = engine.last_score_stats()
+                dead[tag], items[tag] = st["n_dead_entries"], st["n_items"]
+        assert torch.equal(got["off"], got["default"]) and torch.equal(got["off"], got["everywhere"])
+        assert dead["off"] == 0 and dead["everywhere"] >= dead["default"] > 0
+        assert items["everywhere"] <= items["default"] < items["off"]
 
 
 def test_sixteen_pockets_at_shard_size(oracle):
