@@ -25,8 +25,10 @@ extern "C" {
 
 #define PMX_NUM_TYPES 7          /* Hydrophobic, Aromatic, Cation, Anion, HBond_donor, HBond_acceptor, Halogen */
 #define PMX_MAX_LEVELS 20        /* src/pmnet/scoring/graph_match.py:88 */
-#define PMX_MAX_MODEL_NODES 64
-#define PMX_MAX_MODEL_CLUSTERS 64
+#define PMX_MAX_MODEL_NODES 256   /* node sets are lists on the device; cluster_nodes is a bit mask of ceil(n_nodes / 64) words */
+#define PMX_MAX_MODEL_CLUSTERS 128 /* candidate sets of a ligand cluster are two 64-bit words */
+#define PMX_MAX_LEVEL_CANDIDATES 64 /* model clusters that share a type with ONE ligand cluster (a tree level's candidates): a ligand
+                                       with a cluster beyond that is reported PMX_LIGAND_UNSUPPORTED (only models of more than 64 clusters can do that) */
 #define PMX_MAX_LIGAND_NODES 64
 #define PMX_MAX_LIGAND_CLUSTERS 64
 #define PMX_MAX_CONFORMERS 64
@@ -62,7 +64,8 @@ typedef struct {
     const uint8_t *node_type;        /* [n_nodes] type id 0..6 */
     const float *edge_mean;          /* [n_nodes * n_nodes] */
     const float *edge_std;           /* [n_nodes * n_nodes] */
-    const uint64_t *cluster_nodes;   /* [n_clusters] bit m = node m belongs to the cluster */
+    const uint64_t *cluster_nodes;   /* [n_clusters * W], W = max(1, ceil(n_nodes / 64)): bit (m % 64) of word a * W + m / 64 = node m belongs
+                                        to cluster a (one word per cluster for models of up to 64 nodes) */
     const uint8_t *cluster_typemask; /* [n_clusters] */
     const double *cluster_center;    /* [n_clusters * 3] */
     const double *cluster_size;      /* [n_clusters] */

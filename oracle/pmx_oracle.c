@@ -51,7 +51,7 @@ static void arena_reset(void) {
 }
 
 #define MAX_LEVELS 20 /* scoring/graph_match.py:88 */
-#define MAX_K 64
+#define MAX_K 128
 #define MAX_N 64
 #define MAX_C 64
 
@@ -60,7 +60,7 @@ typedef struct {
     const uint8_t *node_type;        /* [Nm] */
     const float *edge_mean;          /* [Nm*Nm] */
     const float *edge_std;           /* [Nm*Nm] */
-    const uint64_t *cluster_nodes;   /* [K] */
+    const uint64_t *cluster_nodes;   /* [K * W], W = max(1, ceil(n_nodes / 64)): bit m % 64 of word a * W + m / 64 <=> node m in cluster a */
     const uint8_t *cluster_typemask; /* [K] */
     const double *cluster_center;    /* [K*3] */
     const double *cluster_size;      /* [K] */
@@ -204,6 +204,7 @@ static void node_pair_term(ctx_t *X, const node_match *a, const node_match *b, f
 static void build_node_matches(ctx_t *X, const float w[7]) {
     const oracle_model *M = X->M;
     const ligand_t *L = &X->L;
+    const int nw = M->n_nodes > 64 ? (M->n_nodes + 63) / 64 : 1;
     for (int i = 0; i < X->nl; ++i) {
         int ci = X->lev_cluster[i];
         int start = ci ? L->cluster_end[ci - 1] : 0, end = L->cluster_end[ci];
@@ -217,7 +218,7 @@ static void build_node_matches(ctx_t *X, const float w[7]) {
                 it->u = u;
                 it->nm = 0;
                 for (int m = 0; m < M->n_nodes; ++m) /* graph_match.py:148-150 */
-                    if (((M->cluster_nodes[a] >> m) & 1) && ((L->typemask[u] >> M->node_type[m]) & 1)) {
+                    if (((M->cluster_nodes[(size_t)a * nw + (m >> 6)] >> (m & 63)) & 1) && ((L->typemask[u] >> M->node_type[m]) & 1)) {
                         it->m[it->nm] = (uint8_t)m;
                         it->w[it->nm] = w[M->node_type[m]]; /* :151-154 */
                         it->nm++;
@@ -416,6 +417,15 @@ int oracle_score(const oracle_model *M, const uint64_t *offsets, const uint8_t *
 int oracle_score_variant(const oracle_model *M, const uint64_t *offsets, const uint8_t *data, uint64_t first, uint64_t count,
                          const float weights[7], double *scores, oracle_result *results, int num_threads, int variant) {
     if (num_threads < 1) num_threads = 1;
+    if (M->n_clusters > MAX_K || M->n_nodes > 256) return 2; /* fixed-size tables of this restatement */
+    {
+        const int nw = M->n_nodes > 64 ? (M->n_nodes + 63) / 64 : 1;
+        for (int a = 0; a < M->n_clusters; ++a) { /* node_match holds 64 model nodes */
+            int cnt = 0;
+            for (int w = 0; w < nw; ++w) cnt += __builtin_popcountll(M->cluster_nodes[(size_t)a * nw + w]);
+            if (cnt > 64) return 3;
+        }
+    }
     int64_t n = (int64_t)count;
 #pragma omp parallel for schedule(dynamic, 16) num_threads(num_threads)
     for (int64_t i = 0; i < n; ++i) {

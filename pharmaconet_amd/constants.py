@@ -48,8 +48,8 @@ CLUSTER_PRIORITY: dict[str, tuple[int, int]] = {
 MAX_LEVELS = 20
 
 # Device-side structural limits of this implementation (not of the reference).
-MAX_MODEL_NODES = 64  # model node sets are 64-bit masks
-MAX_MODEL_CLUSTERS = 64  # candidate sets are 64-bit masks
+MAX_MODEL_NODES = 256  # include/pmx.h PMX_MAX_MODEL_NODES (node sets are lists on the device)
+MAX_MODEL_CLUSTERS = 128  # PMX_MAX_MODEL_CLUSTERS (candidate sets of a ligand cluster are two 64-bit words)
 MAX_LIGAND_NODES = 64
 MAX_LIGAND_CLUSTERS = 64
 MAX_CONFORMERS = 64  # one wavefront lane per conformer

@@ -78,12 +78,30 @@ struct pmx_model {
     uint32_t NS = 0, NF = 0, ncell = 0;
     float h = 0.f;
     uint16_t *sidtab = nullptr;  // device [K * 128]
-    uint64_t *subnodes = nullptr; // device [NS]
+    uint32_t *sub_off = nullptr;  // device [NS + 1]: the nodes of subset s are sub_nodes[sub_off[s] .. sub_off[s + 1]), ascending
+    uint8_t *sub_nodes = nullptr; // device
     float2 *win = nullptr;        // device [NS * NS * ncell] exact pass windows
     uint64_t n_complex_cells = 0;
     std::mutex fn_mu;
     std::vector<FnEntry> fn;
     uint64_t fn_stamp = 0;
+};
+
+// A set of model nodes (PMX_MAX_MODEL_NODES bits).
+struct NodeSet {
+    static constexpr int W = PMX_MAX_MODEL_NODES / 64;
+    uint64_t w[W] = {};
+    bool any() const { for (int i = 0; i < W; ++i) if (w[i]) return true; return false; }
+    int count() const { int c = 0; for (int i = 0; i < W; ++i) c += __builtin_popcountll(w[i]); return c; }
+    void set(int m) { w[m >> 6] |= 1ull << (m & 63); }
+    bool operator==(const NodeSet &o) const { return std::memcmp(w, o.w, sizeof(w)) == 0; }
+    NodeSet operator&(const NodeSet &o) const { NodeSet r; for (int i = 0; i < W; ++i) r.w[i] = w[i] & o.w[i]; return r; }
+    std::vector<int> list() const { // ascending
+        std::vector<int> v;
+        for (int i = 0; i < W; ++i)
+            for (uint64_t x = w[i]; x; x &= x - 1) v.push_back(i * 64 + __builtin_ctzll(x));
+        return v;
+    }
 };
 
 // Largest float T with fl(T / std) < 2 under round-to-nearest-even float32 division: the quotient
@@ -130,15 +148,15 @@ static bool edge_window(float mean, float T, float &lo, float &hi) {
     return true;
 }
 
-static int build_pair_functions(pmx_model *m, const pmx_model_desc *d, const std::vector<uint64_t> &cnodes, const uint64_t *tnodes) {
+static int build_pair_functions(pmx_model *m, const pmx_model_desc *d, const std::vector<NodeSet> &cnodes, const NodeSet *tnodes) {
     const int Nm = m->dm.Nm, K = m->dm.K;
     // node subsets: (model cluster, ligand type mask) -> the cluster's nodes of those types (graph_match.py:148-150)
-    std::vector<uint64_t> subs(1, 0ull);
+    std::vector<NodeSet> subs(1);
     std::vector<uint16_t> sidtab((size_t)std::max(K, 1) * 128, 0);
     for (int a = 0; a < K; ++a)
         for (int mask = 0; mask < 128; ++mask) {
-            const uint64_t nodes = cnodes[a] & tnodes[mask];
-            if (!nodes) continue;
+            const NodeSet nodes = cnodes[a] & tnodes[mask];
+            if (!nodes.any()) continue;
             size_t id = 1;
             for (; id < subs.size(); ++id)
                 if (subs[id] == nodes) break;
@@ -146,6 +164,17 @@ static int build_pair_functions(pmx_model *m, const pmx_model_desc *d, const std
             sidtab[(size_t)a * 128 + mask] = (uint16_t)id;
         }
     const uint32_t NS = (uint32_t)subs.size();
+    if (NS > 65535u) return fail(PMX_ERR_INVALID, "model has %u distinct node subsets (max 65535)", NS);
+    std::vector<std::vector<int>> sublist(NS);
+    std::vector<uint32_t> sub_off(NS + 1, 0);
+    std::vector<uint8_t> sub_nodes;
+    for (uint32_t s = 0; s < NS; ++s) {
+        sublist[s] = subs[s].list();
+        sub_off[s] = (uint32_t)sub_nodes.size();
+        for (int x : sublist[s]) sub_nodes.push_back((uint8_t)x);
+    }
+    sub_off[NS] = (uint32_t)sub_nodes.size();
+    if (sub_nodes.empty()) sub_nodes.push_back(0);
     // grid: h = the largest power of two <= std_min / 4 (quintic Hermite error < 6e-8 of the peak, measured), range to mean + 7 std
     float std_min = 1e30f, dmax = 1.f;
     for (int i = 0; i < Nm * Nm; ++i) {
@@ -174,16 +203,16 @@ static int build_pair_functions(pmx_model *m, const pmx_model_desc *d, const std
         for (uint32_t sb = 0; sb < NS; ++sb) {
             if (tri && sb > sa) continue;
             float2 *out = win.data() + (size_t)(tri ? sa * (sa + 1) / 2 + sb : sa * NS + sb) * ncell;
-            const uint64_t A = subs[sa], B = subs[sb];
-            if (!A || !B) { // no item: never a fail
+            const std::vector<int> &A = sublist[sa], &B = sublist[sb];
+            if (A.empty() || B.empty()) { // no item: never a fail
                 for (uint32_t i = 0; i < ncell; ++i) out[i] = make_float2(-INF, INF);
                 continue;
             }
-            const int mn = __builtin_popcountll(A) * __builtin_popcountll(B);
+            const int mn = (int)(A.size() * B.size());
             ev.clear();
-            for (uint64_t am = A; am; am &= am - 1)
-                for (uint64_t bm = B; bm; bm &= bm - 1) {
-                    const int e = __builtin_ctzll(am) * Nm + __builtin_ctzll(bm);
+            for (const int am : A)
+                for (const int bm : B) {
+                    const int e = am * Nm + bm;
                     if (!wok[e]) continue;
                     ev.emplace_back(wlo[e], +1);
                     ev.emplace_back(std::nextafterf(whi[e], INF), -1); // first float after the window
@@ -218,10 +247,12 @@ static int build_pair_functions(pmx_model *m, const pmx_model_desc *d, const std
             }
         }
     HIPCHECK(hipMalloc((void **)&m->sidtab, sidtab.size() * 2));
-    HIPCHECK(hipMalloc((void **)&m->subnodes, (size_t)NS * 8));
+    HIPCHECK(hipMalloc((void **)&m->sub_off, (size_t)(NS + 1) * 4));
+    HIPCHECK(hipMalloc((void **)&m->sub_nodes, sub_nodes.size()));
     HIPCHECK(hipMalloc((void **)&m->win, win.size() * sizeof(float2)));
     HIPCHECK(hipMemcpy(m->sidtab, sidtab.data(), sidtab.size() * 2, hipMemcpyHostToDevice));
-    HIPCHECK(hipMemcpy(m->subnodes, subs.data(), (size_t)NS * 8, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(m->sub_off, sub_off.data(), (size_t)(NS + 1) * 4, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(m->sub_nodes, sub_nodes.data(), sub_nodes.size(), hipMemcpyHostToDevice));
     HIPCHECK(hipMemcpy(m->win, win.data(), win.size() * sizeof(float2), hipMemcpyHostToDevice));
     m->NS = NS;
     m->NF = NF;
@@ -274,7 +305,7 @@ static int pair_functions(pmx_model *m, const Weights &W, hipStream_t stream, Fn
             HIPCHECK(hipDeviceSynchronize());
         }
         hit->W = W;
-        fn_build_kernel<<<dim3(m->NF), dim3(128), 0, stream>>>(m->dm, W, m->subnodes, m->NS, m->ncell, m->h, m->win, hit->cells, fn_rel_tol(), fn_max_exponent());
+        fn_build_kernel<<<dim3(m->NF), dim3(128), 0, stream>>>(m->dm, W, m->sub_off, m->sub_nodes, m->NS, m->ncell, m->h, m->win, hit->cells, fn_rel_tol(), fn_max_exponent());
         HIPCHECK(hipGetLastError());
         HIPCHECK(hipEventRecord(hit->ready, stream));
     } else {
@@ -302,18 +333,16 @@ extern "C" int pmx_model_create(const pmx_model_desc *d, int device, pmx_model *
     const size_t n_edge = (size_t)Nm * Nm, n_pair = (size_t)K * K;
     const size_t off_edge = 0;
     const size_t off_type = off_edge + round16(n_edge * sizeof(float4));
-    const size_t off_cnodes = off_type + 64;
-    const size_t off_tnodes = off_cnodes + 64 * 8;
-    const size_t off_tclus = off_tnodes + 128 * 8;
-    const size_t off_cpair = off_tclus + 128 * 8;
+    const size_t off_tclus = off_type + PMX_MAX_MODEL_NODES;
+    const size_t off_cpair = off_tclus + 128 * 16;
     const size_t off_cwin = off_cpair + round16(n_pair * sizeof(float2));
     const size_t total = off_cwin + round16(n_pair * sizeof(float2)) + 16;
     std::vector<unsigned char> host(total, 0);
     float4 *edge = reinterpret_cast<float4 *>(host.data() + off_edge);
     uint8_t *ntype = host.data() + off_type;
-    uint64_t *cnodes = reinterpret_cast<uint64_t *>(host.data() + off_cnodes);
-    uint64_t *tnodes = reinterpret_cast<uint64_t *>(host.data() + off_tnodes);
-    uint64_t *tclus = reinterpret_cast<uint64_t *>(host.data() + off_tclus);
+    uint64_t *tclus = reinterpret_cast<uint64_t *>(host.data() + off_tclus); // [128][2]
+    std::vector<NodeSet> cnodes((size_t)std::max(K, 1));
+    NodeSet tnodes[128];
     float2 *cpair = reinterpret_cast<float2 *>(host.data() + off_cpair);
     float2 *cwin = reinterpret_cast<float2 *>(host.data() + off_cwin);
 
@@ -323,20 +352,26 @@ extern "C" int pmx_model_create(const pmx_model_desc *d, int device, pmx_model *
         if (!(sd > 0.f)) return fail(PMX_ERR_INVALID, "edge %zu has distance_std %g", i, (double)sd);
         edge[i] = make_float4(mean, (float)(s_const / (double)sd), pass_threshold(sd), sd);
     }
-    uint64_t type_nodes[PMX_NUM_TYPES] = {0};
+    NodeSet type_nodes[PMX_NUM_TYPES];
     for (int m = 0; m < Nm; ++m) {
         ntype[m] = d->node_type[m];
-        type_nodes[d->node_type[m]] |= 1ull << m;
+        type_nodes[d->node_type[m]].set(m);
     }
-    for (int a = 0; a < K; ++a) cnodes[a] = d->cluster_nodes[a];
+    const int NW = std::max(1, (Nm + 63) / 64); // words per cluster in cluster_nodes
+    for (int a = 0; a < K; ++a)
+        for (int m = 0; m < Nm; ++m)
+            if (d->cluster_nodes[(size_t)a * NW + (m >> 6)] >> (m & 63) & 1) cnodes[a].set(m);
     for (int mask = 0; mask < 128; ++mask) {
-        uint64_t nodes = 0, clus = 0;
+        NodeSet nodes;
+        uint64_t clus[2] = {0, 0};
         for (int t = 0; t < PMX_NUM_TYPES; ++t)
-            if (mask >> t & 1) nodes |= type_nodes[t];
+            if (mask >> t & 1)
+                for (int i = 0; i < NodeSet::W; ++i) nodes.w[i] |= type_nodes[t].w[i];
         for (int a = 0; a < K; ++a)
-            if (d->cluster_typemask[a] & mask) clus |= 1ull << a;
+            if (d->cluster_typemask[a] & mask) clus[a >> 6] |= 1ull << (a & 63);
         tnodes[mask] = nodes;
-        tclus[mask] = clus;
+        tclus[2 * mask] = clus[0];
+        tclus[2 * mask + 1] = clus[1];
     }
     for (int a = 0; a < K; ++a)
         for (int b = 0; b < K; ++b) {
@@ -353,9 +388,9 @@ extern "C" int pmx_model_create(const pmx_model_desc *d, int device, pmx_model *
         for (int a = 0; a < K; ++a)
             for (int b = 0; b < K; ++b) {
                 float lo = INFINITY, hi = -INFINITY;
-                for (uint64_t am = d->cluster_nodes[a]; am; am &= am - 1)
-                    for (uint64_t bm = d->cluster_nodes[b]; bm; bm &= bm - 1) {
-                        const size_t e = (size_t)__builtin_ctzll(am) * Nm + __builtin_ctzll(bm);
+                for (const int am : cnodes[a].list())
+                    for (const int bm : cnodes[b].list()) {
+                        const size_t e = (size_t)am * Nm + bm;
                         if (!wok[e]) continue;
                         lo = std::min(lo, wlo[e]);
                         hi = std::max(hi, whi[e]);
@@ -388,14 +423,11 @@ extern "C" int pmx_model_create(const pmx_model_desc *d, int device, pmx_model *
     m->dm.pad_ = 0;
     m->dm.edge = reinterpret_cast<const float4 *>(b8 + off_edge);
     m->dm.node_type = b8 + off_type;
-    m->dm.cnodes = reinterpret_cast<const uint64_t *>(b8 + off_cnodes);
-    m->dm.tnodes = reinterpret_cast<const uint64_t *>(b8 + off_tnodes);
     m->dm.tclus = reinterpret_cast<const uint64_t *>(b8 + off_tclus);
     m->dm.cpair = reinterpret_cast<const float2 *>(b8 + off_cpair);
     m->dm.cwin = reinterpret_cast<const float2 *>(b8 + off_cwin);
     {
-        std::vector<uint64_t> cn(cnodes, cnodes + 64);
-        const int rc = build_pair_functions(m, d, cn, tnodes);
+        const int rc = build_pair_functions(m, d, cnodes, tnodes);
         if (rc != PMX_OK) {
             pmx_model_destroy(m);
             return rc;
@@ -410,7 +442,8 @@ extern "C" int pmx_model_destroy(pmx_model *m) {
     (void)hipSetDevice(m->device);
     (void)hipFree(m->blob);
     if (m->sidtab) (void)hipFree(m->sidtab);
-    if (m->subnodes) (void)hipFree(m->subnodes);
+    if (m->sub_off) (void)hipFree(m->sub_off);
+    if (m->sub_nodes) (void)hipFree(m->sub_nodes);
     if (m->win) (void)hipFree(m->win);
     for (FnEntry &e : m->fn) {
         if (e.cells) (void)hipFree(e.cells);
@@ -665,7 +698,8 @@ static int score_screen(const pmx_model *const *models, int n_models, const pmx_
         if (rc) return rc;
         p.lib = lib->dl;
         p.sidtab = model->sidtab;
-        p.subnodes = model->subnodes;
+        p.sub_off = model->sub_off;
+        p.sub_nodes = model->sub_nodes;
         p.W = W;
         p.first = first;
         p.flags = flags;
@@ -689,7 +723,7 @@ static int score_screen(const pmx_model *const *models, int n_models, const pmx_
         // PMX_BIG_SLICE_MB each, PMX_BIG_TOTAL_MB together (what is larger still goes to the arena)
         {
             const uint64_t nlmax = (uint64_t)std::min<int>(PMX_MAX_LEVELS, std::max(1, lib->info.max_clusters));
-            const uint64_t K = (uint64_t)std::max(1, model->dm.K);
+            const uint64_t K = (uint64_t)std::max(1, std::min(model->dm.K, PMX_MAX_LEVEL_CANDIDATES)); // (candidates per level)
             const uint64_t worst = rec_bytes<G>((uint32_t)(nlmax * K), (uint32_t)(nlmax * (nlmax - 1) / 2 * K * K), (uint32_t)nlmax);
             const uint64_t cap = (uint64_t)std::max<long>(1, env_long("PMX_BIG_SLICE_MB", G >= 32 ? 4 : 32)) << 20;
             pl.worst_bytes = worst;
@@ -700,7 +734,7 @@ static int score_screen(const pmx_model *const *models, int n_models, const pmx_
         big_need = std::max(big_need, (size_t)pl.big_grid * pl.big_bytes);
         if (cand_bounds<G>()) { // float[matches <= levels][candidates of all levels][G], at most 1 MB per wavefront (larger jobs do without)
             const uint64_t nlmax = (uint64_t)std::min<int>(PMX_MAX_LEVELS, std::max(1, lib->info.max_clusters));
-            const uint64_t need = (nlmax + 1) * nlmax * (uint64_t)std::max(1, model->dm.K) * G * 4;
+            const uint64_t need = (nlmax + 1) * nlmax * (uint64_t)std::max(1, std::min(model->dm.K, PMX_MAX_LEVEL_CANDIDATES)) * G * 4;
             pl.pa_bytes = (uint32_t)std::min<uint64_t>((need + 255) & ~255ull, (uint64_t)std::max<long>(1, env_long("PMX_PATH_KB", 1024)) << 10);
             pabuf_need = std::max(pabuf_need, (size_t)grid * pl.pa_bytes * 2u); // ligand kernel | task kernel
         }

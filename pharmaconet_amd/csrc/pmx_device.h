@@ -17,10 +17,8 @@ struct DevModel {
     int32_t symmetric;        // edge[m][n] == edge[n][m] bit for bit (distances are; checked when the model is created)
     int32_t pad_;
     const float4 *edge;       // [Nm * Nm]
-    const uint8_t *node_type; // [64]
-    const uint64_t *cnodes;   // [64]   model cluster -> node set
-    const uint64_t *tnodes;   // [128]  ligand node type mask -> model nodes of any of those types
-    const uint64_t *tclus;    // [128]  ligand cluster type mask -> model clusters sharing a type (graph_match.py:130-134)
+    const uint8_t *node_type; // [PMX_MAX_MODEL_NODES]
+    const uint64_t *tclus;    // [128][2] ligand cluster type mask -> model clusters sharing a type (graph_match.py:130-134), 128 bits
     const float2 *cpair;      // [K * K] {float32(|center_a - center_b|), float32(size_a + size_b)}  (graph_match.py:263-265)
     const float2 *cwin;       // [K * K] {lo, hi}: the hull of the 2-sigma pass windows of every node pair (m in a, n in b) - a ligand
                               // node pair at a distance outside it fails the majority test of match_utils.py:55-61 against every

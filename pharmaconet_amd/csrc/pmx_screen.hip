@@ -196,7 +196,8 @@ struct ScreenParams {
     FnTable F;
     DevLibrary lib;
     const uint16_t *sidtab;    // [K * 128] node subset of (model cluster, ligand type mask); 0 = empty
-    const uint64_t *subnodes;  // [NS] node set of a subset
+    const uint32_t *sub_off;   // [NS + 1] the model nodes of node subset s: sub_nodes[sub_off[s] .. sub_off[s + 1]), ascending (0 = the empty subset)
+    const uint8_t *sub_nodes;
     Weights W;                 // for the exact-term debug path
     uint64_t first;            // library index of the call's first ligand
     uint32_t lo, hi;           // ligands [lo, hi) of the call (relative to first) are this super-chunk
@@ -287,7 +288,7 @@ __device__ inline float norm3f(float dx, float dy, float dz) { // np.linalg.norm
 // Tabulates F_(sa, sb)(d) for every pair of node subsets on the grid x_i = i * h: quintic Hermite cells from F, F', F''
 // at the two ends of a cell, evaluated in float64. `win` holds the exact pass windows of every cell (host, model-only).
 // A subset pair with a zero weight sum scores NaN in the reference (0 * (1 / 0), match_utils.py:50-52,69): NaN cells.
-__global__ void fn_build_kernel(DevModel M, Weights W, const uint64_t *subnodes, uint32_t NS, uint32_t ncell, float h,
+__global__ void fn_build_kernel(DevModel M, Weights W, const uint32_t *sub_off, const uint8_t *sub_nodes, uint32_t NS, uint32_t ncell, float h,
                                 const float2 *win, FnCell *cells, double rel_tol, double max_exponent) {
     const uint32_t fid = blockIdx.x;
     uint32_t sa, sb;
@@ -299,24 +300,25 @@ __global__ void fn_build_kernel(DevModel M, Weights W, const uint64_t *subnodes,
     } else {
         sa = fid / NS, sb = fid - sa * NS;
     }
-    const uint64_t A = subnodes[sa], B = subnodes[sb];
+    const uint8_t *A = sub_nodes + sub_off[sa], *B = sub_nodes + sub_off[sb];
+    const int nA = (int)(sub_off[sa + 1] - sub_off[sa]), nB = (int)(sub_off[sb + 1] - sub_off[sb]);
     const int Nm = M.Nm;
     bool a_nz = false, b_nz = false;
-    for (uint64_t x = A; x; x &= x - 1) a_nz = a_nz || W.w[M.node_type[__ffsll((unsigned long long)x) - 1]] != 0.f;
-    for (uint64_t x = B; x; x &= x - 1) b_nz = b_nz || W.w[M.node_type[__ffsll((unsigned long long)x) - 1]] != 0.f;
-    const bool empty = A == 0 || B == 0;
+    for (int i = 0; i < nA; ++i) a_nz = a_nz || W.w[M.node_type[A[i]]] != 0.f;
+    for (int i = 0; i < nB; ++i) b_nz = b_nz || W.w[M.node_type[B[i]]] != 0.f;
+    const bool empty = nA == 0 || nB == 0;
     const bool nanfn = !empty && (!a_nz || !b_nz);
-    const double inv_mn = empty ? 0.0 : 1.0 / (double)(__popcll(A) * __popcll(B));
+    const double inv_mn = empty ? 0.0 : 1.0 / (double)(nA * nB);
     for (uint32_t i = threadIdx.x; i < ncell; i += blockDim.x) {
         double f[2], d1[2], d2[2];
         for (int e = 0; e < 2; ++e) {
             const double x = (double)(i + e) * (double)h;
             double s0 = 0.0, s1 = 0.0, s2 = 0.0;
             if (!empty && !nanfn) {
-                for (uint64_t am = A; am; am &= am - 1) {
-                    const int m = __ffsll((unsigned long long)am) - 1;
-                    for (uint64_t bm = B; bm; bm &= bm - 1) {
-                        const int n = __ffsll((unsigned long long)bm) - 1;
+                for (int ia = 0; ia < nA; ++ia) {
+                    const int m = A[ia];
+                    for (int ib = 0; ib < nB; ++ib) {
+                        const int n = B[ib];
                         const float4 eg = M.edge[m * Nm + n]; // {mean, s, T, std}
                         const float wprod = W.w[M.node_type[m]] * W.w[M.node_type[n]];
                         const double coef = (double)(wprod / eg.w); // weights / stds in float32 (match_utils.py:65)
@@ -346,10 +348,10 @@ __global__ void fn_build_kernel(DevModel M, Weights W, const uint64_t *subnodes,
             for (int k = 0; k < 8 && !rough; ++k) {
                 const double t = ((double)k + 0.5) * 0.125, x = ((double)i + t) * (double)h;
                 double s0 = 0.0, e0 = 0.0;
-                for (uint64_t am = A; am; am &= am - 1) {
-                    const int m = __ffsll((unsigned long long)am) - 1;
-                    for (uint64_t bm = B; bm; bm &= bm - 1) {
-                        const int n = __ffsll((unsigned long long)bm) - 1;
+                for (int ia = 0; ia < nA; ++ia) {
+                    const int m = A[ia];
+                    for (int ib = 0; ib < nB; ++ib) {
+                        const int n = B[ib];
                         const float4 eg = M.edge[m * Nm + n];
                         const float wprod = W.w[M.node_type[m]] * W.w[M.node_type[n]];
                         const double z = (x - (double)eg.x) / (double)eg.w;
@@ -1249,21 +1251,23 @@ __device__ __forceinline__ uint32_t fn_index(const FnTable &F, uint32_t sidu, ui
 // an IEEE division, exp(-0.5 z^2) to float32 accuracy, the likelihood added up in the order of itertools.product, then
 // likelihood * (1 / weights_sum) * (weights_sum / num_match). A subset pair whose weights sum to 0 gives NaN like the
 // reference (x * inf * 0). np = the terms within 2 sigma (:56-60). A, B non-empty.
-__device__ __forceinline__ float exact_value(const ScreenParams &p, uint64_t A, uint64_t B, float d, int &np) {
+__device__ __forceinline__ float exact_value(const ScreenParams &p, uint32_t sidu, uint32_t sidv, float d, int &np, int &mn) {
+    const uint8_t *A = p.sub_nodes + p.sub_off[sidu], *B = p.sub_nodes + p.sub_off[sidv];
+    const int nA = (int)(p.sub_off[sidu + 1] - p.sub_off[sidu]), nB = (int)(p.sub_off[sidv + 1] - p.sub_off[sidv]);
     float weights_sum = 0.f;
-    for (uint64_t am = A; am; am &= am - 1) {
-        const float wa = p.W.w[p.M.node_type[__ffsll((unsigned long long)am) - 1]];
-        for (uint64_t bm = B; bm; bm &= bm - 1) weights_sum = weights_sum + wa * p.W.w[p.M.node_type[__ffsll((unsigned long long)bm) - 1]];
+    for (int ia = 0; ia < nA; ++ia) {
+        const float wa = p.W.w[p.M.node_type[A[ia]]];
+        for (int ib = 0; ib < nB; ++ib) weights_sum = weights_sum + wa * p.W.w[p.M.node_type[B[ib]]];
     }
-    const int mn = __popcll(A) * __popcll(B);
+    mn = nA * nB;
     const float normalize_coeff = 1.0f / weights_sum, score_coeff = weights_sum / (float)mn;
     float likelihood = 0.f;
     np = 0;
-    for (uint64_t am = A; am; am &= am - 1) {
-        const int m = __ffsll((unsigned long long)am) - 1;
+    for (int ia = 0; ia < nA; ++ia) {
+        const int m = A[ia];
         const float wa = p.W.w[p.M.node_type[m]];
-        for (uint64_t bm = B; bm; bm &= bm - 1) {
-            const int n = __ffsll((unsigned long long)bm) - 1;
+        for (int ib = 0; ib < nB; ++ib) {
+            const int n = B[ib];
             const float4 e = p.M.edge[m * p.M.Nm + n]; // {mean, s, T, std}
             const float t = d - e.x, z = t / e.w;
             np += fabsf(t) <= e.z ? 1 : 0; // == abs(z) < 2 (pmx_device.h)
@@ -1272,6 +1276,18 @@ __device__ __forceinline__ float exact_value(const ScreenParams &p, uint64_t A, 
         }
     }
     return likelihood * normalize_coeff * score_coeff;
+}
+// The terms of the subset pair within 2 sigma at distance d against half of their number (match_utils.py:56-61): does the item fail?
+__device__ __forceinline__ bool majority_fails(const ScreenParams &p, uint32_t sidu, uint32_t sidv, float d) {
+    const uint8_t *A = p.sub_nodes + p.sub_off[sidu], *B = p.sub_nodes + p.sub_off[sidv];
+    const int nA = (int)(p.sub_off[sidu + 1] - p.sub_off[sidu]), nB = (int)(p.sub_off[sidv + 1] - p.sub_off[sidv]);
+    int np = 0;
+    for (int ia = 0; ia < nA; ++ia)
+        for (int ib = 0; ib < nB; ++ib) {
+            const float4 e = p.M.edge[(int)A[ia] * p.M.Nm + (int)B[ib]];
+            np += fabsf(d - e.x) <= e.z ? 1 : 0;
+        }
+    return 2 * np < nA * nB;
 }
 
 // One (ligand node, ligand node) item of match_utils.py:26-69 for the subset pair (sidu, sidv) at distance d: the tabulated
@@ -1293,8 +1309,8 @@ __device__ __forceinline__ void item(const ScreenParams &p, uint32_t sidu, uint3
         v = __builtin_fmaf(t, v, a.x);
         if (SELF) {
             if (__builtin_expect((__float_as_uint(b.y) & 1u) != 0u && sidu != 0u && sidv != 0u, 0)) {
-                int np;
-                v = exact_value(p, p.subnodes[sidu], p.subnodes[sidv], d, np);
+                int np, mn;
+                v = exact_value(p, sidu, sidv, d, np, mn);
                 ++n_exactv;
             }
             acc = acc + v;
@@ -1302,14 +1318,7 @@ __device__ __forceinline__ void item(const ScreenParams &p, uint32_t sidu, uint3
         }
         acc = acc + v;
         if (__builtin_expect(b.z != b.z, 0)) { // the pass set is not one interval inside this cell: count the terms
-            const uint64_t A = p.subnodes[sidu], B = p.subnodes[sidv];
-            int np = 0;
-            for (uint64_t am = A; am; am &= am - 1)
-                for (uint64_t bm = B; bm; bm &= bm - 1) {
-                    const float4 e = p.M.edge[(__ffsll((unsigned long long)am) - 1) * p.M.Nm + (__ffsll((unsigned long long)bm) - 1)];
-                    np += fabsf(d - e.x) <= e.z ? 1 : 0;
-                }
-            fails += 2 * np < __popcll(A) * __popcll(B) ? 1 : 0;
+            fails += majority_fails(p, sidu, sidv, d) ? 1 : 0;
             ++n_exact;
         } else {
             fails += (d >= b.z && d <= b.w) ? 0 : 1;
@@ -1317,11 +1326,10 @@ __device__ __forceinline__ void item(const ScreenParams &p, uint32_t sidu, uint3
         return;
     }
     // debug / validation (flags & 8): every item term by term
-    const uint64_t A = p.subnodes[sidu], B = p.subnodes[sidv];
-    if (!A || !B) return;
-    int np;
-    acc = acc + exact_value(p, A, B, d, np);
-    fails += 2 * np < __popcll(A) * __popcll(B) ? 1 : 0;
+    if (sidu == 0u || sidv == 0u) return; // (0 = the empty subset)
+    int np, mn;
+    acc = acc + exact_value(p, sidu, sidv, d, np, mn);
+    fails += 2 * np < mn ? 1 : 0;
 }
 
 // The same item in two steps, so that the loads of several items are in flight together: address + loads, then value + test.
@@ -1358,14 +1366,7 @@ __device__ __forceinline__ void item_finish(const ScreenParams &p, const ItemLoa
     v = __builtin_fmaf(t, v, L.a.x);
     acc = acc + v;
     if (__builtin_expect(L.b.z != L.b.z, 0)) { // the pass set is not one interval inside this cell: count the terms
-        const uint64_t A = p.subnodes[L.sids & 0xffffu], B = p.subnodes[L.sids >> 16];
-        int np = 0;
-        for (uint64_t am = A; am; am &= am - 1)
-            for (uint64_t bm = B; bm; bm &= bm - 1) {
-                const float4 e = p.M.edge[(__ffsll((unsigned long long)am) - 1) * p.M.Nm + (__ffsll((unsigned long long)bm) - 1)];
-                np += fabsf(L.d - e.x) <= e.z ? 1 : 0;
-            }
-        fails += 2 * np < __popcll(A) * __popcll(B) ? 1 : 0;
+        fails += majority_fails(p, L.sids & 0xffffu, L.sids >> 16, L.d) ? 1 : 0;
         ++n_exact;
     } else {
         fails += (L.d >= L.b.z && L.d <= L.b.w) ? 0 : 1;
@@ -1390,29 +1391,40 @@ __device__ __forceinline__ LevelInfo scan_ligand(const ScreenParams &p, unsigned
     uint8_t *tm = lds + kOffTm, *lstart = lds + kOffStart, *lend = lds + kOffEnd, *lk = lds + kOffK;
     uint16_t *ksum = reinterpret_cast<uint16_t *>(lds + kOffKsum), *ncoff = reinterpret_cast<uint16_t *>(lds + kOffNcoff);
     uint32_t *rowbase = reinterpret_cast<uint32_t *>(lds + kOffRow);
-    uint64_t *bits = reinterpret_cast<uint64_t *>(lds + kOffBits);
     uint32_t *scal = reinterpret_cast<uint32_t *>(lds + kOffBits + 8 * PMX_MAX_LEVELS); // ksumtot, T
     uint8_t *cand = lds + ws.off_cand, *lcnt = lds + ws.off_lcnt;
     uint16_t *nc = reinterpret_cast<uint16_t *>(lds + ws.off_nc);
     if (lane < r.n) tm[lane] = r.typemask[lane];
     wave_sync();
     int cs = 0, ce = 0;
-    uint64_t cb = 0;
+    uint64_t cb0 = 0, cb1 = 0; // candidate clusters of the ligand cluster (PMX_MAX_MODEL_CLUSTERS bits)
     if (lane < r.ncl) {
         cs = lane ? r.cluster_end[lane - 1] : 0;
         ce = r.cluster_end[lane];
         unsigned lm = 0;
         for (int u = cs; u < ce; ++u) lm |= tm[u];
-        cb = p.M.tclus[lm & 127u];
+        cb0 = p.M.tclus[2u * (lm & 127u)];
+        cb1 = p.M.tclus[2u * (lm & 127u) + 1u];
     }
-    const unsigned long long bal = __ballot(cb != 0);
+    const bool has = (cb0 | cb1) != 0ull;
+    const int kc = (int)__popcll(cb0) + (int)__popcll(cb1);
+    const unsigned long long bal = __ballot(has);
     const int lev = __popcll(bal & ((1ull << lane) - 1ull));
     const int nl = min((int)__popcll(bal), PMX_MAX_LEVELS);
-    if (cb && lev < PMX_MAX_LEVELS) {
+    // (a level's candidates are a 64-bit set in the walker: a ligand cluster with more - only a model of more than 64 clusters has
+    // that many of one type - makes the ligand unsupported)
+    if (__ballot(has && lev < PMX_MAX_LEVELS && kc > PMX_MAX_LEVEL_CANDIDATES) != 0ull) {
+        LevelInfo bad;
+        bad.nl = -1, bad.ksumtot = 0, bad.T = 0;
+        return bad;
+    }
+    if (has && lev < PMX_MAX_LEVELS) {
         lstart[lev] = (uint8_t)cs;
         lend[lev] = (uint8_t)ce;
-        lk[lev] = (uint8_t)__popcll(cb);
-        bits[lev] = cb;
+        lk[lev] = (uint8_t)kc;
+        int q = 0;
+        for (uint64_t x = cb0; x; x &= x - 1, ++q) cand[lev * ws.kp + q] = (uint8_t)(__ffsll((unsigned long long)x) - 1);
+        for (uint64_t x = cb1; x; x &= x - 1, ++q) cand[lev * ws.kp + q] = (uint8_t)(64 + __ffsll((unsigned long long)x) - 1);
     }
     wave_sync();
     if (lane == 0) {
@@ -1432,10 +1444,6 @@ __device__ __forceinline__ LevelInfo scan_ligand(const ScreenParams &p, unsigned
         }
         scal[0] = ks;
         scal[1] = rb;
-    }
-    if (lane < nl) {
-        uint64_t x = bits[lane];
-        for (int q = 0; x; x &= x - 1, ++q) cand[lane * ws.kp + q] = (uint8_t)(__ffsll((unsigned long long)x) - 1);
     }
     wave_sync();
     for (int l = 0; l < nl; ++l) {
@@ -1975,6 +1983,13 @@ __device__ __forceinline__ unsigned char *prepare_ligand(const ScreenParams &p, 
     }
     const unsigned long long t_a = __builtin_amdgcn_s_memtime();
     const LevelInfo L = scan_ligand<G>(p, lds, ws, r);
+    if (L.nl < 0) { // a ligand cluster with more than PMX_MAX_LEVEL_CANDIDATES candidate clusters
+        if (lane == 0) {
+            p.scores[li] = __builtin_nanf("");
+            if (p.status) p.status[li] = PMX_LIGAND_UNSUPPORTED;
+        }
+        return nullptr;
+    }
     if (L.nl == 0) { // no ligand cluster has a candidate (graph_match.py:95-99)
         if (lane == 0) p.scores[li] = 0.f;
         return nullptr;

@@ -50,7 +50,7 @@ class FlatModel:
     node_type: np.ndarray  # u8 [Nm]       type id of each model node
     edge_mean: np.ndarray  # f32 [Nm, Nm]  distance_mean of edge (m, n), symmetric, self-loops on the diagonal
     edge_std: np.ndarray  # f32 [Nm, Nm]   distance_std
-    cluster_nodes: np.ndarray  # u64 [K]   bit m set <=> node m in cluster
+    cluster_nodes: np.ndarray  # u64 [K] (models of up to 64 nodes) or [K, ceil(Nm / 64)]: bit m % 64 of word m // 64 set <=> node m in cluster
     cluster_typemask: np.ndarray  # u8 [K] bit t set <=> type t in the cluster's stored node_types
     cluster_center: np.ndarray  # f64 [K, 3]
     cluster_size: np.ndarray  # f64 [K]
@@ -63,6 +63,19 @@ class FlatModel:
     @property
     def num_clusters(self) -> int:
         return int(self.cluster_nodes.shape[0])
+
+
+def _node_masks(masks: list[int], nm: int) -> np.ndarray:
+    """Python-int node sets -> the words `pmx_model_desc.cluster_nodes` holds (one per cluster up to 64 nodes)."""
+    words = max(1, (nm + 63) // 64)
+    out = np.array([[(m >> (64 * w)) & 0xFFFFFFFFFFFFFFFF for w in range(words)] for m in masks], dtype=np.uint64).reshape(len(masks), words)
+    return out[:, 0].copy() if words == 1 else out
+
+
+def cluster_node_sets(flat: "FlatModel") -> list[int]:
+    """The node set of every cluster as a Python int (bit m <=> node m), whatever the word count."""
+    cn = np.asarray(flat.cluster_nodes, dtype=np.uint64).reshape(flat.num_clusters, -1)
+    return [sum(int(cn[k, w]) << (64 * w) for w in range(cn.shape[1])) for k in range(cn.shape[0])]
 
 
 def _flatten_state(state: dict[str, Any]) -> FlatModel:
@@ -129,7 +142,7 @@ def _flatten_state(state: dict[str, Any]) -> FlatModel:
         node_type=node_type,
         edge_mean=np.ascontiguousarray(edge_mean),
         edge_std=np.ascontiguousarray(edge_std),
-        cluster_nodes=np.array(cluster_nodes, dtype=np.uint64),
+        cluster_nodes=_node_masks(cluster_nodes, nm),
         cluster_typemask=np.array(cluster_typemask, dtype=np.uint8),
         cluster_center=np.array(centers, dtype=np.float64).reshape(-1, 3),
         cluster_size=np.array(sizes, dtype=np.float64),

@@ -23,6 +23,7 @@ GOLDEN_SETS = (
     "set_c21_c8",
     "set_s64_c8",
     "set_s64_c64",
+    "set_l110_c8",  # 110-node / 86-cluster model (tests/golden/make_golden_large.py)
 )
 
 

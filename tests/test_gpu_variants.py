@@ -95,7 +95,7 @@ def test_engine_settings_match_reference_golden(name, env, monkeypatch):
 
 
 def test_structural_limits_are_explicit():
-    """include/pmx.h: at most 64 model nodes / clusters and 64 ligand nodes / clusters / conformers. A model beyond
+    """include/pmx.h: at most 256 model nodes / 128 clusters and 64 ligand nodes / clusters / conformers. A model beyond
     them is refused with a message; a ligand beyond them is reported per ligand (status 1, score NaN) and ranks last."""
     from pharmaconet_amd import PharmacophoreModel
     from pharmaconet_amd.library import UNSUPPORTED_RECORD
@@ -103,10 +103,10 @@ def test_structural_limits_are_explicit():
     model, lib, _, _ = load_golden("set_6oim_c5")
     st = json.loads(json.dumps(model.__getstate__()))
     node = dict(st["nodes"][0])
-    for i in range(len(st["nodes"]), 65):
+    for i in range(len(st["nodes"]), 257):
         extra = dict(node, index=i)
         st["nodes"].append(extra)
-    with pytest.raises(ValueError, match="at most 64"):
+    with pytest.raises(ValueError, match="at most 256"):
         big = PharmacophoreModel.__new__(PharmacophoreModel)
         big.__setstate__(st)
         _ = big.flat
@@ -116,6 +116,51 @@ def test_structural_limits_are_explicit():
     scores = res.scores.cpu().numpy()
     assert status.tolist() == [0, 1, 0] and np.isnan(scores[1]) and np.isfinite(scores[[0, 2]]).all()
     assert [i for i, _ in res.ranking()][-1] == 1
+
+
+def test_models_beyond_64_nodes_and_clusters(oracle):
+    """Rounds 1-3 refused models of more than 64 nodes or clusters (64-bit node and candidate sets); the reference has no limit
+    (pharmacophore_model.py:191-204). Node subsets are lists on the device now and a ligand cluster's candidates two words: the
+    110-node / 86-cluster fixture model (minted by tests/golden/make_golden_large.py with the reference's own scores, also one of
+    GOLDEN_SETS) against a fresh library and the oracle, default and term-by-term table phase. What stays limited is the number
+    of candidates of ONE ligand cluster (64, a tree level's width): a model in which every cluster shares a type makes ligands
+    that meet it unsupported - reported per ligand, the others scored as the oracle scores them."""
+    import copy
+
+    from pharmaconet_amd import PharmacophoreModel
+    from pharmaconet_amd.constants import weights_vector
+    from pharmaconet_amd.synthetic import synthetic_library
+
+    model = PharmacophoreModel.load(GOLDEN / "model_large110.pm")
+    assert model.flat.num_nodes > 64 and model.flat.num_clusters > 64 and model.flat.cluster_nodes.shape[1] == 2
+    lib = synthetic_library(400, num_conformers=8, model_nodes=_model_nodes(model), active_fraction=0.4, seed=110110)
+    ref = oracle.oracle_score(model.flat, lib, weights_vector(None), num_threads=os.cpu_count() or 8)
+    got, status = _gpu(model, lib)
+    assert np.all(status == 0)
+    zero = ref == 0
+    assert np.all(got[zero] == 0.0) and np.count_nonzero(ref) > 200
+    assert rel_err(got[~zero], ref[~zero]).max() < RTOL
+    import os as _os
+    _os.environ["PMX_TREE_FLAGS"] = "8"
+    try:
+        exact, _ = _gpu(model, lib)
+    finally:
+        del _os.environ["PMX_TREE_FLAGS"]
+    assert rel_err(exact[~zero], ref[~zero]).max() < RTOL and np.all(exact[zero] == 0.0)
+
+    st = copy.deepcopy(model.__getstate__())
+    for clusters in st["node_cluster_dict"].values():
+        for cl in clusters:
+            cl["node_types"] = sorted(set(cl["node_types"]) | {"Hydrophobic"})
+    wide = PharmacophoreModel.__new__(PharmacophoreModel)
+    wide.__setstate__(st)
+    ref = oracle.oracle_score(wide.flat, lib, weights_vector(None), num_threads=os.cpu_count() or 8)
+    got, status = _gpu(wide, lib)
+    hyd = np.array([bool(np.any(lib.unpack(i)["typemask"] & 1)) for i in range(len(lib))])  # type id 0 = Hydrophobic
+    assert hyd.sum() > 100
+    assert np.all(status[hyd] == 1) and np.all(np.isnan(got[hyd]))
+    assert np.all(status[~hyd] == 0)
+    assert rel_err(got[~hyd], ref[~hyd])[ref[~hyd] != 0].max(initial=0.0) < RTOL and np.all(got[~hyd][ref[~hyd] == 0] == 0.0)
 
 
 def test_corrupt_library_is_neutralised_not_followed():
