@@ -18,3 +18,5 @@ rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_
 python $ROOT/bench.py --pockets 16 --ligands 200000 --steps 1 --warmup 1 --no-cpu-baseline --no-serial-leg > $OUT/bench_pockets16.json 2> $OUT/bench_pockets16.err
 python $ROOT/tools/stress_shape.py 196 > $OUT/stress64.log 2>&1
 ls -R $OUT | head -40
+python $ROOT/bench.py --ligands 12500000 --steps 2 --warmup 1 --no-cpu-baseline --no-serial-leg > $OUT/bench_shard12M.json 2> $OUT/bench_shard12M.err
+python $ROOT/bench.py --pockets 16 --ligands 1253376 --steps 1 --warmup 1 --no-cpu-baseline --no-serial-leg > $OUT/bench_pockets16_shard.json 2> $OUT/bench_pockets16_shard.err
