@@ -216,6 +216,25 @@ int pmx_sdf_heavy_atoms(const char *text, uint64_t len, uint64_t max_records, ui
 int pmx_mol2_heavy_atoms(const char *text, uint64_t len, uint64_t max_records, uint64_t cap_records, uint64_t cap_atoms,
                          uint64_t *n_records, uint64_t *n_atoms, int32_t *atoms_per_record, uint8_t *atomic_num, float *xyz);
 
+/*
+ * Voxel components of hotspot density maps on the device - the search of `DensityMapGraph.__extract_pharmacophores`
+ * (src/pmnet/utils/density_map.py:78-110) that `PharmacophoreModel.create` (pharmacophore_model.py:108-149) runs per hotspot in a
+ * Python loop over 26 neighbours per voxel. `maps`: n_maps arrays float32 [size][size][size] (C order, mask[x][y][z]); a voxel is
+ * in a component where its value is > 0; voxels are named by their linear index (x * size + y) * size + z.
+ *   pmx_density_create  uploads the maps and labels the 26-connected components (label = smallest linear index of the component);
+ *   pmx_density_labels  labels_out [n_maps * size^3], -1 outside the components;
+ *   pmx_density_order   for n_components components (map, seed voxel, offset into members_out; sizes from the labels): the voxels in
+ *                       the order the reference's breadth-first search from that seed discovers them (:93-109: the member list is the
+ *                       queue, neighbours in itertools.product((-1, 0, 1), repeat=3) order) - the order of its centroid sums. The seed
+ *                       of a search is `set.pop()` on a CPython set (:91-92): the caller's business (pharmaconet_amd/model_builder.py).
+ */
+typedef struct pmx_density pmx_density;
+int pmx_density_create(const float *maps, int32_t n_maps, int32_t size, int device, pmx_density **out);
+int pmx_density_labels(pmx_density *d, int32_t *labels_out);
+int pmx_density_order(pmx_density *d, int32_t n_components, const int32_t *comp_map, const int32_t *comp_seed,
+                      const int32_t *comp_offset, int32_t *members_out);
+int pmx_density_destroy(pmx_density *d);
+
 /* Frees the scoring workspaces libpmx keeps between calls on `device` (synchronises the device first). */
 int pmx_release_workspaces(int device);
 

@@ -116,6 +116,10 @@ SIGNATURES = {
         [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p],
     ),
     "pmx_release_workspaces": (ctypes.c_int, [ctypes.c_int]),
+    "pmx_density_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
+    "pmx_density_labels": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "pmx_density_order": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "pmx_density_destroy": (ctypes.c_int, [ctypes.c_void_p]),
     "pmx_pack_features": (
         ctypes.c_int,
         [ctypes.POINTER(FeatureBatch), ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64), ctypes.c_void_p],

@@ -16,7 +16,7 @@ REPO = PKG.parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libpmx.so"
 PACK_LIB = PKG / "libpmx_pack.so"  # the packer alone, host-only (no HIP / RCCL runtime)
-SOURCES = ("pmx_api.hip", "pmx_topk.hip", "pmx_pack.cpp", "pmx_sdf.cpp")
+SOURCES = ("pmx_api.hip", "pmx_topk.hip", "pmx_density.hip", "pmx_pack.cpp", "pmx_sdf.cpp")
 DEPS = ("pmx_screen.hip", "pmx_device.h")
 FLAGS = (
     "--offload-arch=gfx950",

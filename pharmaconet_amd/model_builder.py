@@ -95,6 +95,68 @@ def voxel_components(mask: np.ndarray) -> Iterable[tuple[list[tuple[int, int, in
         yield members, values
 
 
+def voxel_components_device(masks: Sequence[np.ndarray], device: int = 0) -> list[list[tuple[np.ndarray, np.ndarray]]]:
+    """`voxel_components` for all hotspot maps of a pocket at once, the searches on the GPU (`csrc/pmx_density.hip`): per map
+    the list of (members int64 [n, 3], values float64 [n]) in the reference's order. What stays here is what only CPython can
+    say - which voxel `set.pop()` returns next (`density_map.py:91-92`): the set is built as the reference builds it, a popped
+    seed's whole component (known from the device's labels) is discarded from it voxel by voxel - discarding marks the same table
+    slots whatever the order, so every later `pop()` returns what the reference's returns - and the device then lists every component
+    from its seed in breadth-first discovery order (`:93-109`)."""
+    import ctypes
+    from collections import deque
+
+    from . import _ffi
+
+    lib = _ffi.load()
+    size = int(masks[0].shape[0])
+    stack = np.ascontiguousarray(np.stack([np.asarray(m, dtype=np.float32) for m in masks]))
+    assert stack.shape[1:] == (size, size, size)
+    handle = ctypes.c_void_p()
+    _ffi.check(lib.pmx_density_create(stack.ctypes.data, len(masks), size, int(device), ctypes.byref(handle)))
+    try:
+        labels = np.empty(stack.size, dtype=np.int32)
+        _ffi.check(lib.pmx_density_labels(handle, labels.ctypes.data))
+        labels = labels.reshape(len(masks), -1)
+        comp_map: list[int] = []
+        comp_seed: list[int] = []
+        comp_size: list[int] = []
+        for mi, mask in enumerate(masks):
+            xs, ys, zs = np.where(mask > 0.0)
+            left = {(int(x), int(y), int(z)) for x, y, z in zip(xs, ys, zs)}  # as density_map.py:91-92 builds it
+            lin = (xs.astype(np.int64) * size + ys) * size + zs
+            lab = labels[mi][lin]
+            order = np.argsort(lab, kind="stable")
+            bounds = np.flatnonzero(np.diff(lab[order], prepend=-2))
+            groups = {int(lab[order[b]]): order[b:e] for b, e in zip(bounds, list(bounds[1:]) + [len(order)])}
+            while left:
+                seed = left.pop()
+                sl = (seed[0] * size + seed[1]) * size + seed[2]
+                idx = groups[int(labels[mi][sl])]
+                # (one discard per voxel, as the reference's `remove` calls: `difference_update` rebuilds the table once a
+                # quarter of it is dummies, which would change what pop() returns next)
+                deque(map(left.discard, zip(xs[idx].tolist(), ys[idx].tolist(), zs[idx].tolist())), maxlen=0)
+                comp_map.append(mi)
+                comp_seed.append(sl)
+                comp_size.append(len(idx))
+        n = len(comp_map)
+        offsets = np.zeros(n + 1, dtype=np.int32)
+        np.cumsum(comp_size, out=offsets[1:])
+        members = np.empty(int(offsets[-1]), dtype=np.int32)
+        cm, cs = np.asarray(comp_map, dtype=np.int32), np.asarray(comp_seed, dtype=np.int32)
+        _ffi.check(lib.pmx_density_order(handle, n, cm.ctypes.data, cs.ctypes.data, offsets.ctypes.data, members.ctypes.data))
+    finally:
+        lib.pmx_density_destroy(handle)
+    if members.size and members.min() < 0:
+        raise RuntimeError("pmx_density_order left a component incomplete")
+    out: list[list[tuple[np.ndarray, np.ndarray]]] = [[] for _ in masks]
+    for c in range(n):
+        lin = members[offsets[c]:offsets[c + 1]].astype(np.int64)
+        coords = np.stack([lin // (size * size), (lin // size) % size, lin % size], axis=1)
+        vals = np.asarray(masks[comp_map[c]], dtype=np.float32).reshape(-1)[lin].astype(np.float64)
+        out[comp_map[c]].append((coords, vals))
+    return out
+
+
 def _grid_to_world(coords, center, resolution: float, size: int) -> tuple[float, float, float]:
     """density_map.py:16-25: voxel coordinates -> Angstrom, the box being centred on `center`."""
     half = resolution * (size - 1) / 2
@@ -107,9 +169,11 @@ def build_model_state(
     hotspot_infos: Sequence[dict],
     resolution: float = 0.5,
     size: int = 64,
+    device: int | None = None,
 ) -> dict[str, Any]:
     """State dict (`.pm` / `.json` schema) of the model that `PharmacophoreModel.create` builds from
-    `hotspot_infos` = [{nci_type, hotspot_position, hotspot_score, point_map}] (`pharmacophore_model.py:108-131`)."""
+    `hotspot_infos` = [{nci_type, hotspot_position, hotspot_score, point_map}] (`pharmacophore_model.py:108-131`).
+    `device`: GPU ordinal - the voxel searches of all hotspots run there (`voxel_components_device`); None: on the host."""
     assert len(center) == 3
     if not isinstance(center, tuple):
         center = tuple(np.asarray(center).tolist())
@@ -121,11 +185,12 @@ def build_model_state(
     nodes: list[dict[str, Any]] = []
     edges: list[dict[str, Any]] = []
     mean_of: dict[tuple[int, int], float] = {}
-    for info in hotspot_infos:
+    searched = voxel_components_device([info["point_map"] for info in hotspot_infos], device) if device is not None and len(hotspot_infos) else None
+    for h, info in enumerate(hotspot_infos):
         kind = info["nci_type"]
         hx, hy, hz = tuple(np.asarray(info["hotspot_position"]).tolist())
         score = float(info["hotspot_score"])
-        for members, values in voxel_components(info["point_map"]):
+        for members, values in (searched[h] if searched is not None else voxel_components(info["point_map"])):
             if len(members) < MIN_COMPONENT_VOXELS:
                 continue
             grids = np.array(members)

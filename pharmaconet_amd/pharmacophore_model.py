@@ -197,14 +197,25 @@ class PharmacophoreModel:
         self._object_graph = None
 
     @classmethod
-    def create(cls, pdbblock, center, hotspot_infos, resolution: float = 0.5, size: int = 64):
+    def create(cls, pdbblock, center, hotspot_infos, resolution: float = 0.5, size: int = 64, device="auto"):
         """Hotspot density maps -> model (`pharmacophore_model.py:108-149`): same arguments as the reference;
         `hotspot_infos` = [{nci_type, hotspot_position, hotspot_score, point_map}]. The graph build of
-        `utils/density_map.py` is restated in `pharmaconet_amd.model_builder` (host side, once per pocket)."""
+        `utils/density_map.py` is restated in `pharmaconet_amd.model_builder`: the voxel searches of all hotspots run on the GPU
+        (`device`: ordinal, "auto" = the current GPU if one is visible, None = the host loop), the rest - a few dozen nodes - on
+        the host; the state is the reference's either way."""
         from .model_builder import build_model_state
 
+        if device == "auto":
+            device = None
+            try:
+                import torch
+
+                if torch.cuda.is_available():
+                    device = torch.cuda.current_device()
+            except Exception:
+                device = None
         model = cls()
-        model.__setstate__(build_model_state(pdbblock, center, hotspot_infos, resolution, size))
+        model.__setstate__(build_model_state(pdbblock, center, hotspot_infos, resolution, size, device=device))
         return model
 
     # ------------------------------------------------------------ accessors

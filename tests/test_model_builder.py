@@ -27,11 +27,10 @@ def load_inputs(name):
     return z["center"], infos
 
 
-@pytest.mark.parametrize("name", CASES)
-def test_state_equals_reference(name):
+def _assert_state_equals_reference(name, device):
     center, infos = load_inputs(name)
     want = PharmacophoreModel.load(GOLDEN / f"create_{name}.pm").__getstate__()
-    got = build_model_state(want["pdbblock"], center, infos)
+    got = build_model_state(want["pdbblock"], center, infos, device=device)
     assert got["pdbblock"] == want["pdbblock"]
     # nodes: numbering (component order), float32 centres, radii, edge maps and overlap lists - exact
     assert len(got["nodes"]) == len(want["nodes"])
@@ -49,6 +48,57 @@ def test_state_equals_reference(name):
         for g, w in zip(gl, wl):
             assert set(g.pop("node_types")) == set(w.pop("node_types"))
             assert g == w, (kind, g, w)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_state_equals_reference(name):
+    _assert_state_equals_reference(name, None)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_state_equals_reference_with_the_searches_on_the_gpu(name):
+    """the voxel searches of `DensityMapGraph` on the device (`csrc/pmx_density.hip`: component labels +
+    breadth-first member order per component), the seeds from CPython's own `set.pop()`: the same state as the reference's."""
+    _assert_state_equals_reference(name, 0)
+
+
+@pytest.mark.gpu
+def test_device_member_lists_equal_the_host_search():
+    """Every component of every map, voxel for voxel in discovery order, device against the host search (`voxel_components`, itself
+    held to the reference by test_state_equals_reference): random blobs that touch through faces, edges and corners, specks, a
+    solid 20^3 cube (8 000 voxels: wide frontiers), a thin diagonal line, voxels on the grid's faces, an empty map."""
+    from pharmaconet_amd.model_builder import voxel_components_device
+
+    rng = np.random.default_rng(20250523)
+    masks = []
+    for k in range(6):
+        m = np.zeros((64, 64, 64), dtype=np.float32)
+        for _ in range(12 + 6 * k):
+            c = rng.integers(2, 62, size=3)
+            r = rng.uniform(1.0, 5.5)
+            g = np.stack(np.meshgrid(*[np.arange(64)] * 3, indexing="ij"), -1)
+            inside = ((g - c) ** 2).sum(-1) <= r * r
+            m[inside] = rng.uniform(0.05, 1.0, size=int(inside.sum())).astype(np.float32)
+        m[rng.random(m.shape) < 0.0005] = 0.3  # specks
+        masks.append(m)
+    cube = np.zeros((64, 64, 64), dtype=np.float32)
+    cube[5:25, 30:50, 40:60] = rng.uniform(0.1, 1.0, size=(20, 20, 20)).astype(np.float32)
+    for i in range(40):
+        cube[20 + i, 5 + i // 2, 63 - i] = 0.5  # a line that moves through corners, ending on a face
+    cube[0, 0, 0] = cube[63, 63, 63] = cube[0, 63, 0] = 0.2
+    masks.append(cube)
+    masks.append(np.zeros((64, 64, 64), dtype=np.float32))
+    got = voxel_components_device(masks, 0)
+    n_comp = 0
+    for m, comps in zip(masks, got):
+        want = list(voxel_components(m))
+        assert len(comps) == len(want)
+        for (gm, gv), (wm, wv) in zip(comps, want):
+            assert gm.tolist() == [list(p) for p in wm]
+            assert gv.tolist() == wv
+        n_comp += len(want)
+    assert n_comp > 100 and max(len(w[0]) for w in voxel_components(cube)) >= 8000
 
 
 def test_create_gives_a_scorable_model():
