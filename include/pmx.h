@@ -116,7 +116,7 @@ int pmx_library_destroy(pmx_library *lib);
  * ligands with larger tables, a fixed number of task rounds for the subtrees of over-budget trees, finalize. With
  * PMX_OVERLAP set and more than one chunk, the rounds of a chunk run on a side stream that the workspace owns, beside the
  * next chunk's ligand kernel: they start behind an event recorded on `stream` and `stream` waits for their last event before
- * the call's work counts as done, so a caller sees one stream-ordered operation either way. Work buffers are kept per (device, stream), about 41 GB at the defaults
+ * the call's work counts as done, so a caller sees one stream-ordered operation either way. Work buffers are kept per (device, stream), about 41 GB at the defaults, for at most PMX_MAX_WORKSPACES (default 4) streams per device - the least recently used idle workspace is freed when one more stream appears -
  * (PMX_ARENA_MB, PMX_TASKQ_MB: per buffer set, two sets); the table arenas shrink when device memory is short - a smaller
  * arena is slower, never wrong. PMX_LIGAND_TOO_LARGE is reported for a ligand whose tables exceed a whole arena; a ligand
  * that merely found the arena full of other ligands' tables is taken again with the arena empty.

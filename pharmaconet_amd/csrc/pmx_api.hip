@@ -611,18 +611,60 @@ struct ScreenWs {
         ev_valid = false;
         ctl_used[0] = ctl_used[1] = false;
     }
-    bool released = false; // pmx_release_workspaces took the buffers: a caller that was waiting on `mu` asks for a new workspace
+    uint64_t stamp = 0;    // last use (ensure_screen): the least recently used workspace of a device goes first
+    bool released = false; // pmx_release_workspaces (or the cap on workspaces per device) took the buffers: a caller that was waiting on `mu` asks for a new workspace
 };
 // Workspaces are shared: the map, a call in progress and the thread that asks for the last call's statistics each hold a
 // reference, so pmx_release_workspaces can take a workspace out of the map and free its buffers while none of them is left
 // with a dangling pointer (the object itself goes with its last reference).
 static std::map<std::pair<int, hipStream_t>, std::shared_ptr<ScreenWs>> g_screen; // (device, stream)
 
+static uint64_t g_screen_stamp = 0;
+
+// The workspace of (device, stream), made on first use. At most PMX_MAX_WORKSPACES (default 4) are kept per device: a host
+// program that scores on short-lived streams would otherwise leave some 40 GB behind per stream it ever used (the key is the raw
+// stream handle; nothing tells libpmx that a stream is gone). When one more is needed the least recently used idle one is
+// taken out of the map and freed - after a device synchronisation, its stream may no longer exist - and a caller that was
+// waiting for it finds it `released` and asks again.
 static std::shared_ptr<ScreenWs> ensure_screen(int device, hipStream_t stream) {
-    std::lock_guard<std::mutex> lock(g_mu);
-    auto &slot = g_screen[std::make_pair(device, stream)];
-    if (!slot) slot = std::make_shared<ScreenWs>();
-    return slot;
+    std::shared_ptr<ScreenWs> out, victim;
+    {
+        std::lock_guard<std::mutex> lock(g_mu);
+        const auto key = std::make_pair(device, stream);
+        auto it = g_screen.find(key);
+        if (it != g_screen.end() && it->second) {
+            it->second->stamp = ++g_screen_stamp;
+            return it->second;
+        }
+        const long cap = std::max<long>(1, env_long("PMX_MAX_WORKSPACES", 4));
+        long have = 0;
+        for (const auto &kv : g_screen) have += kv.first.first == device && kv.second ? 1 : 0;
+        if (have >= cap) {
+            auto lru = g_screen.end();
+            for (auto jt = g_screen.begin(); jt != g_screen.end(); ++jt) {
+                if (jt->first.first != device || !jt->second) continue;
+                if (lru != g_screen.end() && jt->second->stamp >= lru->second->stamp) continue;
+                if (!jt->second->mu.try_lock()) continue; // a call is enqueuing on it
+                if (lru != g_screen.end()) lru->second->mu.unlock();
+                lru = jt;
+            }
+            if (lru != g_screen.end()) {
+                victim = std::move(lru->second); // (its mutex is held)
+                g_screen.erase(lru);
+            }
+        }
+        out = std::make_shared<ScreenWs>();
+        out->stamp = ++g_screen_stamp;
+        g_screen[key] = out;
+    }
+    if (victim) {
+        (void)hipSetDevice(device);
+        (void)hipDeviceSynchronize();
+        victim->free_buffers();
+        victim->released = true;
+        victim->mu.unlock();
+    }
+    return out;
 }
 
 // (a buffer only ever grows; queued work may still use the old one, on the caller's stream or on the side stream)

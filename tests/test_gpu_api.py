@@ -292,6 +292,32 @@ def test_concurrent_callers_are_serialised_not_corrupted():
     np.testing.assert_array_equal(got[1], alone[1])
 
 
+def test_workspaces_of_abandoned_streams_are_recycled(monkeypatch):
+    """Work buffers are cached per (device, stream), some 40 GB each at the defaults, and nothing tells libpmx that a stream is
+    gone: at most PMX_MAX_WORKSPACES are kept per device, the least recently used idle one is freed when one more is needed
+    (ADVICE r3). Six short-lived streams, a cap of two: the same scores every time, and the device does not fill up."""
+    import torch
+
+    from pharmaconet_amd import engine
+
+    model, lib, _, expected = load_golden("set_6oim_c8")
+    engine.release_workspaces()
+    monkeypatch.setenv("PMX_MAX_WORKSPACES", "2")
+    monkeypatch.setenv("PMX_ARENA_MB", "2048")
+    want = model.screen(lib).scores.cpu().numpy()
+    free = []
+    for k in range(6):
+        stream = torch.cuda.Stream()
+        with torch.cuda.stream(stream):
+            got = model.screen(lib).scores.cpu().numpy()
+        np.testing.assert_array_equal(got, want)
+        del stream
+        torch.cuda.synchronize()
+        free.append(torch.cuda.mem_get_info()[0])
+    assert min(free[2:]) > free[1] - (3 << 30), free  # (two workspaces of 2 x 2 GB arenas + slices stay; four more would be 25 GB)
+    engine.release_workspaces()
+
+
 def test_full_task_queue_changes_nothing_but_time(monkeypatch):
     """The queue of exported subtrees is 64 shards of fixed size. When a wave finds its shard full it keeps the subtree
     and walks it itself (and the call reports `queue_overflow`): same bits."""
