@@ -1550,6 +1550,22 @@ __device__ __forceinline__ void build_tables(const ScreenParams &p, unsigned cha
         if (kStageLds) lds_sync();
         else wave_sync();
     };
+    // Centre and size of every level's ligand cluster (ligand.py:458-473), once, with a slot per level: the pair loop below needs
+    // them for every pair of levels and used to work them out again per pair (nl (nl - 1) / 2 + nl times instead of nl: 6 % of
+    // the bench pass). They wait in the record's R / W regions, which build_bounds() fills only after this phase.
+    constexpr bool kCentersStaged = cand_bounds<G>(); // (the W region exists; single-node clusters - the 32 / 64-lane stress model - gain nothing)
+    float2 *cxy = reinterpret_cast<float2 *>(rec + rec_r_off<G>(L.ksumtot, L.T));
+    float2 *czs = reinterpret_cast<float2 *>(rec + rec_w_off<G>(L.ksumtot, L.T, (uint32_t)L.nl));
+    if (kCentersStaged) {
+        for (int l = s; l < nl; l += SLOTS) {
+            Pos3 ctr;
+            float size;
+            center_size(xyz, C, (int)lstart[l], (int)lend[l], cc, ctr, size);
+            cxy[l * G + c] = make_float2(ctr.x, ctr.y);
+            czs[l * G + c] = make_float2(ctr.z, size);
+        }
+        wave_sync();
+    }
     for (int i = 0; i < nl; ++i) {
         const int si = uni(lstart[i]), ni = uni(lend[i]) - si, ki = uni(lk[i]), nci = uni(ncoff[i]), ksi = uni(ksum[i]);
         const uint32_t row_i = (uint32_t)uni((int)rowbase_l[i]), nd_i = L.ksumtot - (uint32_t)uni(ksum[i + 1]);
@@ -1575,12 +1591,24 @@ __device__ __forceinline__ void build_tables(const ScreenParams &p, unsigned cha
         PMX_TICK(0);
         Pos3 ctr_i;
         float size_i;
-        center_size(xyz, C, si, si + ni, cc, ctr_i, size_i);
+        if (kCentersStaged) {
+            const float2 a = cxy[i * G + c], b = czs[i * G + c];
+            ctr_i = Pos3{a.x, a.y, b.x};
+            size_i = b.y;
+        } else {
+            center_size(xyz, C, si, si + ni, cc, ctr_i, size_i);
+        }
         for (int j = i + 1; j < nl; ++j) {
             const int sj = uni(lstart[j]), nj = uni(lend[j]) - sj, kj = uni(lk[j]), ncj = uni(ncoff[j]);
             Pos3 ctr_j;
             float size_j;
-            center_size(xyz, C, sj, sj + nj, cc, ctr_j, size_j);
+            if (kCentersStaged) {
+                const float2 a = cxy[j * G + c], b = czs[j * G + c];
+                ctr_j = Pos3{a.x, a.y, b.x};
+                size_j = b.y;
+            } else {
+                center_size(xyz, C, sj, sj + nj, cc, ctr_j, size_j);
+            }
             const float ldist = norm3f(ctr_i.x - ctr_j.x, ctr_i.y - ctr_j.y, ctr_i.z - ctr_j.z); // graph_match.py:240
             const float lsize = size_i + size_j;                                                  // :241
             const int E = ki * kj;
