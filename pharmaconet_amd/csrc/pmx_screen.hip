@@ -264,6 +264,27 @@ __device__ inline float wave_max_f32(float v) {
     const float r2 = __int_as_float(__builtin_amdgcn_readlane(x, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(x, 48));
     return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
+// Largest value over the lanes that stand for the same conformer (lane % G) in all 64 / G slots, in every lane: rotations
+// inside the rows of 16 lanes (DPP), then the rows by the lane swaps of gfx950 (v_permlane16_swap / v_permlane32_swap) -
+// no trip through the LDS crossbar (ds_bpermute, what __shfl_xor compiles to).
+template <int G>
+__device__ __forceinline__ float slot_max_f32(float v) {
+    if (G <= 1) { const int x = __float_as_int(v); v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x121, 0xf, 0xf, false))); } // row_ror:1
+    if (G <= 2) { const int x = __float_as_int(v); v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x122, 0xf, 0xf, false))); } // row_ror:2
+    if (G <= 4) { const int x = __float_as_int(v); v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x124, 0xf, 0xf, false))); } // row_ror:4
+    if (G <= 8) { const int x = __float_as_int(v); v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x128, 0xf, 0xf, false))); } // row_ror:8
+    if (G <= 16) {
+        const unsigned x = __float_as_uint(v);
+        const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false); // {rows 0 0 2 2, rows 1 1 3 3}
+        v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    }
+    if (G <= 32) {
+        const unsigned x = __float_as_uint(v);
+        const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false); // {lower half twice, upper half twice}
+        v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    }
+    return v;
+}
 __device__ inline void wave_sync() { // LDS / global hand-over between the lanes of one wavefront
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -1956,11 +1977,7 @@ __device__ __forceinline__ void build_bounds(const ScreenParams &p, unsigned cha
                         mf = pv > mf ? pv : mf;
                         pb = a0 == b0 ? pv : pb;
                     }
-#pragma unroll
-                    for (int d = G; d < 64; d <<= 1) {
-                        const float o = __shfl_xor(mf, d);
-                        mf = o > mf ? o : mf;
-                    }
+                    mf = slot_max_f32<G>(mf); // (entries are finite or NaN-free here: -1 or a sum of positive terms; 0 where no candidate)
                     const double val = (base - (double)mf) + (double)pb;
                     u = (pb > 0.f && val > u) ? val : u;
                 }
