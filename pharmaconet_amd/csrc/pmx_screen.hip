@@ -1955,35 +1955,42 @@ __device__ __forceinline__ void build_bounds(const ScreenParams &p, unsigned cha
         }
         return;
     }
+    // Two windows of level f's candidates at a time (slot s <-> candidates b0 + s and b0 + SLOTS + s): what a deeper candidate's base
+    // counted for level f - the maximum over ALL of f's candidates, a load per window and a cross-slot maximum - is the same for
+    // every window, and was worked out again for each (levels of 9-16 candidates, the fixture pockets': half of this loop).
     for (int f = 0; f < nl; ++f) {
         const int kf = uni(lk[f]), ksf = uni(ksum[f]);
-        for (int b0 = 0; b0 < kf; b0 += SLOTS) { // slot s <-> candidate b0 + s of level f
-            const int b = b0 + s;
-            const bool on = b < kf;
-            double acc = 0.0;
+        for (int b0 = 0; b0 < kf; b0 += 2 * SLOTS) {
+            const int bA = b0 + s, bB = b0 + SLOTS + s;
+            double accA = 0.0, accB = 0.0;
             for (int l = f + 1; l < nl; ++l) {
                 const int kl = uni(lk[l]), ksl = uni(ksum[l]);
                 const uint32_t nd_f = L.ksumtot - (uint32_t)uni((int)ksum[f + 1]);
                 const uint32_t e_fl = (uint32_t)uni((int)rowbase[f]) + (uint32_t)(ksl - uni((int)ksum[f + 1])); // entry((f, 0) -> (l, 0))
-                double u = 0.0;
+                double uA = 0.0, uB = 0.0;
                 for (int b1 = 0; b1 < kl; ++b1) {
                     const double base = Wt[(size_t)(ksl + b1) * G + c];
-                    // level f's entries against (l, b1): every slot reads its own candidate's, the largest of all is what
+                    // level f's entries against (l, b1): every slot reads its own candidates', the largest of all is what
                     // base(l, b1) counted for level f
-                    float mf = 0.f, pb = 0.f;
+                    float mf = 0.f, pA = 0.f, pB = 0.f;
                     for (int a0 = 0; a0 < kf; a0 += SLOTS) {
                         const int a = a0 + s;
                         const float pv = a < kf ? Pt[(size_t)(e_fl + (uint32_t)a * nd_f + (uint32_t)b1) * G + c] : 0.f;
                         mf = pv > mf ? pv : mf;
-                        pb = a0 == b0 ? pv : pb;
+                        pA = a0 == b0 ? pv : pA;
+                        pB = a0 == b0 + SLOTS ? pv : pB;
                     }
-                    mf = slot_max_f32<G>(mf); // (entries are finite or NaN-free here: -1 or a sum of positive terms; 0 where no candidate)
-                    const double val = (base - (double)mf) + (double)pb;
-                    u = (pb > 0.f && val > u) ? val : u;
+                    mf = slot_max_f32<G>(mf); // (a NaN entry is passed over here as by the comparisons above)
+                    const double rest = base - (double)mf;
+                    const double valA = rest + (double)pA, valB = rest + (double)pB;
+                    uA = (pA > 0.f && valA > uA) ? valA : uA;
+                    uB = (pB > 0.f && valB > uB) ? valB : uB;
                 }
-                acc += u;
+                accA += uA;
+                accB += uB;
             }
-            if (on) Wt[(size_t)(ksf + b) * G + c] = acc * (1.0 + 1e-12);
+            if (bA < kf) Wt[(size_t)(ksf + bA) * G + c] = accA * (1.0 + 1e-12);
+            if (bB < kf) Wt[(size_t)(ksf + bB) * G + c] = accB * (1.0 + 1e-12);
         }
         wave_sync();
     }
