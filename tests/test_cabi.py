@@ -55,6 +55,31 @@ def test_invalid_arguments_return_status_not_crash(libpmx):
     assert b"null" in libpmx.pmx_last_error()
     with pytest.raises(_ffi.PmxError):
         _ffi.check(libpmx.pmx_library_upload(None, 0, None))
+    assert libpmx.pmx_density_create(None, 0, 0, 0, None) == 1 and b"pmx_density_create" in libpmx.pmx_last_error()
+    assert libpmx.pmx_density_labels(None, None) == 1
+    assert libpmx.pmx_density_order(None, 1, None, None, None, None) == 1
+    assert libpmx.pmx_density_destroy(None) == 0
+
+
+def test_model_build_without_gpu_uses_the_host_search():
+    """`PharmacophoreModel.create(device="auto")` with no GPU visible: the host search, same state (tests/test_model_builder.py holds it to
+    the reference's); asking for a device that is not there fails loudly."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import numpy as np
+
+    from pharmaconet_amd import PharmacophoreModel, _ffi
+    from pharmaconet_amd.model_builder import build_model_state
+
+    m = np.zeros((64, 64, 64), dtype=np.float32)
+    m[10:14, 10:14, 10:14] = 0.5
+    info = [dict(nci_type="Hydrophobic", hotspot_position=np.zeros(3, np.float32), hotspot_score=1.0, point_map=m)]
+    model = PharmacophoreModel.create(None, (0.0, 0.0, 0.0), info)
+    assert model.num_nodes == 1
+    with pytest.raises(_ffi.PmxError):
+        build_model_state(None, (0.0, 0.0, 0.0), info, device=0)
 
 
 def test_scoring_without_gpu_fails_loudly():
