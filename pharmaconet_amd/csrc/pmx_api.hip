@@ -804,7 +804,10 @@ static int score_screen(const pmx_model *const *models, int n_models, const pmx_
     for (ChunkSet &c : ws.set) {
         // (PMX_ARENA_MB / PMX_TASKQ_MB are per set; a smaller arena than asked for is slower - more trees walked by one
         // wavefront alone - never wrong, so it shrinks when memory is short: several streams each keep a workspace)
-        rc = grow(&c.arena, &c.arena_bytes, (size_t)std::max<long>(1, env_long("PMX_ARENA_MB", 16384)) << 20, stream, ws.side, std::min<size_t>((size_t)1 << 30, (size_t)std::max<long>(1, env_long("PMX_ARENA_MB", 16384)) << 20));
+        // (32 / 64 conformer lanes: records of megabytes - 16 GB held the split trees of a 16 384-ligand chunk of the stress configuration
+        // to within 3 %, and every tree past the end is walked by one wavefront alone)
+        const size_t arena_want = (size_t)std::max<long>(1, env_long("PMX_ARENA_MB", G >= 32 ? 32768 : 16384)) << 20;
+        rc = grow(&c.arena, &c.arena_bytes, arena_want, stream, ws.side, std::min<size_t>((size_t)1 << 30, arena_want));
         if (rc) return rc;
         rc = grow(&c.queue, &c.queue_bytes, (size_t)std::max<long>(1, env_long("PMX_TASKQ_MB", 1024L * std::max(1, G / 8))) << 20, stream, ws.side);
         if (rc) return rc;

@@ -66,7 +66,8 @@ struct FnTable {
 
 // Header of one ligand's tables, in a wave's slice or in the arena:
 //   [RecHeader][best u64[G]][S float[ksumtot][G]][P float[T][G]][R double[nl + 1][G]][W double[ksumtot][G]][V mask[T]]
-//   [OB float[nl][ksumtot][G]][LV u8[ksumtot]][DP u8[ksumtot]]                    (where per-candidate bounds exist)
+//   [OB float[nl][ksumtot][G]][LV u8[ksumtot]][DP u8[ksumtot]]                    (where per-candidate bounds exist; at 32 / 64
+//   lanes OB is the one row BF float[ksumtot][G], see ob_rows())
 // OB[f][x] for a candidate x = (l, b') of a level l > f: S[l][b'] + sum_{f < j < l} max(0, max_a P[(j, a), (l, b')]), rounded up - what
 // (l, b') can add to a leaf total apart from its pair entries with the matches on the path down to level f (path_bound()).
 // LV[x] = the level of candidate x.
@@ -124,15 +125,21 @@ template <int G>
 __host__ __device__ inline uint32_t rec_ob_off(uint32_t ksumtot, uint32_t T, uint32_t nl) {
     return rec_v_off<G>(ksumtot, T, nl) + (uint32_t)round16((uint64_t)T * vmask_bytes<G>());
 }
+// rows of the OB table: one per level where per-candidate bounds exist; ONE otherwise (32 / 64 conformer lanes) - BF[x] = base(x)
+// rounded up, what candidate x can add to a leaf total at most whatever is matched above it (path_bound_wide())
+template <int G>
+__host__ __device__ constexpr uint32_t ob_rows(uint32_t nl) {
+    return cand_bounds<G>() ? nl : 1u;
+}
 template <int G>
 __host__ __device__ inline uint32_t rec_ci_off(uint32_t ksumtot, uint32_t T, uint32_t nl) {
-    return rec_ob_off<G>(ksumtot, T, nl) + (cand_bounds<G>() ? nl * ksumtot * G * 4u : 0u);
+    return rec_ob_off<G>(ksumtot, T, nl) + ob_rows<G>(nl) * ksumtot * G * 4u;
 }
 template <int G>
 __host__ __device__ inline uint64_t rec_bytes(uint32_t ksumtot, uint32_t T, uint32_t nl) {
     return (uint64_t)rec_s_off<G>() + round16((uint64_t)ksumtot * G * 4) + round16((uint64_t)T * G * 4) + (uint64_t)(nl + 1) * G * 8 +
            (cand_bounds<G>() ? (uint64_t)ksumtot * G * 8 : 0ull) + round16((uint64_t)T * vmask_bytes<G>()) +
-           (cand_bounds<G>() ? (uint64_t)nl * ksumtot * G * 4 + 2 * round16((uint64_t)ksumtot) : 0ull);
+           (uint64_t)ob_rows<G>(nl) * ksumtot * G * 4 + 2 * round16((uint64_t)ksumtot);
 }
 // (DP u8[ksumtot] follows LV: rec_ci_off + round16(ksumtot))
 template <int G>
@@ -215,7 +222,7 @@ struct ScreenParams {
     uint32_t qcap;             // records per shard
     uint32_t budget;           // passes after which a walker starts handing subtrees to the queue
     uint32_t min_levels;       // only subtrees with at least this many levels below their root are queued
-    uint32_t flags;            // 2: never queue, 4: no bound test, 8: exact Gaussian terms instead of the tabulated functions, 32768: no chain lengths (probe()), 65536: no dead-entry test (build_tables)
+    uint32_t flags;            // 2: never queue, 4: no bound test, 8: exact Gaussian terms instead of the tabulated functions, 32768: no chain lengths (probe()), 65536: no dead-entry test (build_tables), 131072: no path-aware test at 32 / 64 lanes (path_bound_wide())
     uint32_t max_nodes;        // of the library (sizes the LDS node tables)
     uint32_t last_round;       // task_kernel: never queue (walk every subtree to its end)
     uint32_t bound_cost; // per-candidate bounds are built when their cost estimate stays below this (build_bounds)
@@ -578,11 +585,8 @@ __device__ __forceinline__ bool probe(Walk<G> &w, int f, int nm, int cand, uint6
     // DP[x]: no chain of pairwise compatible candidates that starts with x holds more than DP[x] of them (chain_lengths()), so a
     // node with 5 matches lies below a path of nm matches through x only if DP[x] >= 5 - nm. The child itself first, then every
     // candidate the search would try: what they rule out is not there to find.
-    const unsigned char *DP = nullptr;
-    if constexpr (cand_bounds<G>()) {
-        DP = w.OBb + ((size_t)nl * w.ksumtot * G * 4u + (size_t)round16((uint64_t)w.ksumtot));
-        if (uni((int)DP[rl(w.hks, f) + cand]) < 5 - nm) return false;
-    }
+    const unsigned char *DP = w.OBb + ((size_t)ob_rows<G>((uint32_t)nl) * w.ksumtot * G * 4u + (size_t)round16((uint64_t)w.ksumtot));
+    if (uni((int)DP[rl(w.hks, f) + cand]) < 5 - nm) return false;
     // enter the child
     const int fbase = f;
     w.matB = wl(w.matB, nm, match_base(w, f, cand));
@@ -606,8 +610,7 @@ __device__ __forceinline__ bool probe(Walk<G> &w, int f, int nm, int cand, uint6
                 constexpr uint32_t VB = vmask_bytes<G>();
                 bool in = lane >= nb && lane < kf;
                 const uint32_t lo_ = (uint32_t)(lane < kf ? lane : 0) * VB;
-                int reach = 255;
-                if constexpr (cand_bounds<G>()) reach = DP[(uint32_t)ksf + (lane < kf ? (uint32_t)lane : 0u)];
+                const int reach = DP[(uint32_t)ksf + (lane < kf ? (uint32_t)lane : 0u)];
                 auto vload = [&](int q) -> unsigned long long {
                     const unsigned char *ve = Vb + (uint32_t)rl(ebv, q) * VB + lo_;
                     if (G <= 8) return *ve;
@@ -729,6 +732,70 @@ __device__ __forceinline__ bool path_bound(const Walk<G> &w, const ScreenParams 
     const double pooled = __longlong_as_double((long long)pool[c]);
     const double bp = pooled > w.best ? pooled : w.best;
     return __ballot(((cmask >> c) & 1ull) && (tch[c] + bound) * kBoundSlack > bp) != 0ull;
+}
+
+// The path-aware test where a pass holds one or two candidates (32 / 64 conformer lanes). There the test above would move a row of
+// every deeper candidate per evaluation (250-300 candidates x 64 conformers of the stress model: a quarter of a megabyte). But under
+// a path of five matches hardly any deeper candidate is still compatible with ALL of them (a pair of candidates is compatible in
+// a fifth of the cases on that model), and which ones are is in the V masks: with the lanes spread over the deeper candidates, one
+// AND of masks per match on the path - the child Y = (f, bsel) included - lists them, 64 candidates per trip and 8 bytes per
+// candidate and match. Every candidate x left is priced at BF[x] = base(x) rounded up - its self entry plus, for EVERY level above
+// its own, the largest pair entry any candidate of that level has with it (build_bounds): no leaf adds more for x whatever is matched
+// above it - for the conformers its mask still holds; a level adds at most the largest of its candidates, the subtree below Y at
+// most the sum over the levels. Candidate numbers ascend with the level, so the level maxima are a running maximum: no LDS. A child
+// that fails is dropped like one that fails the level-bound test (it holds >= 5 matches: nothing else is asked of it).
+// tests/bound_study (model_stress64, 16 ligands x 64 conformers): the level bound in index order enters 10 036 frames per ligand,
+// this test under >= 5 matches 1 187 with 1 344 evaluations (with the pair entries of the path and the OB table as above: 757).
+template <int G>
+__device__ __forceinline__ bool path_bound_wide(const Walk<G> &w, const double t /* the child's total, in the lanes of its slot: */, const bool sel,
+                                                const unsigned long long *pool, int f, int nm, int bsel, uint64_t cmask) {
+    static_assert(G >= 32, "lanes over candidates, conformer masks of 32 / 64 bits");
+    constexpr uint32_t VB = vmask_bytes<G>();
+    const int lane = lane_id();
+    const int c = lane % G;
+    const uint32_t ksumtot = w.ksumtot;
+    const uint32_t x0 = (uint32_t)rl(w.hks, f + 1); // first candidate of the levels below f
+    const float *BF = reinterpret_cast<const float *>(w.OBb);
+    const unsigned char *LV = w.OBb + (size_t)ksumtot * G * 4u;
+    const unsigned char *Vy = w.Vb + (long)match_base<G>(w, f, bsel) * (long)VB; // Y's masks: Vy + x * VB (the base may be negative, base + x is not)
+    float below = 0.f, cur = 0.f;
+    int cur_lv = -1;
+    for (uint32_t xb = x0; xb < ksumtot; xb += 64u) {
+        const uint32_t x = xb + (uint32_t)lane;
+        const bool in = x < ksumtot;
+        const uint32_t xo = (in ? x : x0) * VB;
+        auto vload = [&](int q) -> unsigned long long {
+            const unsigned char *ve = w.Vb + (long)rl(w.matB, q) * (long)VB + xo;
+            if (G == 32) return *reinterpret_cast<const uint32_t *>(ve);
+            else return *reinterpret_cast<const unsigned long long *>(ve);
+        };
+        unsigned long long m = cmask;
+        if (G == 32) m &= *reinterpret_cast<const uint32_t *>(Vy + xo);
+        else m &= *reinterpret_cast<const unsigned long long *>(Vy + xo);
+        const int lvl = LV[in ? x : x0];
+        for_rows(nm, vload, [&](unsigned long long v) { m &= v; });
+        unsigned long long ex = __ballot(in && m != 0ull);
+        while (ex) { // the candidates still compatible with the whole path, in ascending order
+            const int xl = __ffsll(ex) - 1;
+            ex &= ex - 1ull;
+            uint64_t mm = (uint64_t)(uint32_t)rl((int)(uint32_t)m, xl);
+            if (G > 32) mm |= (uint64_t)(uint32_t)rl((int)(uint32_t)(m >> 32), xl) << 32;
+            const int lv = rl(lvl, xl);
+            const float bf = BF[(size_t)(xb + (uint32_t)xl) * G + c];
+            if (lv != cur_lv) {
+                below = below + cur;
+                cur = 0.f;
+                cur_lv = lv;
+            }
+            const float v = ((mm >> c) & 1ull) ? bf : 0.f;
+            cur = fmaxf(cur, v); // (a NaN base - zero weights - raises no maximum)
+        }
+    }
+    below = below + cur;
+    const double bound = (double)below * (1.0 + 4e-6);
+    const double pooled = __longlong_as_double((long long)pool[c]);
+    const double bp = pooled > w.best ? pooled : w.best;
+    return __ballot(sel && ((cmask >> c) & 1ull) && (t + bound) * kBoundSlack > bp) != 0ull;
 }
 
 // The path sums of the wave's buffer for a job that starts with matches on its path (a queued subtree): the rows of match
@@ -1132,6 +1199,24 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
                         ss = (__ffsll(ab) - 1) / G;
                         const unsigned long long before = ss == 0 ? 0ull : (vb & ((1ull << (ss * G)) - 1ull));
                         if (before) mx = mx > 1 ? mx : 1; // existing children dropped by the bound test return at least 1
+                        if constexpr (G >= 32) {
+                            const bool shallow_w = nm < 4 && bound_from != 255 && !(p.flags & 4096) && !(p.flags & 262144);
+                            if ((bounded || shallow_w) && !(p.flags & 131072)) { // the path-aware test of these shapes: children that passed the level bound, and children with fewer than 5 matches
+                                go = path_bound_wide<G>(w, t, s == ss, pool, f, nm, rl(bvec, ss * G), (vb >> (ss * G)) & GM);
+                                ++w.npath;
+                                if (!go) {
+                                    ++w.ndrop;
+                                    const int bdrop = rl(bvec, ss * G);
+                                    if (nm < 4 && mx < 5 - nm) { // the frame still has to know whether the dropped child reaches 5 matches (tree.py:98)
+                                        probe_slot = ss;         // (the probe's own bookkeeping moves nb / cb past the child)
+                                    } else {
+                                        mx = mx > 1 ? mx : 1;
+                                        nb = bdrop + 1;
+                                        cb &= ~((2ull << bdrop) - 1ull);
+                                    }
+                                }
+                            }
+                        }
                     }
                     if (go) {
                     const int bsel = rl(bvec, ss * G);
@@ -1841,32 +1926,41 @@ __device__ __forceinline__ void chain_lengths(const ScreenParams &p, unsigned ch
     const uint32_t *rowbase = reinterpret_cast<const uint32_t *>(lds + kOffRow);
     const unsigned char *Vt = rec + rec_v_off<G>(L.ksumtot, L.T, (uint32_t)L.nl);
     unsigned char *DPt = rec + rec_dp_off<G>(L.ksumtot, L.T, (uint32_t)L.nl);
-    uint32_t *dpl = reinterpret_cast<uint32_t *>(lds + ws.off_tch);
-    const uint32_t cap = (ws.bytes - ws.off_tch) / 4u;
+    // (32 / 64 conformer lanes keep next to nothing in LDS: there the lengths are worked out in the wave's buffer of path totals in
+    // global memory, idle until the walk)
+    constexpr bool kInLds = totals_in_lds<G>();
+    uint32_t *dpl = kInLds ? reinterpret_cast<uint32_t *>(lds + ws.off_tch) : reinterpret_cast<uint32_t *>(p.totbuf + (size_t)blockIdx.x * kTotBufBytes);
+    const uint32_t cap = kInLds ? (ws.bytes - ws.off_tch) / 4u : kTotBufBytes / 4u;
     if (L.ksumtot > cap || (p.flags & (4u | 32768u))) {
         for (uint32_t x = (uint32_t)lane; x < L.ksumtot; x += 64u) DPt[x] = 255;
         return;
     }
-    lds_sync();
+    auto sync = [&]() {
+        if (kInLds) lds_sync();
+        else wave_sync();
+    };
+    sync();
     for (uint32_t x = (uint32_t)lane; x < L.ksumtot; x += 64u) dpl[x] = 1u;
     constexpr uint32_t VB = vmask_bytes<G>();
     for (int j = L.nl - 2; j >= 0; --j) {
-        lds_sync(); // (the deeper levels' lengths are final)
+        sync(); // (the deeper levels' lengths are final)
         const uint32_t kj = (uint32_t)uni(lk[j]), ksj = (uint32_t)uni((int)ksum[j]), ks1 = (uint32_t)uni((int)ksum[j + 1]);
         const uint32_t nd = L.ksumtot - ks1, row = (uint32_t)uni((int)rowbase[j]);
         const float inv_nd = 1.0f / (float)nd;
         for (uint32_t e = (uint32_t)lane; e < kj * nd; e += 64u) {
             const uint32_t a = (uint32_t)(((float)e + 0.5f) * inv_nd), xo = e - a * nd;
             const unsigned char *ve = Vt + (size_t)(row + e) * VB;
-            uint32_t v;
-            if (VB == 1) v = *ve;
-            else v = *reinterpret_cast<const uint16_t *>(ve);
+            bool v;
+            if (VB == 1) v = *ve != 0;
+            else if (VB == 2) v = *reinterpret_cast<const uint16_t *>(ve) != 0;
+            else if (VB == 4) v = *reinterpret_cast<const uint32_t *>(ve) != 0u;
+            else v = *reinterpret_cast<const unsigned long long *>(ve) != 0ull;
             if (v) atomicMax(&dpl[ksj + a], dpl[ks1 + xo] + 1u);
         }
     }
-    lds_sync();
+    sync();
     for (uint32_t x = (uint32_t)lane; x < L.ksumtot; x += 64u) DPt[x] = (unsigned char)dpl[x];
-    lds_sync();
+    sync();
 }
 
 // Upper bounds for the tree search: level l can add at most
@@ -1891,7 +1985,7 @@ __device__ __forceinline__ void build_bounds(const ScreenParams &p, unsigned cha
 #ifdef PMX_TABLE_TICKS
     unsigned long long tick_ = __builtin_amdgcn_s_memtime();
 #endif
-    if (cand_bounds<G>()) chain_lengths<G>(p, lds, ws, L, rec);
+    chain_lengths<G>(p, lds, ws, L, rec);
     PMX_TICK(5);
     if (p.flags & 4) { // debug: nothing is ever dropped
         for (int l = s; l <= nl; l += SLOTS) Rt[(size_t)l * G + c] = __builtin_inf();
@@ -1920,10 +2014,9 @@ __device__ __forceinline__ void build_bounds(const ScreenParams &p, unsigned cha
                 }
                 v += (double)m;
             }
-            if (cand_bounds<G>()) {
-                Wt[(size_t)(ksl + b) * G + c] = v; // base(l, b), replaced by the candidate's own bound below
-                if (c == 0) LVt[ksl + b] = (unsigned char)l;
-            }
+            if (cand_bounds<G>()) Wt[(size_t)(ksl + b) * G + c] = v; // base(l, b), replaced by the candidate's own bound below
+            else OBt[(size_t)(ksl + b) * G + c] = float_up(v);          // BF: base(l, b) for path_bound_wide()
+            if (c == 0) LVt[ksl + b] = (unsigned char)l;
             u = v > u ? v : u;
         }
 #pragma unroll

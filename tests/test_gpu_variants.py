@@ -74,9 +74,9 @@ def test_zero_type_weight_matches_oracle(oracle):
 @pytest.mark.parametrize("env", [{"PMX_TREE_FLAGS": "8"}, {"PMX_TREE_FLAGS": "4"}, {"PMX_BUDGET": "16", "PMX_MIN_LEVELS": "0"},
                                  {"PMX_SLICE_KB": "4"}, {"PMX_SLICE_KB": "4", "PMX_ARENA_MB": "16", "PMX_BUDGET": "64"},
                                  {"PMX_TREE_FLAGS": "128"}, {"PMX_TREE_FLAGS": "1024"}, {"PMX_PATH_KB": "2"}, {"PMX_TREE_FLAGS": "32768"},
-                                 {"PMX_TREE_FLAGS": "65536"}, {"PMX_DEAD_MIN_ENTRIES": "1"}],
+                                 {"PMX_TREE_FLAGS": "65536"}, {"PMX_DEAD_MIN_ENTRIES": "1"}, {"PMX_TREE_FLAGS": "131072"}],
                          ids=["exact-terms", "no-bound-test", "tiny-budget", "tiny-slices", "tiny-slices-and-arena", "no-candidate-filter",
-                              "no-path-bound", "tiny-path-buffer", "no-chain-lengths", "no-dead-entry-test", "dead-entry-test-everywhere"])
+                              "no-path-bound", "tiny-path-buffer", "no-chain-lengths", "no-dead-entry-test", "dead-entry-test-everywhere", "no-wide-path-test"])
 @pytest.mark.parametrize("name", GOLDEN_SETS)
 def test_engine_settings_match_reference_golden(name, env, monkeypatch):
     """The golden sets under settings that force the rarely taken paths of the engine: Gaussian terms evaluated one by
@@ -92,6 +92,31 @@ def test_engine_settings_match_reference_golden(name, env, monkeypatch):
     zero = ref == 0
     assert np.all(got[zero] == 0.0)
     assert rel_err(got[~zero], ref[~zero]).max() < RTOL + 6e-8
+
+
+@pytest.mark.parametrize("conformers", [2, 3, 4, 12, 16, 20, 32, 33, 48])
+def test_every_lane_shape_matches_the_oracle(conformers, oracle, monkeypatch):
+    """The kernels are instantiated per lane count G = 2^ceil(log2(conformers)) (1 ... 64); the golden sets cover 1, 8 and 64. Every
+    other shape - and the two models: the 6OIM-like one and the 64-node one, whose trees are large enough for the bound tests,
+    the path-aware tests (path_bound() up to 16 lanes, path_bound_wide() at 32 / 64) and the task rounds to matter - against the
+    oracle, default and with the trees split almost at once."""
+    from pharmaconet_amd.constants import weights_vector
+    from pharmaconet_amd.synthetic import synthetic_library
+
+    for name, n in (("set_6oim_c8", 160), ("set_s64_c8", 48)):
+        model, _, _, _ = load_golden(name)
+        lib = synthetic_library(n, num_conformers=conformers, model_nodes=_model_nodes(model), active_fraction=0.5, seed=5000 + conformers)
+        ref = oracle.oracle_score(model.flat, lib, weights_vector(None), num_threads=os.cpu_count() or 8)
+        zero = ref == 0
+        for env in ({}, {"PMX_BUDGET": "16", "PMX_MIN_LEVELS": "0"}):
+            with monkeypatch.context() as mp:
+                for k, v in env.items():
+                    mp.setenv(k, v)
+                got, status = _gpu(model, lib)
+            assert np.all(status == 0)
+            assert np.all(got[zero] == 0.0)
+            assert rel_err(got[~zero], ref[~zero]).max() < RTOL, (name, env)
+        assert np.count_nonzero(ref) > n // 2
 
 
 def test_structural_limits_are_explicit():
