@@ -1844,6 +1844,88 @@ __device__ __forceinline__ void build_tables(const ScreenParams &p, unsigned cha
                         finish_entry(e, on, acc, fails);
                     }
                     n_items += (uint32_t)(((npass + SLOTS - 1) / SLOTS) * ni * nj);
+                } else if constexpr (SLOTS == 1) {
+                    // 64 conformer lanes: the wavefront works on ONE entry at a time, so nothing forces it through the node pairs that
+                    // count for nothing - a node whose subset under the candidate is empty (graph_match.py:148-155: no model node of its
+                    // types in the cluster) adds 0 and never fails, and 45 % of the stress model's items are such pairs. (With 8 slots
+                    // the slots walk in step, and a pair that is empty for one entry is not for its neighbours.) The items of the chunk
+                    // are one list as below - entries in turn, of each its counted pairs in the reference's order, PMX_ITEM_BATCH cells on
+                    // the way at a time across entry boundaries - over L1 x L2 pairs per entry instead of all of them.
+                    constexpr int IB = PMX_ITEM_BATCH;
+                    int total = 0, npass2 = 0;
+                    {
+                        const bool inl = lane < npass;
+                        const int el = plist[inl ? lane : 0];
+                        const int e = eb + el;
+                        const int sa = (int)(((float)e + 0.5f) * inv_kj), sb = e - sa * kj;
+                        int cnt = inl ? (int)lcnt[i * ws.kp + sa] * (int)lcnt[j * ws.kp + sb] : 0;
+                        if (inl && cnt == 0) { // no counted pair: the sum of nothing, no fails (match_utils.py:71-74): 0 for every conformer, empty mask
+                            const uint32_t pe = row_i + (uint32_t)sa * nd_i + off_j + (uint32_t)sb;
+                            float *row = Pt + (size_t)pe * G;
+#pragma unroll
+                            for (int g = 0; g < G; g += 4) *reinterpret_cast<float4 *>(row + g) = make_float4(0.f, 0.f, 0.f, 0.f);
+                            unsigned char *ve = Vt + (size_t)pe * vmask_bytes<G>();
+                            for (uint32_t g = 0; g < vmask_bytes<G>(); ++g) ve[g] = 0;
+                        }
+                        const unsigned long long hb = __ballot(inl && cnt > 0);
+                        lds_sync(); // (every lane has read its entry: the list is compacted in place)
+                        if (inl && cnt > 0) plist[__builtin_amdgcn_mbcnt_hi((uint32_t)(hb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hb, 0u))] = (uint8_t)el;
+                        npass2 = (int)__popcll(hb);
+#pragma unroll
+                        for (int d = 1; d < 64; d <<= 1) cnt += __shfl_xor(cnt, d);
+                        total = uni(cnt);
+                    }
+                    lds_sync();
+                    int le = -1, lu = 0, rowa = 0, rowb = 0;
+                    unsigned long long mur = 0ull, mvr = 0ull, mv_full = 0ull; // nodes of the two clusters still to come for the entry being loaded
+                    auto counted = [&](int k) { // L1 x L2 of the k-th listed entry
+                        const int e = eb + uni((int)plist[k]);
+                        const int sa = (int)(((float)e + 0.5f) * inv_kj), sb = e - sa * kj;
+                        return uni((int)lcnt[i * ws.kp + sa]) * uni((int)lcnt[j * ws.kp + sb]);
+                    };
+                    int fk = 0, fin_left = npass2 > 0 ? counted(0) : 0;
+                    float acc = 0.f;
+                    int fails = 0;
+                    for (int t0 = 0; t0 < total; t0 += IB) {
+                        ItemLoad Lq[IB];
+#pragma unroll
+                        for (int q = 0; q < IB; ++q) {
+                            const bool in = t0 + q < total; // (past the end: the empty subset pair)
+                            int lv = 0;
+                            if (in) {
+                                if (mvr == 0ull) {
+                                    mur &= mur - 1ull; // the next node of the first cluster (0 stays 0)
+                                    if (mur == 0ull) { // the next entry
+                                        ++le;
+                                        const int e = eb + uni((int)plist[le]);
+                                        const int sa = (int)(((float)e + 0.5f) * inv_kj), sb = e - sa * kj;
+                                        rowa = nci + sa * ni, rowb = ncj + sb * nj;
+                                        mur = __ballot(lane < ni && nc[rowa + (lane < ni ? lane : 0)] != 0);
+                                        mv_full = __ballot(lane < nj && nc[rowb + (lane < nj ? lane : 0)] != 0);
+                                    }
+                                    lu = __ffsll((unsigned long long)mur) - 1;
+                                    mvr = mv_full;
+                                }
+                                lv = __ffsll((unsigned long long)mvr) - 1;
+                                mvr &= mvr - 1ull;
+                            }
+                            const int uu = in ? lu : 0, vv = in ? lv : 0;
+                            const float d = staged ? dl[(uu * nj + vv) * G + c] : node_distance(si, uu, sj, vv);
+                            Lq[q] = item_load(p, in ? (uint32_t)nc[rowa + uu] : 0u, in ? (uint32_t)nc[rowb + vv] : 0u, d, cell_of(p, d));
+                        }
+#pragma unroll
+                        for (int q = 0; q < IB; ++q) {
+                            if (t0 + q < total) {
+                                item_finish(p, Lq[q], acc, fails, n_exact);
+                                if (--fin_left == 0) {
+                                    finish_entry(eb + uni((int)plist[fk]), true, acc, fails);
+                                    acc = 0.f, fails = 0;
+                                    if (++fk < npass2) fin_left = counted(fk);
+                                }
+                            }
+                        }
+                    }
+                    n_items += (uint32_t)total;
                 } else {
                     // The (entry, node pair) items of the chunk as ONE list per slot - slot s takes the passing entries s, s + SLOTS, ...
                     // and every entry its node pairs (u, v) in the reference's order (u outer) - walked PMX_ITEM_BATCH items at a
