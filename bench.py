@@ -1,19 +1,26 @@
 #!/usr/bin/env python3
-"""Benchmark of the screening hot path: ligand-conformers scored per second for one pocket.
+"""Benchmark of the screening hot path: ligand-conformers scored per second.
 
     python bench.py --gpus N --steps K --warmup W
 
 One *step* = one pass of the hot path (`PharmacophoreModel.screen`: score tables -> tree search -> scores,
-then top-k) over this rank's resident library. Workload at N = 1 is BASELINE.json configs[1]: the 6OIM-like
-pharmacophore model against 1M synthetic ligands (<= 32 pharmacophore points, 8 conformers each). For N > 1
-every rank holds its own 12.5M-ligand shard of the synthetic library (configs[2]: 100M ligands on 8 GPUs, weak
-scaling) and each step ends with the all-gather of per-rank top-k over RCCL.
+then top-k) over this rank's resident library. Workloads (BASELINE.json `configs`):
+
+* default, N = 1: configs[1] - the 6OIM-like pharmacophore model against 1M synthetic ligands (<= 32
+  pharmacophore points, 8 conformers each);
+* N > 1: configs[2] - every rank holds its own 12.5M-ligand shard of the synthetic library (100M ligands on 8
+  GPUs, weak scaling) and each step ends with the all-gather of per-rank top-k over RCCL. `--gpus N` with no
+  `WORLD_SIZE` in the environment starts the N ranks itself (re-executes under `torch.distributed.run`, one
+  rank per GPU, rendezvous on 127.0.0.1); under the driver's own `torch.distributed.run` it is one of the ranks;
+* `--pockets 16 --ligands 1253376`: the per-GPU shard of configs[3] (16 pockets x one shared library);
+* `--model stress64`: configs[4] - the 64-node model against 64-conformer ligands (100 352 of them by default).
 
 Rank 0 prints ONE JSON line. `value` is measured with the library already resident in HBM.
 `roofline.achieved` prices the dominant kernel (the one with the largest HIP-event time per chunk) at the
 ALGORITHMIC bytes of the path (packed ligand bytes + 8-byte offset in, 4-byte score + 4-byte status out, per
 ligand it processes) over its HIP-event duration; this path is not HBM-bound, the fraction is
-reported as asked.
+reported as asked. `parity_sample` compares 512 ligands of the timed library with the CPU oracle (outside the
+timed region), so the line certifies what it measured.
 """
 
 from __future__ import annotations
@@ -21,6 +28,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -31,20 +39,74 @@ REPO = Path(__file__).resolve().parent
 sys.path.insert(0, str(REPO))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s HBM3E spec
-PROFILE_TAG = "r4"  # the committed rocprofv3 --pmc summaries (profiles/<tag>_*.json) the static blocks of the line are read from
+PROFILE_TAG = "r5"  # the committed rocprofv3 --pmc summaries (profiles/<tag>_*.json) the static blocks of the line are read from
+
+# name -> (model file under tests/golden, conformers, ligands on one GPU, topologies, fraction of ligands drawn on the model's nodes,
+#          (seed of the topologies | None = tools.synthetic.BASE_SEED, offset of the perturbation stream's seed))
+WORKLOADS = {
+    "6oim": ("model_6oim_like.pm", 8, 1_000_000, 4096, 0.1, (None, 0)),
+    "stress64": ("model_stress64.pm", 64, 100_352, 512, 0.2, (6464, 1)),  # (the library of tools/stress_shape.py, rounds 3-4)
+}
+
+
+def csrc_digest():
+    """sha256 over the kernel sources: a committed profile summary is quoted only for the build it was taken on."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in sorted((REPO / "pharmaconet_amd" / "csrc").iterdir()):
+        if f.suffix in (".hip", ".h", ".cpp"):
+            h.update(f.name.encode() + b"\0" + f.read_bytes())
+    return h.hexdigest()[:16]
+
+
+def committed_profile(name):
+    """profiles/<tag>_<name>.json if it was taken on THIS build of csrc/ (tools/collect_profiles.py stamps `csrc_sha16`), else None + why."""
+    path = REPO / "profiles" / f"{PROFILE_TAG}_{name}.json"
+    try:
+        d = json.loads(path.read_text())
+    except Exception:
+        return None, f"profiles/{PROFILE_TAG}_{name}.json not found: not quoted"
+    if d.get("csrc_sha16") != csrc_digest():
+        return None, f"profiles/{PROFILE_TAG}_{name}.json was taken on another build of csrc/ ({d.get('csrc_sha16')} != {csrc_digest()}): not quoted"
+    return d, f"profiles/{PROFILE_TAG}_{name}.json"
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def build_library(model, n_ligands, n_conf, base_count, rank, device):
+def start_ranks(args):
+    """`--gpus N` with no rendezvous in the environment: start the N ranks (one per GPU) under torch.distributed.run and pass
+    their output through; rank 0 of the children prints the JSON line."""
+    import socket
+
+    if os.environ.get("PMX_BENCH_BACKEND", "nccl") == "nccl":
+        import torch
+
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            log(f"bench.py: --gpus {args.gpus} but {have} GPU(s) visible (one rank per GPU over RCCL)")
+            sys.exit(2)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    log("bench.py: starting", args.gpus, "ranks:", " ".join(cmd))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def build_library(model, n_ligands, n_conf, base_count, rank, device, active_fraction=0.1, seed=None):
     import torch
 
     from pharmaconet_amd.constants import TYPE_ID
     from pharmaconet_amd.engine import DeviceLibrary
-    from pharmaconet_amd.synthetic import BASE_SEED, expand_library_on_device, synthetic_library
+    from tools.synthetic import BASE_SEED, expand_library_on_device, synthetic_library
 
+    seed, expand_offset = seed if seed is not None else (None, 0)
+    seed = BASE_SEED if seed is None else seed
     st = model.__getstate__()
     centers = np.array([n["center"] for n in st["nodes"]], dtype=np.float64)
     types = np.array([TYPE_ID[n["type"]] for n in st["nodes"]])
@@ -55,10 +117,10 @@ def build_library(model, n_ligands, n_conf, base_count, rank, device):
     molecules = []
     base = synthetic_library(
         base_count, first=0, num_conformers=n_conf, model_nodes=(centers, types),
-        active_fraction=0.1, seed=BASE_SEED, max_nodes=32, conformer_noise=0.0, molecules_out=molecules,
+        active_fraction=active_fraction, seed=seed, max_nodes=32, conformer_noise=0.0, molecules_out=molecules,
     )
     replicas = (n_ligands + base_count - 1) // base_count
-    offsets, data = expand_library_on_device(base, replicas, device, seed=BASE_SEED + 1000 * rank)
+    offsets, data = expand_library_on_device(base, replicas, device, seed=seed + expand_offset + 1000 * rank)
     n_total = replicas * base_count
     lib = DeviceLibrary.from_device_buffers(offsets, data, device)
     torch.cuda.synchronize()
@@ -109,58 +171,101 @@ def end_to_end(molecules, lib, data, ms_per_step, n_conf_total):
     }
 
 
-def cpu_baseline(model, offsets, data, n_conf, budget_s=15.0):
-    """Time the CPU oracle (oracle/, a port of the reference's algorithm pinned to its outputs) on a
-    bounded sample of the same library with every host core."""
+def host_sample(offsets, data, index):
+    """The records `index` (ascending ligand numbers) of the device library as a host `PackedLibrary`."""
+    from pharmaconet_amd.library import PackedLibrary
+
+    off = offsets.cpu().numpy().astype(np.int64)
+    recs = [bytes(data[int(off[i]) : int(off[i + 1])].cpu().numpy()) for i in index]
+    return PackedLibrary.from_records(recs)
+
+
+def cpu_baseline(pockets, offsets, data, n_conf, budget_s=10.0):
+    """Time the CPU oracle (oracle/, a port of the reference's algorithm pinned to its outputs) on a bounded sample of the same
+    library: with every host core, and with one (`screening.py --cpus N` / `--cpus 1`)."""
     from oracle import oracle as orc
     from pharmaconet_amd.constants import weights_vector
     from pharmaconet_amd.library import PackedLibrary
 
     cores = os.cpu_count() or 1
+    n_all = offsets.numel() - 1
 
     def sample(n):
         off = offsets[: n + 1].cpu().numpy().astype(np.uint64)
         return PackedLibrary(off, data[: int(off[-1])].cpu().numpy())
 
+    def timed(lib, threads):
+        t0 = time.perf_counter()
+        for pocket in pockets:
+            orc.oracle_score(pocket.flat, lib, w, num_threads=threads)
+        return time.perf_counter() - t0
+
     w = weights_vector(None)
-    probe = sample(min(2048, offsets.numel() - 1))
+    probe = sample(min(2048 if n_conf <= 16 else 256, n_all))
     t0 = time.perf_counter()
-    _, probe_stats = orc.oracle_score(model.flat, probe, w, num_threads=cores, with_stats=True)
-    dt = time.perf_counter() - t0
-    rate = len(probe) / max(dt, 1e-6)
-    n = int(min(offsets.numel() - 1, max(len(probe), rate * budget_s)))
-    lib = sample(n)
-    t0 = time.perf_counter()
-    orc.oracle_score(model.flat, lib, w, num_threads=cores)
-    dt = time.perf_counter() - t0
-    work = {  # what the reference's algorithm does per ligand on this library (oracle counters, first 2048 ligands)
+    _, probe_stats = orc.oracle_score(pockets[0].flat, probe, w, num_threads=cores, with_stats=True)
+    rate = len(probe) / max(time.perf_counter() - t0, 1e-6) / len(pockets)  # ligands/s with every core, all pockets
+    work = {  # what the reference's algorithm does per ligand on this library (oracle counters on the probe, first pocket)
         "gaussian_terms_per_ligand_conformer": float(probe_stats["n_terms"].mean()),
         "tree_nodes_per_ligand_without_bound_test": float(probe_stats["n_tree"].mean()),
     }
+    n = int(min(n_all, max(len(probe), rate * budget_s)))
+    lib = sample(n)
+    dt = timed(lib, cores)
+    rate = n / dt
+    n1 = int(min(n, max(16, rate / cores * 2.0 * budget_s)))  # (threads share caches and clocks: one core alone is faster than 1 / cores)
+    lib1 = sample(n1)
+    dt1 = timed(lib1, 1)
     return {
-        "value": n * n_conf / dt,
-        "unit": "ligand-conformers/s",
+        "value": n * n_conf * len(pockets) / dt,
+        "unit": "ligand-conformers/s" if len(pockets) == 1 else "pocket-ligand-conformers/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"first {n} ligands of the same library, OpenMP over ligands, {dt:.1f}s",
+        "sample": f"first {n} ligands of the same library" + (f" against the {len(pockets)} pockets" if len(pockets) > 1 else "") + f", OpenMP over ligands, {dt:.1f}s",
+        "one_core": {"value": n1 * n_conf * len(pockets) / dt1, "cores": 1, "sample": f"first {n1} ligands, {dt1:.1f}s"},
     }, work
 
 
+def parity_sample(pocket, scores, offsets, data, n=512):
+    """512 evenly spaced ligands of the timed library, the GPU's scores of the last timed step against the oracle's."""
+    from oracle import oracle as orc
+    from pharmaconet_amd.constants import weights_vector
+
+    n_lig = offsets.numel() - 1
+    index = np.unique(np.linspace(0, n_lig - 1, num=min(n, n_lig)).astype(np.int64))
+    lib = host_sample(offsets, data, index)
+    import torch
+
+    got = scores[torch.from_numpy(index).to(scores.device)].cpu().numpy().astype(np.float64)
+    ref = orc.oracle_score(pocket.flat, lib, weights_vector(None), num_threads=min(os.cpu_count() or 1, 64))
+    nz = ref > 0
+    err = np.abs(got[nz] - ref[nz]) / ref[nz]
+    return {
+        "ligands": int(len(index)),
+        "against": "oracle/ (CPU restatement of GraphMatcher.run(), pinned to the reference's outputs), outside the timed region",
+        "nonzero_scores": int(nz.sum()),
+        "max_rel_err": float(err.max()) if nz.any() else 0.0,
+        "median_rel_err": float(np.median(err)) if nz.any() else 0.0,
+        "above_1e-5": int((err > 1e-5).sum()),
+        "zero_nonzero_mismatches": int(((got > 0) != nz).sum()),
+    }
+
+
 def issue_block(n_lig, pass_ms):
-    """Scalar / vector wave-instructions per ligand (committed SQ counters) against the CU's issue rates at this run's pass time."""
-    try:
-        sq = json.loads((REPO / "profiles" / (PROFILE_TAG + "_pmc_sq_summary.json")).read_text())["counters"]
-        salu = sum(v["SQ_INSTS_SALU"] for v in sq.values()) / (2 * 200704)
-        valu = sum(v["SQ_INSTS_VALU"] for v in sq.values()) / (2 * 200704)
-    except Exception:
-        return None
+    """Scalar / vector wave-instructions per ligand (committed SQ counters of THIS build) against the CU's issue rates at this run's pass time."""
+    prof, src = committed_profile("pmc_sq_summary")
+    if prof is None:
+        return {"from_profile": None, "note": src}
+    per = prof["ligands"] * prof.get("passes", 2)
+    salu = sum(v["SQ_INSTS_SALU"] for v in prof["counters"].values()) / per
+    valu = sum(v["SQ_INSTS_VALU"] for v in prof["counters"].values()) / per
     cus, clock_hz = 256, 2.4e9
     scalar_ms = salu * n_lig / cus / clock_hz * 1e3          # one scalar wave-instruction per cycle and CU
     vector_ms = valu * n_lig * 2 / (4 * cus) / clock_hz * 1e3  # a wave64 VALU instruction holds one of 4 SIMD-32s for 2 cycles
     return {"scalar_insts_per_ligand": salu, "vector_insts_per_ligand": valu, "scalar_unit_busy": scalar_ms / pass_ms,
             "vector_units_busy": vector_ms / pass_ms, "pass_ms": pass_ms,
-            "from_profile": f"profiles/{PROFILE_TAG}_pmc_sq_summary.json",
-            "note": "instruction counts are NOT measured in this run: they come from the committed rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_VALU pass of the same build (bench.py --ligands 200000 --steps 1 --warmup 0: the timed step + the profiled pass = 2 passes over 200 704 ligands), priced at this run's pass time"}
+            "from_profile": src,
+            "note": "instruction counts are NOT measured in this run: they come from the committed rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_VALU pass of the same build of csrc/ (checked by content hash), priced at this run's pass time"}
 
 
 def main():
@@ -168,24 +273,33 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--ligands", type=int, default=0, help="ligands per GPU (default: 1M on one GPU = BASELINE configs[1]; 12.5M per GPU on several = configs[2])")
-    ap.add_argument("--conformers", type=int, default=8)
-    ap.add_argument("--topologies", type=int, default=4096, help="distinct synthetic molecules per GPU")
+    ap.add_argument("--model", choices=sorted(WORKLOADS), default="6oim", help="6oim: BASELINE configs[1] / [2]; stress64: configs[4] (64-node model, 64 conformers)")
+    ap.add_argument("--ligands", type=int, default=0, help="ligands per GPU (default: 1M on one GPU = BASELINE configs[1]; 12.5M per GPU on several = configs[2]; 100 352 for --model stress64)")
+    ap.add_argument("--conformers", type=int, default=0)
+    ap.add_argument("--topologies", type=int, default=0, help="distinct synthetic molecules per GPU")
     ap.add_argument("--topk", type=int, default=1000)
     ap.add_argument("--pockets", type=int, default=1, help="score this many distinct pockets (1..16) against the shared library (BASELINE configs[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-serial-leg", action="store_true", help="skip the end-to-end (pack + copy) side measurement")
+    ap.add_argument("--no-parity-sample", action="store_true")
+    ap.add_argument("--dump-dir", default=None, help="every rank writes its shard's scores and rank 0 the merged top-k here (tests)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        start_ranks(args)  # does not return
 
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
-    if args.ligands <= 0:
-        args.ligands = 1_000_000 if int(os.environ.get("WORLD_SIZE", "1")) == 1 else 12_500_000
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        log(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}")
+    model_file, wl_conf, wl_ligands, wl_topo, wl_active, wl_seed = WORKLOADS[args.model]
+    if args.ligands <= 0:
+        args.ligands = wl_ligands if (world == 1 or args.model != "6oim") else 12_500_000
+    args.conformers = args.conformers or wl_conf
+    args.topologies = args.topologies or wl_topo
+    if world != args.gpus:
+        log(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}: the line reports n_gpus = {world}")
     # PMX_BENCH_DEVICE / PMX_BENCH_BACKEND exist to rehearse the multi-rank path on a 1-GPU box (all ranks on one
     # device, gloo); the driver's runs use one GPU per rank and RCCL ("nccl").
     dev_index = int(os.environ.get("PMX_BENCH_DEVICE", local_rank))
@@ -206,14 +320,14 @@ def main():
     entry.build()
     from pharmaconet_amd import PharmacophoreModel
     from pharmaconet_amd import engine
-    from pharmaconet_amd.distributed import TopkExchange, allgather_topk, merge_topk
+    from pharmaconet_amd.distributed import TopkExchange, allgather_topk
 
-    model = PharmacophoreModel.load(REPO / "tests" / "golden" / "model_6oim_like.pm")
+    model = PharmacophoreModel.load(REPO / "tests" / "golden" / model_file)
     pockets = [model]
     if args.pockets > 1:
         pockets = [PharmacophoreModel.load(REPO / "tests" / "golden" / "pockets16" / f"model_{k:02d}.pm") for k in range(min(args.pockets, 16))]
     exchange = TopkExchange(device) if (world > 1 and backend == "nccl") else None
-    lib, offsets, data, molecules = build_library(model, args.ligands, args.conformers, args.topologies, rank, device)
+    lib, offsets, data, molecules = build_library(model, args.ligands, args.conformers, args.topologies, rank, device, wl_active, wl_seed)
     n_lig = len(lib)
     n_conf_total = lib.total_conformers
     index_base = rank * n_lig
@@ -244,13 +358,17 @@ def main():
         res, top = step()
     barrier()
     elapsed = time.perf_counter() - t0
+    if args.dump_dir:
+        os.makedirs(args.dump_dir, exist_ok=True)
+        np.savez(os.path.join(args.dump_dir, f"rank{rank}.npz"), scores=res.scores.cpu().numpy(), index_base=index_base,
+                 top_scores=np.asarray(top[0].cpu() if hasattr(top[0], "cpu") else top[0]), top_indices=np.asarray(top[1].cpu() if hasattr(top[1], "cpu") else top[1]))
     # One more, untimed pass with HIP events around the phases (pmx_set_profiling: event records only) and the device
     # counters read back: the kernel durations behind the roofline block.
     prof = None
     if rank == 0:
         engine.set_profiling(True)
         try:
-            engine.screen(pockets[0], lib, topk=args.topk, index_base=index_base)
+            engine.screen(pockets[-1], lib, topk=args.topk, index_base=index_base)
             torch.cuda.synchronize()
             prof = engine.last_score_stats()
             log(f"[rank 0] profiled pass: {prof}")
@@ -276,15 +394,16 @@ def main():
         ligands_per_launch = prof["ligands_last"]
         achieved = (alg_bytes_per_ligand * ligands_per_launch) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         # HBM traffic per launch from the committed PMC passes (FETCH_SIZE / WRITE_SIZE, collected separately with
-        # rocprofv3 --pmc and corrected as MI355X_MICROARCH.md prescribes), scaled to this launch's ligands
-        traffic = None
-        try:
-            pmc = json.loads((REPO / "profiles" / (PROFILE_TAG + "_hbm_traffic.json")).read_text())
-            key = "ligand_kernel" if dominant.startswith("ligand_kernel") else "task_kernel"
-            if args.conformers == 8 and len(pockets) == 1:
+        # rocprofv3 --pmc and corrected as MI355X_MICROARCH.md prescribes), scaled to this launch's ligands - quoted only
+        # when the summary was taken on this build of csrc/ and on this workload
+        bench_shape = args.model == "6oim" and args.conformers == 8 and len(pockets) == 1
+        traffic, traffic_src = None, "profiled on the 6OIM-like model at 8 conformers only: not quoted for this workload"
+        if bench_shape:
+            pmc, traffic_src = committed_profile("hbm_traffic")
+            if pmc is not None:
+                key = "ligand_kernel" if dominant.startswith("ligand_kernel") else "task_kernel"
                 traffic = pmc["kernels"][key]["hbm_bytes_per_ligand"] * ligands_per_launch
-        except Exception:
-            traffic = None
+        model_words = {"6oim": "6OIM-like model (37 nodes, 11 clusters)", "stress64": "stress model (64 nodes, 54 clusters)"}[args.model]
         out = {
             "metric": f"ligand-conformers scored/sec ({len(pockets)} pocket{'s' if len(pockets) > 1 else ''})",
             "value": value,
@@ -299,15 +418,17 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": (f"6OIM-like model (37 nodes, 11 clusters)" if len(pockets) == 1 else f"{len(pockets)} fixture pockets (pockets16)")
+                "workload": (model_words if len(pockets) == 1 else f"{len(pockets)} fixture pockets (pockets16)")
                             + f" vs {n_lig} synthetic ligands per GPU = {min(args.topologies, n_lig)} molecule topologies x "
                             f"{-(-n_lig // min(args.topologies, n_lig))} copies with every node displaced (sigma 0.35 A) and every conformer "
                             f"coordinate jittered (sigma 0.30 A); mean {lib.num_bytes / n_lig / (12.0 * args.conformers):.1f} pharmacophore nodes "
-                            f"(<= 32), {args.conformers} conformers each, 10 % drawn on the model's nodes; top-{args.topk}",
+                            f"(<= 32), {args.conformers} conformers each, {100 * wl_active:.0f} % drawn on the model's nodes; top-{args.topk}",
                 "pockets": len(pockets),
                 "ligands_per_gpu": n_lig,
                 "conformers_per_ligand": args.conformers,
                 "parallelism": f"ligand-sharded x{world}" if world > 1 else "single GPU",
+                "exchange": None if world == 1 else ({"collective": "ncclAllGather of per-rank top-k (pmx_topk_allgather, merge on the device)", "rccl_ranks": exchange.world}
+                                                     if exchange is not None else {"collective": f"{backend} all_gather of per-rank top-k (rehearsal backend, merge on the host)", "ranks": world}),
             },
             "roofline": {
                 "bound": "hbm",
@@ -317,26 +438,23 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "traffic_from_profile": f"profiles/{PROFILE_TAG}_hbm_traffic.json",
-                "traffic_note": "NOT measured in this run: HBM bytes per ligand of that kernel from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same build (separate runs, read side doubled per MI355X_MICROARCH.md), scaled to this launch's ligands; null if unavailable",
+                "traffic_from_profile": traffic_src,
+                "traffic_note": "NOT measured in this run: HBM bytes per ligand of that kernel from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same build of csrc/ (content hash checked; separate runs, read side doubled per MI355X_MICROARCH.md), scaled to this launch's ligands; null if no summary of this build and workload is committed",
                 "algorithmic_bytes_per_ligand": alg_bytes_per_ligand,
                 "ligands_per_launch": ligands_per_launch,
                 "kernel_ms_per_launch": kernels,
                 "profiled_pass_ms": prof["ms_total"],
                 "note": "HIP-event times of one extra, untimed pass with pmx_set_profiling(1) (event records on the call's stream, no synchronisation); "
                         "the timed steps run with profiling off. The path is not HBM-bound (SURVEY.md section 0, DESIGN.md section 4): what binds is "
-                        "the CU's scalar instruction issue, see `issue` (DESIGN.md section 4).",
+                        "instruction issue and memory latency, see `issue` (DESIGN.md section 4).",
             },
             # The resource that is busiest on this path: the CU's scalar unit, one wave-instruction per cycle.
-            # Instruction counts per ligand from the committed PMC pass (profiles/<tag>_pmc_sq_summary.json: 200 704 ligands, the
-            # timed step + the profiled pass = 2 passes), priced at this run's time per pass.
-            "issue": issue_block(n_lig, prof["ms_total"]) if (args.conformers == 8 and len(pockets) == 1) else None,
-            # what the kernels do per ligand, and how that compares with the CU's issue rate (one VALU and one SALU wave-instruction
-            # per cycle and CU: MI355X_MICROARCH.md); instruction counts from the committed PMC pass
+            "issue": issue_block(n_lig, prof["ms_total"]) if bench_shape else None,
+            # what the kernels do per ligand
             "work": {
                 "tree_frames_per_ligand": prof["n_frames"] / max(n_lig, 1),
                 "walker_passes_per_ligand": prof["n_passes"] / max(n_lig, 1),
-                "table_items_per_ligand_conformer": prof["n_items"] * (64 // 8 if args.conformers == 8 else 1) / max(n_lig, 1),
+                "table_items_per_ligand_conformer": prof["n_items"] * (64 // max(1, 1 << (args.conformers - 1).bit_length())) / max(n_lig, 1),  # (wave-iterations x slots of a wavefront)
                 "queued_subtrees_per_ligand": prof["n_tasks"] / max(n_lig, 1),
                 "path_bound_tests_per_ligand": prof["n_path_bounds"] / max(n_lig, 1),
                 "children_dropped_by_path_bound_per_ligand": prof["n_path_drops"] / max(n_lig, 1),
@@ -346,9 +464,15 @@ def main():
                 "longest_walk_passes": prof["max_passes"],
                 "wave_time_share": {k: prof["ticks_" + k] / max(prof["ticks_alive"], 1) for k in ("scan", "tables", "bounds", "walk")},
             },
+            "csrc_sha16": csrc_digest(),
         }
+        if not args.no_parity_sample:
+            try:
+                out["parity_sample"] = parity_sample(pockets[-1], res.scores, offsets, data)
+            except Exception as e:  # never lose the bench line over the check - but say so
+                out["parity_sample"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"], work = cpu_baseline(model, offsets, data, args.conformers)
+            out["cpu_baseline"], work = cpu_baseline(pockets, offsets, data, args.conformers)
             # Gaussian terms as the reference evaluates them (counted by the oracle on the same ligands) per second: the
             # table phase replaces each group of |A||B| terms by one tabulated pair function, so this is an equivalent rate
             terms_per_conf = work["gaussian_terms_per_ligand_conformer"]

@@ -571,6 +571,7 @@ struct ChunkSet {
     size_t lists_bytes = 0;
     hipEvent_t lig_done = nullptr, tasks_done = nullptr;
     bool pending = false; // tasks_done was recorded by the call in progress
+    size_t arena_shrunk_to = 0; // the arena size that was accepted when memory was short (0: never shrunk)
 };
 struct ScreenWs {
     ChunkSet set[2];
@@ -706,16 +707,24 @@ template <int G>
 static int score_screen(const pmx_model *const *models, int n_models, const pmx_library *lib, const Weights &W, uint64_t first, uint64_t count,
                         float *scores_dev, int32_t *status_dev, hipStream_t stream, ScreenWs &ws) {
     if (count > 0xfffffff0ull) return fail(PMX_ERR_INVALID, "more than 2^32 ligands in one call");
-    if (!ws.num_cu) {
-        hipDeviceProp_t prop;
-        HIPCHECK(hipGetDeviceProperties(&prop, lib->device));
-        ws.num_cu = prop.multiProcessorCount;
-        for (auto &e : ws.ev) HIPCHECK(hipEventCreate(&e));
-        HIPCHECK(hipStreamCreateWithFlags(&ws.side, hipStreamNonBlocking));
-        for (ChunkSet &c : ws.set) {
-            HIPCHECK(hipMalloc((void **)&c.ctl, sizeof(Ctl)));
-            HIPCHECK(hipEventCreateWithFlags(&c.lig_done, hipEventDisableTiming));
-            HIPCHECK(hipEventCreateWithFlags(&c.tasks_done, hipEventDisableTiming));
+    if (!ws.num_cu) { // (num_cu is set last: a workspace whose events, stream or control blocks could not be made stays uninitialised)
+        auto init = [&]() -> int {
+            hipDeviceProp_t prop;
+            HIPCHECK(hipGetDeviceProperties(&prop, lib->device));
+            for (auto &e : ws.ev) HIPCHECK(hipEventCreate(&e));
+            HIPCHECK(hipStreamCreateWithFlags(&ws.side, hipStreamNonBlocking));
+            for (ChunkSet &c : ws.set) {
+                HIPCHECK(hipMalloc((void **)&c.ctl, sizeof(Ctl)));
+                HIPCHECK(hipEventCreateWithFlags(&c.lig_done, hipEventDisableTiming));
+                HIPCHECK(hipEventCreateWithFlags(&c.tasks_done, hipEventDisableTiming));
+            }
+            ws.num_cu = prop.multiProcessorCount;
+            return PMX_OK;
+        };
+        const int irc = init();
+        if (irc) {
+            ws.free_buffers();
+            return irc;
         }
     }
     const uint32_t flags = (uint32_t)env_long("PMX_TREE_FLAGS", 0);
@@ -724,6 +733,10 @@ static int score_screen(const pmx_model *const *models, int n_models, const pmx_
     const uint32_t task_budget = (uint32_t)std::max<long>(16, env_long("PMX_TASK_BUDGET", lig_budget)); // a queued subtree's own budget
     const int rounds = (int)std::max<long>(1, env_long("PMX_ROUNDS", 12));
     const bool exact = (flags & 8) != 0;
+    // arena passes over the ligands an arena pass had no room for, each with the arena to itself (a pass with an empty list exits at
+    // once): a ligand is reported PMX_LIGAND_TOO_LARGE when its tables exceed the whole arena - or when the arena-class ligands of a
+    // chunk need more than 1 + PMX_ARENA_RETRIES arenas
+    const int arena_retries = (int)std::max<long>(1, env_long("PMX_ARENA_RETRIES", 4));
 
     // ---- per pocket: parameters and launch shapes
     std::vector<PocketPlan> plan((size_t)n_models);
@@ -801,19 +814,6 @@ static int score_screen(const pmx_model *const *models, int n_models, const pmx_
         rc = grow(&ws.pabuf, &ws.pabuf_bytes, pabuf_need, stream, ws.side);
         if (rc) return rc;
     }
-    for (ChunkSet &c : ws.set) {
-        // (PMX_ARENA_MB / PMX_TASKQ_MB are per set; a smaller arena than asked for is slower - more trees walked by one
-        // wavefront alone - never wrong, so it shrinks when memory is short: several streams each keep a workspace)
-        // (32 / 64 conformer lanes: records of megabytes - 16 GB held the split trees of a 16 384-ligand chunk of the stress configuration
-        // to within 3 %, and every tree past the end is walked by one wavefront alone)
-        const size_t arena_want = (size_t)std::max<long>(1, env_long("PMX_ARENA_MB", G >= 32 ? 32768 : 16384)) << 20;
-        rc = grow(&c.arena, &c.arena_bytes, arena_want, stream, ws.side, std::min<size_t>((size_t)1 << 30, arena_want));
-        if (rc) return rc;
-        rc = grow(&c.queue, &c.queue_bytes, (size_t)std::max<long>(1, env_long("PMX_TASKQ_MB", 1024L * std::max(1, G / 8))) << 20, stream, ws.side);
-        if (rc) return rc;
-        rc = grow(&c.lists, &c.lists_bytes, (size_t)super_max * 12, stream, ws.side);
-        if (rc) return rc;
-    }
     uint64_t n_chunks = 0;
     for (const PocketPlan &pl : plan) n_chunks += (count + pl.super - 1) / pl.super;
     // The rounds go to the side stream when there is something to run them next to. (Not when an arena pass may have to be
@@ -830,6 +830,28 @@ static int score_screen(const pmx_model *const *models, int n_models, const pmx_
     const bool overlap = n_chunks >= 2 && !retry_possible && overlap_mode != 0 && (overlap_mode >= 2 || super_min >= (1u << 19));
     const bool overlap_pockets = overlap_mode >= 2;
     hipStream_t side = overlap ? ws.side : stream;
+    // Arena, task queue and lists: one set - a second one only where the rounds of a chunk run beside the next chunk's ligand kernel
+    // (PMX_OVERLAP, off by default): in order on one stream a chunk is through with them when the next one starts.
+    for (int ci = 0; ci < (overlap ? 2 : 1); ++ci) {
+        ChunkSet &c = ws.set[ci];
+        // (PMX_ARENA_MB / PMX_TASKQ_MB are per set; a smaller arena than asked for is slower - more trees walked by one
+        // wavefront alone - never wrong, so it shrinks when memory is short: several streams each keep a workspace. A size that was
+        // accepted after shrinking stands until the workspace is released: asking for the full size again on every call would
+        // synchronise, free and fail again each time)
+        // (32 / 64 conformer lanes: records of megabytes - 16 GB held the split trees of a 16 384-ligand chunk of the stress configuration
+        // to within 3 %, and every tree past the end is walked by one wavefront alone)
+        size_t arena_want = (size_t)std::max<long>(1, env_long("PMX_ARENA_MB", G >= 32 ? 32768 : 16384)) << 20;
+        const size_t arena_min = std::min<size_t>((size_t)1 << 30, arena_want);
+        if (c.arena_shrunk_to) arena_want = std::min(arena_want, std::max(c.arena_shrunk_to, arena_min));
+        const size_t asked = arena_want;
+        int rc2 = grow(&c.arena, &c.arena_bytes, arena_want, stream, ws.side, arena_min);
+        if (rc2) return rc2;
+        if (c.arena_bytes < asked) c.arena_shrunk_to = c.arena_bytes;
+        rc2 = grow(&c.queue, &c.queue_bytes, (size_t)std::max<long>(1, env_long("PMX_TASKQ_MB", 1024L * std::max(1, G / 8))) << 20, stream, ws.side);
+        if (rc2) return rc2;
+        rc2 = grow(&c.lists, &c.lists_bytes, (size_t)super_max * 12, stream, ws.side);
+        if (rc2) return rc2;
+    }
     const double lig_share = std::min(0.9, std::max(0.1, std::atof(std::getenv("PMX_LIG_SHARE") ? std::getenv("PMX_LIG_SHARE") : "0.5")));
 
     if (g_profiling) HIPCHECK(hipEventRecord(ws.ev[0], stream));
@@ -846,8 +868,8 @@ static int score_screen(const pmx_model *const *models, int n_models, const pmx_
             const bool last_of_call = seq + 1 == n_chunks;
             // a chunk that has the device to itself: the call's first / last, or (by default) a pocket's first / last
             const bool first_chunk = seq == 0 || (!overlap_pockets && lo == 0), last_chunk = last_of_call || (!overlap_pockets && lo + super >= count);
-            ChunkSet &c = ws.set[seq & 1];
-            const int ci = (int)(seq & 1);
+            const int ci = overlap ? (int)(seq & 1) : 0;
+            ChunkSet &c = ws.set[ci];
             p.lo = (uint32_t)lo;
             p.hi = (uint32_t)std::min<uint64_t>(count, lo + super);
             p.ctl = c.ctl;
@@ -916,13 +938,13 @@ static int score_screen(const pmx_model *const *models, int n_models, const pmx_
             };
             rounds_and_finalize();
             // Ligands the arena pass had no room for, with the arena to themselves (only models and libraries whose largest tables
-            // exceed a large slice ever get here; `side` is the caller's stream then): twice, the second time reporting what
+            // exceed a large slice ever get here; `side` is the caller's stream then): PMX_ARENA_RETRIES times, the last time reporting what
             // still does not fit.
             if (pl.worst_bytes > pl.big_bytes) {
-                for (int t = 0; t < 2; ++t) {
+                for (int t = 0; t < arena_retries; ++t) {
                     retry_prep_kernel<<<dim3(1), dim3(64), 0, side>>>(c.ctl, (uint32_t)(t + 1) & 1u);
-                    p.retry_in = t == 0 ? c.lists : c.lists + super;
-                    p.retry_out = t == 0 ? c.lists + super : nullptr;
+                    p.retry_in = (t & 1) == 0 ? c.lists : c.lists + super;
+                    p.retry_out = t + 1 == arena_retries ? nullptr : ((t & 1) == 0 ? c.lists + super : c.lists);
                     p.retry_slot = (uint32_t)(t + 1) & 1u;
                     p.totbuf = ws.totbuf;
                     p.pabuf = ws.pabuf;

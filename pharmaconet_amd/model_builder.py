@@ -111,6 +111,11 @@ def voxel_components_device(masks: Sequence[np.ndarray], device: int = 0) -> lis
     size = int(masks[0].shape[0])
     stack = np.ascontiguousarray(np.stack([np.asarray(m, dtype=np.float32) for m in masks]))
     assert stack.shape[1:] == (size, size, size)
+    # the device sees float32 maps, the voxel set below the maps as given (density_map.py:91): a float64 value that underflows in
+    # float32 would be active here and not there
+    for m, f32 in zip(masks, stack):
+        if np.asarray(m).dtype != np.float32 and np.any((np.asarray(m) > 0.0) != (f32 > 0.0)):
+            raise RuntimeError("voxel_components_device: a map's active voxels change when cast to float32; use the host search (device=None)")
     handle = ctypes.c_void_p()
     _ffi.check(lib.pmx_density_create(stack.ctypes.data, len(masks), size, int(device), ctypes.byref(handle)))
     try:

@@ -205,7 +205,9 @@ class PharmacophoreModel:
         the host; the state is the reference's either way."""
         from .model_builder import build_model_state
 
-        if device == "auto":
+        model = cls()
+        auto = device == "auto"
+        if auto:
             device = None
             try:
                 import torch
@@ -214,8 +216,15 @@ class PharmacophoreModel:
                     device = torch.cuda.current_device()
             except Exception:
                 device = None
-        model = cls()
-        model.__setstate__(build_model_state(pdbblock, center, hotspot_infos, resolution, size, device=device))
+        try:
+            state = build_model_state(pdbblock, center, hotspot_infos, resolution, size, device=device)
+        except (RuntimeError, OSError):  # (_ffi.PmxError is a RuntimeError)
+            # "auto" promises a model, not a GPU: libpmx.so missing or unloadable, or maps the device search cannot take
+            # (model_builder.voxel_components_device) - the host search gives the same state
+            if not auto or device is None:
+                raise
+            state = build_model_state(pdbblock, center, hotspot_infos, resolution, size, device=None)
+        model.__setstate__(state)
         return model
 
     # ------------------------------------------------------------ accessors

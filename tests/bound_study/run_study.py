@@ -6,7 +6,7 @@ from conftest import GOLDEN
 from oracle import oracle
 from pharmaconet_amd import PharmacophoreModel
 from pharmaconet_amd.constants import weights_vector, TYPE_ID
-from pharmaconet_amd.synthetic import synthetic_library, BASE_SEED
+from tools.synthetic import synthetic_library, BASE_SEED
 here = os.path.dirname(os.path.abspath(__file__))
 so = "/tmp/libbound_study.so"
 os.system(f"gcc -O2 -fopenmp -shared -fPIC {here}/bound_study.c -o {so} -lm")

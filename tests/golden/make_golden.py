@@ -12,7 +12,7 @@ What it does (procedure of SURVEY.md Appendix B):
   * builds synthetic pharmacophore models through the real `PharmacophoreModel.create`
     (`pharmacophore_model.py:108-149` -> `utils/density_map.py`) and saves them with the real
     `save()` as `.pm` / `.json`;
-  * draws synthetic feature molecules (`pharmaconet_amd.synthetic`), wraps each in a fake ligand
+  * draws synthetic feature molecules (`tools.synthetic`), wraps each in a fake ligand
     object, builds the real `LigandGraph` (`scoring/ligand.py:110-259`) and scores it with the real
     `GraphMatcher(...).run()` (`scoring/graph_match.py:94-101`);
   * writes, per ligand set: the packed library extracted from the real `LigandGraph`
@@ -51,7 +51,7 @@ from pmnet.scoring.ligand_utils import PharmacophoreNode  # noqa: E402
 
 from pharmaconet_amd.constants import TYPE_ID  # noqa: E402
 from pharmaconet_amd.library import ClusteredLigand, LigandFeatures, PackedLibrary, pack_clustered_ligand  # noqa: E402
-from pharmaconet_amd.synthetic import ligand_rng, random_molecule  # noqa: E402
+from tools.synthetic import ligand_rng, random_molecule  # noqa: E402
 
 assert ref_gm.scoring_matching_pair.__module__ == "pmnet.scoring.match_utils", "expected the NumPy kernels"
 

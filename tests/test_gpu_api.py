@@ -115,7 +115,7 @@ def test_order_and_partition_invariance_large():
 
     from pharmaconet_amd.constants import TYPE_ID
     from pharmaconet_amd.engine import DeviceLibrary
-    from pharmaconet_amd.synthetic import expand_library_on_device, synthetic_library
+    from tools.synthetic import expand_library_on_device, synthetic_library
 
     model, _, _, _ = load_golden("set_6oim_c8")
     st = model.__getstate__()
@@ -196,7 +196,7 @@ def test_scores_do_not_depend_on_how_the_work_is_cut(monkeypatch):
     from pharmaconet_amd import engine
     from pharmaconet_amd.constants import TYPE_ID
     from pharmaconet_amd.engine import DeviceLibrary
-    from pharmaconet_amd.synthetic import expand_library_on_device, synthetic_library
+    from tools.synthetic import expand_library_on_device, synthetic_library
 
     model, _, _, _ = load_golden("set_6oim_c8")
     st = model.__getstate__()
@@ -326,7 +326,7 @@ def test_full_task_queue_changes_nothing_but_time(monkeypatch):
     from pharmaconet_amd import engine
     from pharmaconet_amd.constants import TYPE_ID
     from pharmaconet_amd.engine import DeviceLibrary
-    from pharmaconet_amd.synthetic import expand_library_on_device, synthetic_library
+    from tools.synthetic import expand_library_on_device, synthetic_library
 
     model, _, _, _ = load_golden("set_6oim_c8")
     st = model.__getstate__()

@@ -39,7 +39,7 @@ def test_matches_reference_golden(name):
 def test_matches_oracle_on_fresh_ligands(name, oracle):
     """Seeded ligands that are not in the fixtures, engine vs CPU oracle."""
     from pharmaconet_amd.constants import TYPE_ID, weights_vector
-    from pharmaconet_amd.synthetic import synthetic_library
+    from tools.synthetic import synthetic_library
 
     model, _, _, _ = load_golden(name)
     st = model.__getstate__()
@@ -59,7 +59,7 @@ def test_matches_oracle_on_fresh_ligands(name, oracle):
 def test_other_conformer_counts_match_oracle(num_conf, oracle):
     """Conformer-group widths 2, 4, 16, 32, 64 (the fixtures cover 1, 8 and 64 lanes per ligand)."""
     from pharmaconet_amd.constants import TYPE_ID, weights_vector
-    from pharmaconet_amd.synthetic import synthetic_library
+    from tools.synthetic import synthetic_library
 
     model, _, _, _ = load_golden("set_6oim_c8")
     st = model.__getstate__()
@@ -78,7 +78,7 @@ def test_mixed_conformer_counts_in_one_library(oracle):
     """Ligands of one library may have different conformer counts (one SDF record per conformer, ligand.py:63-84)."""
     from pharmaconet_amd import PackedLibrary
     from pharmaconet_amd.constants import TYPE_ID, weights_vector
-    from pharmaconet_amd.synthetic import synthetic_library
+    from tools.synthetic import synthetic_library
 
     model, _, _, _ = load_golden("set_c21_c8")
     st = model.__getstate__()
@@ -138,7 +138,7 @@ def test_bench_size_library_properties_and_oracle_sample(oracle, monkeypatch):
     from pharmaconet_amd import PackedLibrary
     from pharmaconet_amd.constants import TYPE_ID, weights_vector
     from pharmaconet_amd.engine import DeviceLibrary
-    from pharmaconet_amd.synthetic import BASE_SEED, expand_library_on_device, synthetic_library
+    from tools.synthetic import BASE_SEED, expand_library_on_device, synthetic_library
 
     model, _, _, _ = load_golden("set_6oim_c8")
     st = model.__getstate__()
@@ -188,7 +188,7 @@ def test_config2_shard_size_properties(oracle):
     from pharmaconet_amd import PackedLibrary
     from pharmaconet_amd.constants import TYPE_ID, weights_vector
     from pharmaconet_amd.engine import DeviceLibrary
-    from pharmaconet_amd.synthetic import BASE_SEED, expand_library_on_device, synthetic_library
+    from tools.synthetic import BASE_SEED, expand_library_on_device, synthetic_library
 
     model, _, _, _ = load_golden("set_6oim_c8")
     st = model.__getstate__()

@@ -35,7 +35,7 @@ def test_within_1e5_of_both_reference_variants(oracle):
     """north_star: scores within 1e-5 relative of the reference's CPU path - NumPy kernels (pinned) and Numba kernels
     (restated, match_utils_numba.py:54-86). Flips (a ligand beyond 1e-6 of either) are counted and must be absent."""
     from pharmaconet_amd.constants import weights_vector
-    from pharmaconet_amd.synthetic import synthetic_library
+    from tools.synthetic import synthetic_library
 
     model, _, _, _ = load_golden("set_6oim_c8")
     lib = synthetic_library(600, num_conformers=8, model_nodes=_model_nodes(model), active_fraction=0.3, seed=90210)
@@ -56,7 +56,7 @@ def test_zero_type_weight_matches_oracle(oracle):
     """`--hydrophobic 0` (screening.py:33): node pairs whose weights sum to 0 give 0 * (1 / 0) = NaN in the reference
     (match_utils.py:50-52,69), which invalidates the pair entry / poisons the self entry. GPU == oracle."""
     from pharmaconet_amd.constants import weights_vector
-    from pharmaconet_amd.synthetic import synthetic_library
+    from tools.synthetic import synthetic_library
 
     model, _, _, _ = load_golden("set_6oim_c8")
     lib = synthetic_library(300, num_conformers=8, model_nodes=_model_nodes(model), active_fraction=0.4, seed=31337)
@@ -101,7 +101,7 @@ def test_every_lane_shape_matches_the_oracle(conformers, oracle, monkeypatch):
     the path-aware tests (path_bound() up to 16 lanes, path_bound_wide() at 32 / 64) and the task rounds to matter - against the
     oracle, default and with the trees split almost at once."""
     from pharmaconet_amd.constants import weights_vector
-    from pharmaconet_amd.synthetic import synthetic_library
+    from tools.synthetic import synthetic_library
 
     for name, n in (("set_6oim_c8", 160), ("set_s64_c8", 48)):
         model, _, _, _ = load_golden(name)
@@ -154,7 +154,7 @@ def test_models_beyond_64_nodes_and_clusters(oracle):
 
     from pharmaconet_amd import PharmacophoreModel
     from pharmaconet_amd.constants import weights_vector
-    from pharmaconet_amd.synthetic import synthetic_library
+    from tools.synthetic import synthetic_library
 
     model = PharmacophoreModel.load(GOLDEN / "model_large110.pm")
     assert model.flat.num_nodes > 64 and model.flat.num_clusters > 64 and model.flat.cluster_nodes.shape[1] == 2
@@ -218,7 +218,7 @@ def test_small_arena_changes_nothing_but_time(monkeypatch):
 
     from pharmaconet_amd import engine
     from pharmaconet_amd.engine import DeviceLibrary
-    from pharmaconet_amd.synthetic import expand_library_on_device, synthetic_library
+    from tools.synthetic import expand_library_on_device, synthetic_library
 
     model, _, _, _ = load_golden("set_6oim_c8")
     base = synthetic_library(256, num_conformers=8, model_nodes=_model_nodes(model), conformer_noise=0.0, seed=777)
@@ -318,7 +318,7 @@ def test_dead_entry_test_changes_no_score(monkeypatch):
 
     from pharmaconet_amd import PharmacophoreModel, engine
     from pharmaconet_amd.engine import DeviceLibrary
-    from pharmaconet_amd.synthetic import synthetic_library
+    from tools.synthetic import synthetic_library
 
     model8, _, _, _ = load_golden("set_6oim_c8")
     lib8 = DeviceLibrary(synthetic_library(3000, num_conformers=8, model_nodes=_model_nodes(model8), active_fraction=0.3, seed=777))
@@ -352,7 +352,7 @@ def test_sixteen_pockets_at_shard_size(oracle):
     from pharmaconet_amd import PackedLibrary, PharmacophoreModel, _ffi
     from pharmaconet_amd.constants import weights_vector
     from pharmaconet_amd.engine import DeviceLibrary, device_model
-    from pharmaconet_amd.synthetic import BASE_SEED, expand_library_on_device, synthetic_library
+    from tools.synthetic import BASE_SEED, expand_library_on_device, synthetic_library
 
     model6, _, _, _ = load_golden("set_6oim_c8")
     base = synthetic_library(4096, num_conformers=8, model_nodes=_model_nodes(model6), active_fraction=0.1, seed=BASE_SEED, max_nodes=32,
@@ -402,7 +402,7 @@ def test_stress_config_at_full_size(oracle, monkeypatch):
     from pharmaconet_amd import PackedLibrary
     from pharmaconet_amd.constants import weights_vector
     from pharmaconet_amd.engine import DeviceLibrary
-    from pharmaconet_amd.synthetic import expand_library_on_device, synthetic_library
+    from tools.synthetic import expand_library_on_device, synthetic_library
 
     model, _, _, _ = load_golden("set_s64_c64")
     assert model.flat.num_nodes == 64

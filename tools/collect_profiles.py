@@ -18,7 +18,7 @@ import os
 
 REPO = Path(__file__).resolve().parents[1]
 PROF = REPO / "profiles"
-TAG = os.environ.get("PMX_PROFILE_TAG", "r4")  # file name prefix: the round the profiles belong to
+TAG = os.environ.get("PMX_PROFILE_TAG", "r5")  # file name prefix: the round the profiles belong to
 
 
 def short(name):
@@ -28,6 +28,16 @@ def short(name):
 def main():
     bench, kstats, fetch_dir, write_dir, sq_dir = (Path(a) for a in sys.argv[1:6])
     n_lig = int(sys.argv[6]) if len(sys.argv) > 6 else 200704
+    # the build the counters belong to: tools/profile_round.sh leaves bench.csrc_digest() of the tree it ran on next to them; bench.py quotes
+    # the summaries only while csrc/ still hashes to it
+    sha_file = bench.parent / "csrc_sha16.txt"
+    if sha_file.exists():
+        sha = sha_file.read_text().strip()
+    else:
+        sys.path.insert(0, str(REPO))
+        import bench as bench_module
+
+        sha = bench_module.csrc_digest()
     PROF.mkdir(exist_ok=True)
     shutil.copy(bench, PROF / f"{TAG}_bench_1M.json")
     # kernel stats: keep pmx kernels and the five largest others
@@ -55,6 +65,7 @@ def main():
                 "uncalibrated, so the read figure is an upper estimate). The counters see L2 <-> fabric traffic, i.e. they "
                 "include what the 256 MB Infinity Cache serves (the per-wavefront table slices).",
         "ligands": n_lig,
+        "csrc_sha16": sha,
         "kernels": {},
     }
     # passes of the engine in the profiled command: bench.py makes its timed steps and one more pass for the kernel times (3 ligand-kernel
@@ -80,7 +91,7 @@ def main():
             sq[short(k).replace("pmx::", "")][row["Counter_Name"]] += float(row["Counter_Value"])
     json.dump({"source": "rocprofv3 --pmc SQ_* (one profiler run) of bench.py --ligands 200000 --steps 1 --warmup 0; SQ_WAVE_CYCLES, "
                          "SQ_WAIT_* and SQ_ACTIVE_* count quad-cycles; totals over the run's engine passes (SQ_WAVES / 18432 = passes)",
-               "ligands": n_lig, "passes": n_pass, "counters": sq},
+               "ligands": n_lig, "passes": n_pass, "csrc_sha16": sha, "counters": sq},
               open(PROF / f"{TAG}_pmc_sq_summary.json", "w"), indent=1)
     for k, v in out["kernels"].items():
         print(f"{k:40s} fetch {v['fetch_kib_raw'] / 1e6:8.3f} GiB  write {v['write_kib'] / 1e6:8.3f} GiB  {v['hbm_bytes_per_ligand']:10.0f} B/ligand")

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 from conftest import GOLDEN
 from pharmaconet_amd import PharmacophoreModel, _ffi
 from pharmaconet_amd.constants import TYPE_ID
-from pharmaconet_amd.synthetic import synthetic_library, BASE_SEED
+from tools.synthetic import synthetic_library, BASE_SEED
 from pharmaconet_amd.library import flatten_features
 model = PharmacophoreModel.load(GOLDEN / "model_6oim_like.pm")
 st = model.__getstate__()

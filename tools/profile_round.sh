@@ -1,22 +1,24 @@
 #!/bin/bash
-# Run on the GPU box (through gpurun): the bench line, kernel stats, the PMC passes (separate runs, --pmc only) of the
+# Run on the GPU box (through gpurun): the bench lines, kernel stats, the PMC passes (separate runs, --pmc only) of the
 # round's build; tools/collect_profiles.py then turns them into the tracked summaries under profiles/.
 #   gpurun -- 'bash tools/profile_round.sh'
 # then, in the repository (gpurun merges gpurun_out/ back, not profiles/):
-#   O=gpurun_out/prof_r4; PMX_PROFILE_TAG=r4 python tools/collect_profiles.py $O/bench.json $O/stats/*kernel_stats.csv $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_SQ 200704
+#   O=gpurun_out/prof_r5; PMX_PROFILE_TAG=r5 python tools/collect_profiles.py $O/bench.json $O/stats/*kernel_stats.csv $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_SQ 200704
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-OUT=$ROOT/gpurun_out/prof_r4
+OUT=$ROOT/gpurun_out/prof_r5
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+python -c "import sys; sys.path.insert(0, '$ROOT'); import bench; print(bench.csrc_digest())" > $OUT/csrc_sha16.txt
 python $ROOT/bench.py --steps 5 --warmup 2 > $OUT/bench.json 2> $OUT/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-serial-leg > $OUT/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-serial-leg --no-parity-sample > $OUT/stats.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -o p -- python $ROOT/bench.py --ligands 200000 --steps 1 --warmup 0 --no-cpu-baseline --no-serial-leg > $OUT/pmc_$c.log 2>&1
+  rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -o p -- python $ROOT/bench.py --ligands 200000 --steps 1 --warmup 0 --no-cpu-baseline --no-serial-leg --no-parity-sample > $OUT/pmc_$c.log 2>&1
 done
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES --output-format csv -d $OUT/pmc_SQ -o p -- python $ROOT/bench.py --ligands 200000 --steps 1 --warmup 0 --no-cpu-baseline --no-serial-leg > $OUT/pmc_SQ.log 2>&1
-python $ROOT/bench.py --pockets 16 --ligands 200000 --steps 1 --warmup 1 --no-cpu-baseline --no-serial-leg > $OUT/bench_pockets16.json 2> $OUT/bench_pockets16.err
-python $ROOT/tools/stress_shape.py 196 > $OUT/stress64.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES --output-format csv -d $OUT/pmc_SQ -o p -- python $ROOT/bench.py --ligands 200000 --steps 1 --warmup 0 --no-cpu-baseline --no-serial-leg --no-parity-sample > $OUT/pmc_SQ.log 2>&1
+# BASELINE configs[3] (16 pockets, per-GPU shard) and configs[4] (stress model, 64 conformers): the driver-reproducible lines
+python $ROOT/bench.py --model stress64 --steps 3 --warmup 1 > $OUT/bench_stress64.json 2> $OUT/bench_stress64.err
+python $ROOT/bench.py --pockets 16 --ligands 200000 --steps 1 --warmup 1 --no-serial-leg > $OUT/bench_pockets16.json 2> $OUT/bench_pockets16.err
 ls -R $OUT | head -40
 python $ROOT/bench.py --ligands 12500000 --steps 2 --warmup 1 --no-cpu-baseline --no-serial-leg > $OUT/bench_shard12M.json 2> $OUT/bench_shard12M.err
-python $ROOT/bench.py --pockets 16 --ligands 1253376 --steps 1 --warmup 1 --no-cpu-baseline --no-serial-leg > $OUT/bench_pockets16_shard.json 2> $OUT/bench_pockets16_shard.err
+python $ROOT/bench.py --pockets 16 --ligands 1253376 --steps 1 --warmup 1 --no-serial-leg > $OUT/bench_pockets16_shard.json 2> $OUT/bench_pockets16_shard.err

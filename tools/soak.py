@@ -8,7 +8,7 @@ sys.path.insert(0, "tests")
 from conftest import load_golden  # noqa: E402
 from pharmaconet_amd.constants import TYPE_ID  # noqa: E402
 from pharmaconet_amd.engine import DeviceLibrary  # noqa: E402
-from pharmaconet_amd.synthetic import BASE_SEED, expand_library_on_device, synthetic_library  # noqa: E402
+from tools.synthetic import BASE_SEED, expand_library_on_device, synthetic_library  # noqa: E402
 
 model, _, _, _ = load_golden("set_6oim_c8")
 st = model.__getstate__()

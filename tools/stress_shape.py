@@ -6,7 +6,7 @@ from conftest import load_golden
 from pharmaconet_amd import engine
 from pharmaconet_amd.constants import TYPE_ID
 from pharmaconet_amd.engine import DeviceLibrary
-from pharmaconet_amd.synthetic import expand_library_on_device, synthetic_library
+from tools.synthetic import expand_library_on_device, synthetic_library
 model, _, _, _ = load_golden("set_s64_c64")
 st = model.__getstate__()
 centers = np.array([n["center"] for n in st["nodes"]], dtype=np.float64)

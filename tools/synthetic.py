@@ -18,8 +18,8 @@ import math
 
 import numpy as np
 
-from .constants import TYPE_ID
-from .library import LigandFeatures, PackedLibrary, pack_ligand
+from pharmaconet_amd.constants import TYPE_ID
+from pharmaconet_amd.library import LigandFeatures, PackedLibrary, pack_ligand
 
 __all__ = ["random_molecule", "synthetic_library", "ligand_rng"]
 
