@@ -732,7 +732,26 @@ static int score_screen(const pmx_model *const *models, int n_models, const pmx_
     const uint32_t lig_budget = (uint32_t)std::max<long>(16, env_long("PMX_BUDGET", 384));
     const uint32_t task_budget = (uint32_t)std::max<long>(16, env_long("PMX_TASK_BUDGET", lig_budget)); // a queued subtree's own budget
     const int rounds = (int)std::max<long>(1, env_long("PMX_ROUNDS", 12));
+    const int task_decay_from = (int)std::max<long>(1, env_long("PMX_TASK_DECAY_FROM", 99));
+    const uint32_t task_budget_min = (uint32_t)std::max<long>(8, env_long("PMX_TASK_BUDGET_MIN", 48));
     const bool exact = (flags & 8) != 0;
+    // Type weights further apart than PMX_TAILS_RATIO (default 16; the reference's defaults are 8 : 1, graph_match.py:32-40): pair items
+    // evaluate rough cells term by term like self items do (item_finish<TAILS>, pmx_screen.hip) - slower, and only then.
+    // PMX_PAIR_TAILS = 0 / 1 forces it off / on.
+    bool tails = false;
+    {
+        float wmin = INFINITY, wmax = 0.f;
+        for (int t = 0; t < PMX_NUM_TYPES; ++t) {
+            const float a = std::fabs(W.w[t]);
+            if (a > 0.f && std::isfinite(a)) wmin = std::min(wmin, a), wmax = std::max(wmax, a);
+        }
+        const char *rs = std::getenv("PMX_TAILS_RATIO");
+        const double ratio = (rs && *rs) ? std::atof(rs) : 16.0;
+        tails = wmax > 0.f && (double)wmax > ratio * (double)wmin;
+        const long force = env_long("PMX_PAIR_TAILS", -1);
+        if (force == 0) tails = false;
+        if (force > 0) tails = true;
+    }
     // arena passes over the ligands an arena pass had no room for, each with the arena to itself (a pass with an empty list exits at
     // once): a ligand is reported PMX_LIGAND_TOO_LARGE when its tables exceed the whole arena - or when the arena-class ligands of a
     // chunk need more than 1 + PMX_ARENA_RETRIES arenas
@@ -897,8 +916,9 @@ static int score_screen(const pmx_model *const *models, int n_models, const pmx_
             const uint32_t task_grid = (uint32_t)ws.num_cu * std::min<uint32_t>(4u * PMX_TASK_WAVES, (overlap && !last_chunk) ? full - lig_waves : full);
             auto launch = [&](int mode, uint32_t blocks, hipStream_t on) {
                 p.mode = mode;
-                if (exact) ligand_kernel<G, true><<<dim3(blocks), dim3(64), pl.lds, on>>>(p);
-                else ligand_kernel<G, false><<<dim3(blocks), dim3(64), pl.lds, on>>>(p);
+                if (exact) ligand_kernel<G, true, false><<<dim3(blocks), dim3(64), pl.lds, on>>>(p);
+                else if (tails) ligand_kernel<G, false, true><<<dim3(blocks), dim3(64), pl.lds, on>>>(p);
+                else ligand_kernel<G, false, false><<<dim3(blocks), dim3(64), pl.lds, on>>>(p);
             };
             p.last_round = 0;
             p.budget = lig_budget;
@@ -926,8 +946,10 @@ static int score_screen(const pmx_model *const *models, int n_models, const pmx_
             if (!totals_in_lds<G>()) p.totbuf = ws.totbuf + ws.totbuf_bytes / 2;
             if (ws.pabuf) p.pabuf = ws.pabuf + ws.pabuf_bytes / 2;
             auto rounds_and_finalize = [&]() {
-                p.budget = task_budget;
                 for (int r = 0; r < rounds; ++r) {
+                    // Late rounds hold few subtrees (fewer than wavefronts): what they cost is their longest walk, i.e. the budget. Halving
+                    // it from round PMX_TASK_DECAY_FROM on spreads a deep subtree over the idle wavefronts sooner.
+                    p.budget = r < task_decay_from ? task_budget : std::max<uint32_t>(task_budget_min, task_budget >> std::min(r - task_decay_from + 1, 16));
                     p.last_round = r + 1 == rounds ? 1u : 0u;
                     round_kernel<<<dim3(1), dim3(64), 0, side>>>(c.ctl, p.qcap);
                     task_kernel<G><<<dim3(task_grid), dim3(64), pl.lds, side>>>(p);

@@ -1463,7 +1463,23 @@ __device__ __forceinline__ ItemLoad item_load(const ScreenParams &p, uint32_t si
     L.b = *reinterpret_cast<const float4 *>(pb + off);
     return L;
 }
-__device__ __forceinline__ void item_finish(const ScreenParams &p, const ItemLoad &L, float &acc, int &fails, uint32_t &n_exact) {
+// TAILS: the call's type weights differ by more than PMX_TAILS_RATIO (pmx_api.hip) - a pair item honours the rough-cell flag like a
+// self item. With the reference's default weights (8 : 1 at most) an entry that counts is made of items near their functions' peaks, next
+// to which the error of a tail value is below float32 rounding; with `--cation 100 --hydrophobic 0.1` (screening.py:54-62) an entry can
+// be a handful of passing Hydrophobic items beside one failing Cation x Cation item five sigma out whose function is 10^6 times theirs -
+// and the tail IS the entry (tests/test_gpu_pair_tails.py).
+template <bool TAILS>
+__device__ __forceinline__ void item_finish(const ScreenParams &p, const ItemLoad &L, float &acc, int &fails, uint32_t &n_exact, uint32_t &n_exactv) {
+    if (TAILS) {
+        const uint32_t su = L.sids & 0xffffu, sv = L.sids >> 16;
+        if (__builtin_expect((__float_as_uint(L.b.y) & 1u) != 0u && su != 0u && sv != 0u, 0)) {
+            int np, mn;
+            acc = acc + exact_value(p, su, sv, L.d, np, mn);
+            fails += 2 * np < mn ? 1 : 0; // match_utils.py:56-61
+            ++n_exactv;
+            return;
+        }
+    }
     const float t = fminf(__builtin_fmaf(L.d, p.F.inv_h, -L.cell), 1.0f); // (= d / h - cell exactly: the product is exact)
     float v = __builtin_fmaf(t, L.b.y, L.b.x);
     v = __builtin_fmaf(t, v, L.a.w);
@@ -1605,7 +1621,7 @@ __device__ __forceinline__ void center_size(GlobalFloats xyz, int C, int start, 
 }
 
 // The self / pair score tables of match_utils.py for the ligand whose levels are in LDS, into `rec`.
-template <int G, bool EXACT>
+template <int G, bool EXACT, bool TAILS>
 __device__ __forceinline__ void build_tables(const ScreenParams &p, unsigned char *lds, const WaveShape<G> &ws, const Record &r, const LevelInfo &L,
                                              unsigned char *rec, uint32_t &n_items, uint32_t &n_exact, uint32_t &n_exactv, uint32_t &n_dead) {
     constexpr int SLOTS = 64 / G;
@@ -1916,7 +1932,7 @@ __device__ __forceinline__ void build_tables(const ScreenParams &p, unsigned cha
 #pragma unroll
                         for (int q = 0; q < IB; ++q) {
                             if (t0 + q < total) {
-                                item_finish(p, Lq[q], acc, fails, n_exact);
+                                item_finish<TAILS>(p, Lq[q], acc, fails, n_exact, n_exactv);
                                 if (--fin_left == 0) {
                                     finish_entry(eb + uni((int)plist[fk]), true, acc, fails);
                                     acc = 0.f, fails = 0;
@@ -1971,7 +1987,7 @@ __device__ __forceinline__ void build_tables(const ScreenParams &p, unsigned cha
 #pragma unroll
                         for (int q = 0; q < IB; ++q) {
                             if (t0 + q < total) {
-                                item_finish(p, L[q], acc, fails, n_exact);
+                                item_finish<TAILS>(p, L[q], acc, fails, n_exact, n_exactv);
                                 if (++fr == npair) {
                                     bool on;
                                     const int e = slot_entry(fk, on);
@@ -2190,7 +2206,7 @@ __device__ inline unsigned long long arena_alloc(const ScreenParams &p, uint32_t
 
 // Ligand -> job: levels, tables, bounds, and the root's subtree record in LDS. Returns the ligand's record (slice or arena), or
 // nullptr when the ligand is finished without a tree search (unsupported record, no candidates, tables too large for this pass).
-template <int G, bool EXACT>
+template <int G, bool EXACT, bool TAILS>
 __device__ __forceinline__ unsigned char *prepare_ligand(const ScreenParams &p, unsigned char *lds, const WaveShape<G> &ws, const uint32_t li, const uint32_t wave_id,
                                                          WaveStats *stat) {
     const int lane = lane_id();
@@ -2281,7 +2297,7 @@ __device__ __forceinline__ unsigned char *prepare_ligand(const ScreenParams &p, 
     if (lane < G) reinterpret_cast<unsigned long long *>(rec + sizeof(RecHeader))[lane] = 0ull;
     uint32_t n_items = 0, n_exact = 0, n_exactv = 0, n_dead = 0;
     const unsigned long long t_b = __builtin_amdgcn_s_memtime();
-    build_tables<G, EXACT>(p, lds, ws, r, L, rec, n_items, n_exact, n_exactv, n_dead);
+    build_tables<G, EXACT, TAILS>(p, lds, ws, r, L, rec, n_items, n_exact, n_exactv, n_dead);
     wave_sync();
     const unsigned long long t_c = __builtin_amdgcn_s_memtime();
     build_bounds<G>(p, lds, ws, L, rec);
@@ -2479,7 +2495,7 @@ __device__ inline void flush_wave_stats(const ScreenParams &p, const WaveStats *
 // or in the arena (mode 2), walk its tree, write its score. A tree that runs over its budget hands its open subtrees to the
 // task queue, which task_kernel drains afterwards. (One kernel for ligands and queued subtrees together was built: the two
 // bodies in one loop cost 80-300 spilled registers, inside the walker's pass loop; apart they need none.)
-template <int G, bool EXACT>
+template <int G, bool EXACT, bool TAILS>
 __global__ __launch_bounds__(64, PMX_SCREEN_WAVES) void ligand_kernel(const ScreenParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int lane0 = lane_id();
@@ -2506,7 +2522,7 @@ __global__ __launch_bounds__(64, PMX_SCREEN_WAVES) void ligand_kernel(const Scre
         }
         const uint32_t next = lig_next++;
         const uint32_t li = p.mode == 0 ? p.lo + next : (uint32_t)uni((int)list[next]);
-        unsigned char *rec = prepare_ligand<G, EXACT>(p, lds, ws, li, wave_id, stat);
+        unsigned char *rec = prepare_ligand<G, EXACT, TAILS>(p, lds, ws, li, wave_id, stat);
         if (!rec) continue;
         const unsigned char *root = lds + ws.off_task;
         const uint32_t rec16 = (uint32_t)uni((int)reinterpret_cast<const TaskRec *>(root)->rec16);

@@ -217,3 +217,99 @@ def test_pair_entries_with_one_item_in_the_tails_match_the_oracle(name, max_pair
     for wname, st in acc.items():
         assert st["n_valid"] >= 1000, f"[{wname}] the sweep does not reach valid pair entries"
         assert st["worst"] <= RTOL, f"[{wname}] max rel err {st['worst']:.3e} at (a, b, oracle score) = {st['at']}"
+
+
+def _heavy_light(flat, a, w7):
+    """The node subsets of cluster `a` made of its heaviest-weighted type only and of its lightest only: ((nodes, mask), (nodes, mask)) or None."""
+    subs = _subsets(flat, a)
+    ws = sorted({w7[int(flat.node_type[m])] for sub in subs for m in sub})
+    if len(ws) < 2:
+        return None
+    pick = {}
+    for sub, mask in subs.items():
+        kinds = {w7[int(flat.node_type[m])] for m in sub}
+        for name, w in (("H", ws[-1]), ("L", ws[0])):
+            if kinds == {w} and (name not in pick or len(sub) > len(pick[name][0])):
+                pick[name] = (sub, mask)
+    return (pick["H"], pick["L"]) if len(pick) == 2 else None
+
+
+def _rescaled(flat, sigma_min_to: float):
+    """The same model with every length multiplied so that its smallest edge sigma is `sigma_min_to` - just above a power of two, the
+    tabulated functions' grid (h = the largest power of two <= sigma_min / 4) is as coarse against the sigmas as it can get."""
+    f = np.float64(sigma_min_to) / np.float64(np.nanmin(flat.edge_std))
+    return dataclasses.replace(
+        flat,
+        edge_mean=(flat.edge_mean.astype(np.float64) * f).astype(np.float32),
+        edge_std=(flat.edge_std.astype(np.float64) * f).astype(np.float32),
+        cluster_center=flat.cluster_center * f,
+        cluster_size=flat.cluster_size * f,
+    )
+
+
+@pytest.mark.parametrize("wname,sigma_min_to", [("core_heavy", None), ("core_light", None), ("charged_heavy", None), ("core_heavy", 1.0000005), ("core_light", 2.000001)])
+def test_one_heavy_item_in_the_tails_beside_light_items_that_pass(wname, sigma_min_to, oracle, monkeypatch):
+    """The entry the 2- and 4-pair sweeps above cannot build (their mixed items cap the contrast at w_max / w_min): two ligand
+    clusters of three light-typed nodes and one heavy-typed node each. The nine light x light node pairs sit where their function
+    passes, the six heavy x light ones 25 A away (they fail and add nothing), and the ONE heavy x heavy pair is swept through the
+    tails of its function: 7 of 16 counted pairs fail, the entry stands (match_utils.py:71-74) - and between 3 and 6 sigma it is
+    little else than that one tail value, w_max^2 / w_min^2 = 10^6 times the weight of the items that pass. Pair items evaluate
+    rough cells term by term when the call's weights are this far apart (item_finish<TAILS>); PMX_PAIR_TAILS=0 shows what the
+    tabulated value alone would have given (the fixture model's sigmas are 5.6 grid steps and more; rescaled so that the smallest is
+    exactly 4, the tabulated tail alone is off by 10^-5)."""
+    from pharmaconet_amd import PackedLibrary, PharmacophoreModel, engine
+    from pharmaconet_amd.constants import weights_vector
+
+    flat = PharmacophoreModel.load(GOLDEN / "model_6oim_like.pm").flat
+    if sigma_min_to is not None:
+        flat = _rescaled(flat, sigma_min_to)
+    wdict = WEIGHT_SETS[wname]
+    w7 = weights_vector(wdict)
+    rng = np.random.default_rng(7)
+    far = 12.0 * float(np.nanmax(flat.edge_std))  # where the heavy nodes sit, off the axis of the light ones
+    step = 0.0125 * float(np.nanmin(flat.edge_std)) / 1.4
+    worst, worst_off, n_scores, n_tail, n_pairs, n_exactv = 0.0, 0.0, 0, 0, 0, 0
+    for a in range(flat.num_clusters):
+        for b in range(flat.num_clusters):
+            if a == b:
+                continue
+            ha, hb = _heavy_light(flat, a, w7), _heavy_light(flat, b, w7)
+            if ha is None or hb is None:
+                continue
+            (Ha, mHa), (La, mLa) = ha
+            (Hb, mHb), (Lb, mLb) = hb
+            p_ll, p_hh = _pin(flat, La, Lb), _pin(flat, Ha, Hb)
+            if p_ll is None or p_hh is None:
+                continue
+            n_pairs += 1
+            jit = rng.normal(size=(2, 3, 3)) * 0.14 * float(np.nanmin(flat.edge_std))
+            recs = []
+            for j in range(200):
+                t = np.maximum(p_hh - 240 * step + (j * 8 + np.arange(8)) * step, 0.05)  # the heavy pair, from 2 sigma inside its mean to 10 sigma beyond
+                xyz = np.zeros((8, 3, 8))
+                for k in range(3):
+                    xyz[k] = jit[0, k][:, None]
+                    xyz[4 + k] = jit[1, k][:, None]
+                    xyz[4 + k, 0, :] += p_ll
+                xyz[3, 0, :], xyz[3, 1, :] = p_ll / 2 - t / 2, far
+                xyz[7, 0, :], xyz[7, 1, :] = p_ll / 2 + t / 2, far
+                recs.append(_record([mLa] * 3 + [mHa], [mLb] * 3 + [mHb], xyz.astype(np.float32)))
+            lib = PackedLibrary.from_records(recs)
+            sub = _two_cluster_model(flat, a, b)
+            ref, stats = oracle.oracle_score(sub, lib, w7, num_threads=os.cpu_count() or 8, with_stats=True)
+            assert np.all(stats["p_entries"] - stats["p_invalid"] > 0)
+            floor_score = ref.min()  # the far end of the sweep: the light items alone
+            n_tail += int(((ref > 1.05 * floor_score) & (ref < 50 * floor_score)).sum())  # entries that are mostly the heavy tail item
+            shim = _Shim(sub)
+            got = engine.screen(shim, lib, weights=wdict).scores.cpu().numpy().astype(np.float64)
+            n_exactv += engine.last_score_stats()["n_exact_values"]
+            worst = max(worst, float(rel_err(got, ref).max()))
+            n_scores += len(ref)
+            monkeypatch.setenv("PMX_PAIR_TAILS", "0")
+            off = engine.screen(shim, lib, weights=wdict).scores.cpu().numpy().astype(np.float64)
+            monkeypatch.delenv("PMX_PAIR_TAILS")
+            worst_off = max(worst_off, float(rel_err(off, ref).max()))
+    print(f"[{wname}, sigma_min {'as is' if sigma_min_to is None else sigma_min_to}] {n_pairs} cluster pairs, {n_scores} scores, {n_tail} of them mostly one tail item; {n_exactv} items term by term; "
+          f"max rel err {worst:.2e} (tabulated tails alone, PMX_PAIR_TAILS=0: {worst_off:.2e})")
+    assert n_pairs >= 6 and n_tail >= 100
+    assert worst <= RTOL
