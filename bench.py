@@ -50,12 +50,12 @@ WORKLOADS = {
 
 
 def csrc_digest():
-    """sha256 over the kernel sources: a committed profile summary is quoted only for the build it was taken on."""
+    """sha256 over the device sources (csrc/*.hip, csrc/*.h): a committed profile summary is quoted only for the kernels it was taken on."""
     import hashlib
 
     h = hashlib.sha256()
     for f in sorted((REPO / "pharmaconet_amd" / "csrc").iterdir()):
-        if f.suffix in (".hip", ".h", ".cpp"):
+        if f.suffix in (".hip", ".h"):
             h.update(f.name.encode() + b"\0" + f.read_bytes())
     return h.hexdigest()[:16]
 

@@ -199,6 +199,42 @@ int pmx_pack_features(const pmx_feature_batch *batch, int threads, uint64_t *off
                       uint64_t *data_bytes, int32_t *status_out);
 
 /*
+ * The rule half of ligand perception in native code (pmx_perceive.cpp): get_pharmacophore_nodes of
+ * src/pmnet/scoring/ligand_utils.py:25-184 for a batch of molecules. The reference asks OpenBabel per atom inside Python
+ * predicates, one molecule at a time; here what only the chemistry toolkit can say comes in as flat per-atom answers, taken on the
+ * hydrogen-free molecule (pybel `removeh()`, ligand.py:37-38) in atom order:
+ *   atomic_num        OBAtom::GetAtomicNum            explicit_degree  GetExplicitDegree        heavy_degree  GetHvyDegree
+ *   hyb               GetHyb                          h_count          explicit hydrogens still bound to the atom (0 after removeh)
+ *   flags             bit 0: IsHbondAcceptor; bit 1: IsHbondDonor of the same atom after AddPolarHydrogens on a copy (ligand_utils.py:30-34,46)
+ *   nbr_off / nbr     heavy-atom neighbours (CSR over all atoms of the batch; indices local to the molecule) in OBAtomAtomIter order
+ *   ring_off / ring_atom_off / ring_atoms   the AROMATIC rings of the SSSR (pybel `sssr`, `ring.IsAromatic()`), atoms in any order
+ * Output: the molecules' feature lists in pharmacophore_list order (ligand_utils.py:80-88) in the layout of pmx_feature_batch
+ * (feat_off[n_mols + 1], feat_type, feat_flags, feat_atom_off, feat_atoms, feat_center_off, feat_centers) - together with the atom arrays
+ * above and the conformer coordinates that IS the input of pmx_pack_features. A call with feat_type == NULL only counts (*n_features,
+ * *n_feat_atoms, *n_feat_centers and feat_off are written). status_out (may be NULL): 2 for a molecule with malformed input (a neighbour
+ * or ring atom outside the molecule), which gets no features.
+ */
+typedef struct {
+    uint64_t n_mols;
+    const uint64_t *atom_off;      /* [n_mols + 1] first atom of each molecule */
+    const uint8_t *atomic_num;     /* [total atoms] */
+    const uint8_t *explicit_degree;
+    const uint8_t *heavy_degree;
+    const uint8_t *hyb;
+    const uint8_t *h_count;
+    const uint8_t *flags;
+    const uint64_t *nbr_off;       /* [total atoms + 1] */
+    const int32_t *nbr;
+    const uint64_t *ring_off;      /* [n_mols + 1] first aromatic ring of each molecule */
+    const uint64_t *ring_atom_off; /* [total rings + 1] */
+    const int32_t *ring_atoms;     /* atom indices local to the molecule */
+} pmx_atom_batch;
+int pmx_perceive_features(const pmx_atom_batch *batch, int threads, uint64_t *feat_off, uint8_t *feat_type, uint8_t *feat_flags,
+                          uint64_t *feat_atom_off, int32_t *feat_atoms, uint64_t *feat_center_off, int32_t *feat_centers,
+                          uint64_t cap_features, uint64_t cap_atoms, uint64_t cap_centers, uint64_t *n_features, uint64_t *n_feat_atoms,
+                          uint64_t *n_feat_centers, int32_t *status_out);
+
+/*
  * Conformer coordinates of an SD file in native code: the coordinate half of Ligand.load_from_file
  * (src/pmnet/scoring/ligand.py:63-84), which has OpenBabel build a molecule object per record and copies
  * `[atom.coords for atom in pbmol.atoms]` in a Python loop after removeh(). The features come from the first record alone

@@ -72,6 +72,11 @@ class FeatureBatch(ctypes.Structure):
     ]
 
 
+class AtomBatch(ctypes.Structure):
+    _fields_ = [("n_mols", ctypes.c_uint64)] + [(n, ctypes.c_void_p) for n in (
+        "atom_off", "atomic_num", "explicit_degree", "heavy_degree", "hyb", "h_count", "flags", "nbr_off", "nbr", "ring_off", "ring_atom_off", "ring_atoms")]
+
+
 class ScoreStats(ctypes.Structure):
     _fields_ = (
         [("ms_total", ctypes.c_double), ("ms_ligand", ctypes.c_double), ("ms_tasks", ctypes.c_double)]
@@ -123,6 +128,10 @@ SIGNATURES = {
     "pmx_pack_features": (
         ctypes.c_int,
         [ctypes.POINTER(FeatureBatch), ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64), ctypes.c_void_p],
+    ),
+    "pmx_perceive_features": (
+        ctypes.c_int,
+        [ctypes.POINTER(AtomBatch), ctypes.c_int] + [ctypes.c_void_p] * 7 + [ctypes.c_uint64] * 3 + [ctypes.POINTER(ctypes.c_uint64)] * 3 + [ctypes.c_void_p],
     ),
     "pmx_sdf_heavy_atoms": (
         ctypes.c_int,
@@ -180,7 +189,7 @@ def load_packer() -> ctypes.CDLL:
         if not path.exists():
             raise PmxError(f"{path} is missing: build with `python -m pharmaconet_amd.build`")
         lib = ctypes.CDLL(str(path))
-        for name in ("pmx_pack_features", "pmx_sdf_heavy_atoms", "pmx_mol2_heavy_atoms", "pmx_last_error", "pmx_version"):
+        for name in ("pmx_pack_features", "pmx_perceive_features", "pmx_sdf_heavy_atoms", "pmx_mol2_heavy_atoms", "pmx_last_error", "pmx_version"):
             restype, argtypes = SIGNATURES[name]
             fn = getattr(lib, name)
             fn.restype = restype

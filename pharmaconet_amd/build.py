@@ -16,7 +16,7 @@ REPO = PKG.parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libpmx.so"
 PACK_LIB = PKG / "libpmx_pack.so"  # the packer alone, host-only (no HIP / RCCL runtime)
-SOURCES = ("pmx_api.hip", "pmx_topk.hip", "pmx_density.hip", "pmx_pack.cpp", "pmx_sdf.cpp")
+SOURCES = ("pmx_api.hip", "pmx_topk.hip", "pmx_density.hip", "pmx_pack.cpp", "pmx_sdf.cpp", "pmx_perceive.cpp")
 DEPS = ("pmx_screen.hip", "pmx_device.h")
 FLAGS = (
     "--offload-arch=gfx950",
@@ -84,7 +84,7 @@ def _build(verbose: bool) -> Path:
     # the host-only packer library
     tmp = PACK_LIB.with_suffix(".so.tmp")
     cmd = [os.environ.get("CXX", "g++"), "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread", "-DPMX_PACK_STANDALONE", f"-I{REPO / 'include'}",
-           str(CSRC / "pmx_pack.cpp"), str(CSRC / "pmx_sdf.cpp"), "-o", str(tmp)]
+           str(CSRC / "pmx_pack.cpp"), str(CSRC / "pmx_sdf.cpp"), str(CSRC / "pmx_perceive.cpp"), "-o", str(tmp)]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

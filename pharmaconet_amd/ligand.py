@@ -24,10 +24,7 @@ import numpy as np
 
 from .library import LigandFeatures
 
-__all__ = ["Ligand", "perceive_features"]
-
-_HALOGENS = (9, 17, 35, 53)
-
+__all__ = ["Ligand", "perceive_features", "toolkit_answers", "perceive_batch", "features_of"]
 
 def _openbabel():
     try:
@@ -47,17 +44,11 @@ def _ffi_error():
     return PmxError
 
 
-def _neighbors(ob, atom):
-    return list(ob.OBAtomAtomIter(atom))
-
-
-def _count(ob, atom, z):
-    return sum(1 for n in _neighbors(ob, atom) if n.GetAtomicNum() == z)
-
-
-def perceive_features(pbmol) -> tuple[list[int], list[list[int]], list[tuple]]:
-    """Atomic numbers, heavy-atom neighbour lists and the typed feature list of a hydrogen-free pybel
-    molecule: the rules of `ligand_utils.py:25-184`, emitted in the type order of `:80-88`."""
+def toolkit_answers(pbmol) -> dict[str, np.ndarray]:
+    """What only the chemistry toolkit can say about a hydrogen-free pybel molecule, as the flat per-atom arrays of
+    `pmx_atom_batch` (include/pmx.h): element, degrees, hybridisation, acceptor / donor flags, heavy-atom neighbours in
+    `OBAtomAtomIter` order, the aromatic rings of the SSSR. One pass over the molecule's atoms; every rule of
+    `ligand_utils.py:25-184` is then decided in native code (`perceive_batch`)."""
     pybel, ob = _openbabel()
     obmol = pbmol.OBMol
     atoms = list(ob.OBMolAtomIter(obmol))
@@ -65,55 +56,127 @@ def perceive_features(pbmol) -> tuple[list[int], list[list[int]], list[tuple]]:
     with_h = pbmol.clone
     with_h.OBMol.AddPolarHydrogens()  # donors are judged on the molecule with polar hydrogens (:30-34,46)
     atoms_h = list(ob.OBMolAtomIter(with_h.OBMol))[:n]
+    z = np.fromiter((a.GetAtomicNum() for a in atoms), dtype=np.uint8, count=n)
+    nbr_off = np.zeros(n + 1, dtype=np.uint64)
+    nbr: list[int] = []
+    h_count = np.zeros(n, dtype=np.uint8)
+    for i, a in enumerate(atoms):
+        for m in ob.OBAtomAtomIter(a):
+            if m.GetAtomicNum() == 1:
+                h_count[i] += 1
+            else:
+                nbr.append(m.GetIdx() - 1)
+        nbr_off[i + 1] = len(nbr)
+    rings = [[i - 1 for i in ring._path] for ring in pbmol.sssr if ring.IsAromatic()]
+    ring_atom_off = np.zeros(len(rings) + 1, dtype=np.uint64)
+    if rings:
+        ring_atom_off[1:] = np.cumsum([len(r) for r in rings])
+    return dict(
+        atomic_num=z,
+        explicit_degree=np.fromiter((a.GetExplicitDegree() for a in atoms), dtype=np.uint8, count=n),
+        heavy_degree=np.fromiter((a.GetHvyDegree() for a in atoms), dtype=np.uint8, count=n),
+        hyb=np.fromiter((a.GetHyb() for a in atoms), dtype=np.uint8, count=n),
+        h_count=h_count,
+        flags=np.fromiter(((1 if a.IsHbondAcceptor() else 0) | (2 if ah.IsHbondDonor() else 0) for a, ah in zip(atoms, atoms_h)), dtype=np.uint8, count=n),
+        nbr_off=nbr_off, nbr=np.asarray(nbr, dtype=np.int32),
+        ring_atom_off=ring_atom_off, ring_atoms=np.asarray([i for r in rings for i in r], dtype=np.int32),
+    )
 
-    z = [a.GetAtomicNum() for a in atoms]
-    nbrs = [[m.GetIdx() - 1 for m in _neighbors(ob, a) if m.GetAtomicNum() != 1] for a in atoms]
 
-    def nbr_idx(a, only=None):
-        return tuple(m.GetIdx() - 1 for m in _neighbors(ob, a) if only is None or m.GetAtomicNum() == only)
+def perceive_batch(answers: list[dict[str, np.ndarray]], positions: list[np.ndarray] | None = None, threads: int = 1) -> dict[str, np.ndarray]:
+    """`get_pharmacophore_nodes` (`ligand_utils.py:25-184`) for a batch of molecules in native code (`pmx_perceive_features`,
+    csrc/pmx_perceive.cpp): the toolkit's answers of `toolkit_answers` in, the flat feature batch out - with `positions`
+    (float32 `[n_atoms, n_conformers, 3]` per molecule) the complete input of `library.pack_features_native`, so a library goes
+    from toolkit answers to packed records without a Python loop over molecules, atoms or features."""
+    import ctypes
 
-    hydrophobic = [i for i, a in enumerate(atoms)
-                   if z[i] == 6 and all(m.GetAtomicNum() in (1, 6) for m in _neighbors(ob, a))]            # :36-40
-    acceptors = [i for i, a in enumerate(atoms) if z[i] not in _HALOGENS and a.IsHbondAcceptor()]           # :41-45
-    donors = [i for i, a in enumerate(atoms_h) if a.IsHbondDonor()]                                           # :46
-    rings = sorted(tuple(sorted(i - 1 for i in ring._path)) for ring in pbmol.sssr if ring.IsAromatic())      # :47-52
+    from . import _ffi
 
-    cations: list[tuple] = []
-    anions: list[tuple] = []
-    for i, a in enumerate(atoms):  # single charged atoms first (:54-58)
-        quaternary_n = z[i] == 7 and a.GetExplicitDegree() == 4 and _count(ob, a, 1) == 0                     # :94-103
-        tertiary_n = z[i] == 7 and a.GetHyb() == 3 and a.GetHvyDegree() == 3                                  # :106-107
-        sulfonium = z[i] == 16 and a.GetExplicitDegree() == 3 and _count(ob, a, 1) == 0                       # :110-118
-        if quaternary_n or tertiary_n or sulfonium:
-            cations.append((i, i))
-    for i, a in enumerate(atoms):  # then charged groups (:61-76)
-        ns = _neighbors(ob, a)
-        guanidine = (z[i] == 6 and len(ns) > 0 and all(m.GetAtomicNum() == 7 for m in ns) and len(ns) == 3
-                     and any(m.GetHvyDegree() == 1 for m in ns))                                              # :121-133
-        phosphate = z[i] == 15 and all(m.GetAtomicNum() == 8 for m in ns)                                     # :156-162
-        sulfate = z[i] == 16 and _count(ob, a, 8) == 4                                                        # :146-153
-        sulfonic = z[i] == 16 and _count(ob, a, 8) == 3                                                       # :136-143
-        carboxylate = z[i] == 6 and _count(ob, a, 8) == 2 and _count(ob, a, 6) == 1                           # :165-175
-        if guanidine:
-            cations.append(((i,) + nbr_idx(a, 7), i))
-        elif phosphate or sulfate:
-            anions.append(((i,) + nbr_idx(a), i))
-        elif sulfonic:
-            anions.append(((i,) + nbr_idx(a, 8), i))
-        elif carboxylate:
-            oxygens = nbr_idx(a, 8)
-            anions.append(((i,) + oxygens, oxygens))
-    halogens = [i for i, a in enumerate(atoms) if z[i] in _HALOGENS and _count(ob, a, 6) > 0]                 # :78,178-184
+    lib = _ffi.load_packer()
+    n = len(answers)
 
-    features: list[tuple] = []
-    features += [("Hydrophobic", i, i) for i in hydrophobic]
-    features += [("Aromatic", r, r) for r in rings]
-    features += [("Cation", at, ce) for at, ce in cations]
-    features += [("Anion", at, ce) for at, ce in anions]
-    features += [("HBond_donor", i, i) for i in donors]
-    features += [("HBond_acceptor", i, i) for i in acceptors]
-    features += [("Halogen", i, i) for i in halogens]
-    return z, nbrs, features
+    def cat(key, dtype):
+        return np.ascontiguousarray(np.concatenate([a[key] for a in answers]) if n else np.zeros(0, dtype), dtype=dtype)
+
+    n_atoms = np.array([len(a["atomic_num"]) for a in answers], dtype=np.uint64)
+    atom_off = np.zeros(n + 1, dtype=np.uint64)
+    atom_off[1:] = np.cumsum(n_atoms)
+    nbr_len = np.array([len(a["nbr"]) for a in answers], dtype=np.uint64)
+    nbr_base = np.zeros(n + 1, dtype=np.uint64)
+    nbr_base[1:] = np.cumsum(nbr_len)
+    nbr_off = np.zeros(int(atom_off[-1]) + 1, dtype=np.uint64)
+    for i, a in enumerate(answers):  # (per molecule, vectorised inside: offsets become absolute)
+        nbr_off[int(atom_off[i]) : int(atom_off[i + 1]) + 1] = a["nbr_off"] + nbr_base[i]
+    n_rings = np.array([len(a["ring_atom_off"]) - 1 for a in answers], dtype=np.uint64)
+    ring_off = np.zeros(n + 1, dtype=np.uint64)
+    ring_off[1:] = np.cumsum(n_rings)
+    ring_atom_off = np.zeros(int(ring_off[-1]) + 1, dtype=np.uint64)
+    base = 0
+    for i, a in enumerate(answers):
+        r0, r1 = int(ring_off[i]), int(ring_off[i + 1])
+        ring_atom_off[r0 : r1 + 1] = a["ring_atom_off"] + np.uint64(base)
+        base += int(a["ring_atom_off"][-1])
+    arrays = dict(
+        atom_off=atom_off, atomic_num=cat("atomic_num", np.uint8), explicit_degree=cat("explicit_degree", np.uint8),
+        heavy_degree=cat("heavy_degree", np.uint8), hyb=cat("hyb", np.uint8), h_count=cat("h_count", np.uint8), flags=cat("flags", np.uint8),
+        nbr_off=nbr_off, nbr=cat("nbr", np.int32), ring_off=ring_off, ring_atom_off=ring_atom_off, ring_atoms=cat("ring_atoms", np.int32),
+    )
+    batch = _ffi.AtomBatch(n, *(arrays[k].ctypes.data for k in (
+        "atom_off", "atomic_num", "explicit_degree", "heavy_degree", "hyb", "h_count", "flags", "nbr_off", "nbr", "ring_off", "ring_atom_off", "ring_atoms")))
+    feat_off = np.zeros(n + 1, dtype=np.uint64)
+    status = np.zeros(n, dtype=np.int32)
+    counts = [ctypes.c_uint64(0) for _ in range(3)]
+
+    def call(*bufs, caps=(0, 0, 0)):
+        rc = lib.pmx_perceive_features(ctypes.byref(batch), int(threads), feat_off.ctypes.data, *bufs, *caps, *(ctypes.byref(c) for c in counts), status.ctypes.data)
+        if rc != 0:
+            raise _ffi.PmxError(f"pmx_perceive_features failed ({rc}): {lib.pmx_last_error().decode()}")
+
+    call(*([None] * 6))  # counts
+    nf, na, nc = (int(c.value) for c in counts)
+    feat_type, feat_flags = np.zeros(nf, np.uint8), np.zeros(nf, np.uint8)
+    fa_off, fc_off = np.zeros(nf + 1, np.uint64), np.zeros(nf + 1, np.uint64)
+    fa, fc = np.zeros(max(na, 1), np.int32), np.zeros(max(nc, 1), np.int32)
+    call(feat_type.ctypes.data, feat_flags.ctypes.data, fa_off.ctypes.data, fa.ctypes.data, fc_off.ctypes.data, fc.ctypes.data, caps=(nf, na, nc))
+    if status.any():
+        raise ValueError(f"perceive_batch: malformed toolkit answers for molecule(s) {np.flatnonzero(status).tolist()[:8]}")
+    out = dict(
+        atom_off=atom_off, atomic_num=arrays["atomic_num"], nbr_off=nbr_off, nbr=arrays["nbr"], feat_off=feat_off, feat_type=feat_type,
+        feat_flags=feat_flags, feat_atom_off=fa_off, feat_atoms=fa[:na], feat_center_off=fc_off, feat_centers=fc[:nc],
+    )
+    if positions is not None:
+        flat_pos = [np.ascontiguousarray(p, dtype=np.float32) for p in positions]
+        pos_off = np.zeros(n + 1, dtype=np.uint64)
+        pos_off[1:] = np.cumsum([p.size for p in flat_pos])
+        out.update(n_conf=np.array([int(p.shape[1]) if p.ndim == 3 else 0 for p in flat_pos], dtype=np.int32), pos_off=pos_off,
+                   positions=np.concatenate([p.reshape(-1) for p in flat_pos]) if flat_pos else np.zeros(0, np.float32))
+    return out
+
+
+def features_of(flat: dict[str, np.ndarray], i: int) -> list[tuple]:
+    """Molecule `i` of a flat feature batch as the reference's `pharmacophore_list` entries `(type, atom_indices, center_indices)`
+    - ints or tuples as the reference holds them (an int and a 1-tuple are different node keys, ligand.py:137)."""
+    from .constants import TYPE_NAMES
+
+    out = []
+    for k in range(int(flat["feat_off"][i]), int(flat["feat_off"][i + 1])):
+        atoms = flat["feat_atoms"][int(flat["feat_atom_off"][k]) : int(flat["feat_atom_off"][k + 1])].tolist()
+        centers = flat["feat_centers"][int(flat["feat_center_off"][k]) : int(flat["feat_center_off"][k + 1])].tolist()
+        fl = int(flat["feat_flags"][k])
+        out.append((TYPE_NAMES[int(flat["feat_type"][k])], tuple(atoms) if fl & 1 else atoms[0], tuple(centers) if fl & 2 else centers[0]))
+    return out
+
+
+def perceive_features(pbmol) -> tuple[list[int], list[list[int]], list[tuple]]:
+    """Atomic numbers, heavy-atom neighbour lists and the typed feature list of a hydrogen-free pybel molecule: the toolkit's
+    answers (`toolkit_answers`) through the native rules of `ligand_utils.py:25-184` (`perceive_batch`), emitted in the type
+    order of `:80-88`."""
+    ans = toolkit_answers(pbmol)
+    flat = perceive_batch([ans])
+    z = [int(x) for x in ans["atomic_num"]]
+    off = ans["nbr_off"].astype(np.int64)
+    nbrs = [ans["nbr"][off[i] : off[i + 1]].tolist() for i in range(len(z))]
+    return z, nbrs, features_of(flat, 0)
 
 
 class Ligand:
@@ -134,8 +197,19 @@ class Ligand:
         assert self.num_atoms == pos.shape[0]
         self.atom_positions = pos
         self.num_conformers = int(pos.shape[1])
-        z, nbrs, feats = perceive_features(self.pbmol)
-        self.features = LigandFeatures(z, nbrs, feats, pos)
+        self.answers = toolkit_answers(self.pbmol)  # everything that is asked of the toolkit; the rules run in native code
+        self._features = None
+
+    @property
+    def features(self) -> LigandFeatures:
+        """The packer's input for this one molecule (`perceive_batch` takes many molecules' `answers` at once)."""
+        if self._features is None:
+            ans = self.answers
+            off = ans["nbr_off"].astype(np.int64)
+            nbrs = [ans["nbr"][off[i] : off[i + 1]].tolist() for i in range(len(ans["atomic_num"]))]
+            feats = features_of(perceive_batch([ans]), 0)
+            self._features = LigandFeatures([int(x) for x in ans["atomic_num"]], nbrs, feats, self.atom_positions)
+        return self._features
 
     @classmethod
     def load_from_file(cls, filename: str | Path, num_conformers: int | None = None) -> "Ligand":

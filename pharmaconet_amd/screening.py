@@ -39,11 +39,13 @@ class Screening_ArgParser(argparse.ArgumentParser):
         par.add_argument("--cation", type=float, default=8.0, help="weight for cation")
 
 
-def _pack_file(path: str) -> tuple[bytes, str | None]:
-    from .library import pack_ligand_or_marker
+def _read_file(path: str):
+    """One molecule file in a worker process: the toolkit parses it and answers the per-atom questions of perception
+    (`ligand.toolkit_answers`); the conformer coordinates come with them. The rules and the packing run on the whole batch."""
     from .ligand import Ligand
 
-    return pack_ligand_or_marker(Ligand.load_from_file(path).features)
+    lig = Ligand.load_from_file(path)
+    return lig.answers, lig.atom_positions
 
 
 def load_library(library: Path, cpus: int) -> tuple[list[str], PackedLibrary]:
@@ -57,14 +59,21 @@ def load_library(library: Path, cpus: int) -> tuple[list[str], PackedLibrary]:
         else:
             names = [f"{library}#{i}" for i in range(len(lib))]
         return names, lib
+    from .library import pack_features_native
+    from .ligand import perceive_batch
+
     file_list = list(library.rglob("*.sdf")) + list(library.rglob("*.mol2"))  # screening.py:63-64
     print(f"find {len(file_list)} molecules")
     with multiprocessing.Pool(cpus) as pool:
-        packed = pool.map(_pack_file, [str(f) for f in file_list])
-    for f, (_, why) in zip(file_list, packed):
-        if why is not None:  # scored by the reference, not by this engine: reported, never silently dropped
+        read = pool.map(_read_file, [str(f) for f in file_list])
+    # features (ligand_utils.py:25-184) and records (LigandGraph, ligand.py:110-259) of all molecules at once, in native code
+    flat = perceive_batch([a for a, _ in read], [p for _, p in read], threads=cpus)
+    lib, status = pack_features_native(flat, threads=cpus)
+    for f, st in zip(file_list, status):
+        if st != 0:  # scored by the reference, not by this engine: reported, never silently dropped
+            why = "outside the engine's structural limits (include/pmx.h)" if st == 1 else "feature graph the packer does not accept"
             print(f"warning: {f}: {why}; written with score nan", file=sys.stderr)
-    return [str(f) for f in file_list], PackedLibrary.from_records([rec for rec, _ in packed])
+    return [str(f) for f in file_list], lib
 
 
 def write_csv(out: Path, names: list[str], scores: np.ndarray, status: np.ndarray | None = None) -> None:

@@ -117,3 +117,77 @@ def test_scoring_pbmol_and_scoring_file_end_to_end(golden, tmp_path):
         got = model.scoring_file(path)
         assert abs(got - want) <= 2e-6 * max(abs(want), 1e-30)
     print(f"scoring_pbmol on {len(e2e['score'])} described molecules: max rel err {worst:.2e}")
+
+
+def test_native_perception_of_the_whole_batch_matches_the_reference(golden):
+    """`pmx_perceive_features` (csrc/pmx_perceive.cpp) on all 600 described molecules in ONE call - the toolkit's per-atom answers in,
+    flat feature lists out - against the reference's own `get_pharmacophore_nodes`; and chained into `pmx_pack_features`, the
+    records of the reference's LigandGraph. One thread and many give the same arrays."""
+    from pharmaconet_amd.library import pack_features_native
+    from pharmaconet_amd.ligand import features_of, perceive_batch, toolkit_answers
+
+    answers, positions = [], []
+    for desc in golden["molecules"]:
+        pb = fake_openbabel.Molecule(desc)
+        pb.removeh()
+        answers.append(toolkit_answers(pb))
+        positions.append(np.ascontiguousarray(np.moveaxis(np.asarray(desc["coords"], dtype=np.float32), 0, 1)))  # [atoms, conformers, 3]
+    flat = perceive_batch(answers, positions, threads=1)
+    many = perceive_batch(answers, positions, threads=8)
+    assert all(np.array_equal(flat[k], many[k]) for k in flat)
+    for i, want in enumerate(golden["reference"]):
+        got = [[t, _plain(a), _plain(c)] for t, a, c in features_of(flat, i)]
+        assert got == want, f"molecule {i}"
+    # ... and on into the packer without a Python loop: records equal to the reference's LigandGraph (perception_e2e.npz holds the first 96)
+    lib, status = pack_features_native(flat, threads=4)
+    e2e = np.load(GOLDEN / "perception_e2e.npz")
+    off = np.concatenate([[0], np.cumsum(e2e["record_len"])])
+    for i in range(len(e2e["record_len"])):
+        assert status[i] == 0
+        assert lib.record(i) == e2e["records"][off[i]:off[i + 1]].tobytes(), f"molecule {i}"
+
+
+def test_malformed_toolkit_answers_are_reported(golden):
+    from pharmaconet_amd.ligand import perceive_batch, toolkit_answers
+
+    pb = fake_openbabel.Molecule(golden["molecules"][0])
+    pb.removeh()
+    ans = toolkit_answers(pb)
+    ans["nbr"] = ans["nbr"].copy()
+    ans["nbr"][0] = 10_000  # a neighbour outside the molecule
+    with pytest.raises(ValueError):
+        perceive_batch([ans])
+
+
+def test_screening_reads_a_directory_in_one_batch(golden, tmp_path, monkeypatch):
+    """`screening.load_library` on a directory (screening.py:63-68): files are read in worker processes, perception rules and
+    packing run once on the batch - the library equals the per-molecule path's."""
+    from pharmaconet_amd import screening
+    from pharmaconet_amd.library import pack_ligand
+    from pharmaconet_amd.ligand import Ligand
+
+    picks = [0, 3, 5, 8, 13]
+    for i in picks:
+        (tmp_path / f"mol{i:03d}.sdf").write_text(json.dumps(golden["molecules"][i]))
+
+    class _Pool:  # (the stand-in toolkit lives in this process only)
+        def __init__(self, n):
+            pass
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+        def map(self, fn, items):
+            return [fn(x) for x in items]
+
+    monkeypatch.setattr(screening.multiprocessing, "Pool", _Pool)
+    names, lib = screening.load_library(tmp_path, cpus=2)
+    assert len(names) == len(picks) == len(lib)
+    for k, name in enumerate(names):
+        i = int(name[-7:-4])
+        desc = golden["molecules"][i]
+        one = Ligand(fake_openbabel.Molecule(desc), np.asarray(desc["coords"], dtype=np.float32), conformer_axis=0)
+        assert lib.record(k) == bytes(pack_ligand(one.features))
