@@ -33,6 +33,8 @@
 // slice, and trees that run over their budget, move to a bump-allocated arena: over-budget walkers append the open
 // subtrees with >= 5 matches to a task queue (exactness argument: see walk()), which launches of task_kernel drain in rounds.
 // Everything is ordered on the caller's stream.
+#include <type_traits>
+
 #include "pmx_device.h"
 
 #pragma clang fp contract(off)
@@ -1345,11 +1347,11 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
 
 // ------------------------------------------------------------------------------------------ table phase
 __device__ __forceinline__ uint32_t fn_index(const FnTable &F, uint32_t sidu, uint32_t sidv) {
-    if (F.tri) {
-        const uint32_t hi = max(sidu, sidv), lo = min(sidu, sidv);
-        return (hi * (hi + 1u) >> 1) + lo;
-    }
-    return sidu * F.NS + sidv;
+    // (both forms and a bit select on the wave-uniform `tri`: a branch here is a branch per table item)
+    const uint32_t hi = max(sidu, sidv), lo = min(sidu, sidv);
+    const uint32_t t = (__umul24(hi, hi + 1u) >> 1) + lo, f = __umul24(sidu, F.NS) + sidv; // (subset ids are 16 bits)
+    const uint32_t m = 0u - F.tri;
+    return (t & m) | (f & ~m);
 }
 
 // One (ligand node, ligand node) item term by term, in the float32 operations of the reference (match_utils.py:50-69 and
@@ -1953,51 +1955,61 @@ __device__ __forceinline__ void build_tables(const ScreenParams &p, unsigned cha
                     const int npair = ni * nj;
                     const int nround = (npass + SLOTS - 1) / SLOTS;
                     const int total = nround * npair;
-                    int lk = 0, lu = 0, lv = 0; // next item to load: entry round, node pair
-                    int fk = 0, fr = 0;         // next item to finish: entry round, pair number
-                    int rowa = 0, rowb = 0;     // node-candidate rows of this slot's entry of round lk
-                    auto slot_entry = [&](int k, bool &on) {
-                        on = k * SLOTS + s < npass;
-                        return eb + (int)plist[on ? k * SLOTS + s : k * SLOTS];
-                    };
-                    auto decode = [&](int k) {
-                        bool on;
-                        const int e = slot_entry(k, on);
-                        const int sa = (int)(((float)e + 0.5f) * inv_kj), sb = e - sa * kj;
-                        rowa = nci + sa * ni, rowb = ncj + sb * nj;
-                    };
-                    decode(0);
-                    float acc = 0.f;
-                    int fails = 0;
-                    for (int t0 = 0; t0 < total; t0 += IB) {
-                        ItemLoad L[IB];
-#pragma unroll
-                        for (int q = 0; q < IB; ++q) {
-                            const bool in = t0 + q < total; // (an item past the end is the empty subset pair: value 0, never a fail)
-                            const float d = staged ? dl[(lu * nj + lv) * G + c] : node_distance(si, lu, sj, lv);
-                            L[q] = item_load(p, in ? (uint32_t)nc[rowa + lu] : 0u, in ? (uint32_t)nc[rowb + lv] : 0u, d, cell_of(p, d));
+                    // (The loop is instantiated for staged / computed distances: what is fixed per level pair is decided once, not per
+                    // item, and the list's end is tested per batch, not per item. [MI355X] tables alone 57.4 -> 56.7 ms per 1 M ligands.)
+                    auto run_items = [&](auto staged_tag) {
+                        constexpr bool STG = decltype(staged_tag)::value;
+                        int lk = 0, lu = 0, lv = 0, lpos = 0; // next item to load: entry round, node pair, its number
+                        int fk = 0, fr = 0;                   // next item to finish: entry round, pair number
+                        int rowa = 0, rowb = 0;               // node-candidate rows of this slot's entry of round lk
+                        auto slot_entry = [&](int k, bool &on) {
+                            on = k * SLOTS + s < npass;
+                            return eb + (int)plist[on ? k * SLOTS + s : k * SLOTS];
+                        };
+                        auto decode = [&](int k) {
+                            bool on;
+                            const int e = slot_entry(k, on);
+                            const int sa = (int)(((float)e + 0.5f) * inv_kj), sb = e - sa * kj;
+                            rowa = nci + sa * ni, rowb = ncj + sb * nj;
+                        };
+                        decode(0);
+                        float acc = 0.f;
+                        int fails = 0;
+                        auto load_next = [&]() {
+                            const float d = STG ? dl[lpos * G + c] : node_distance(si, lu, sj, lv);
+                            const ItemLoad L = item_load(p, (uint32_t)nc[rowa + lu], (uint32_t)nc[rowb + lv], d, cell_of(p, d));
+                            ++lpos;
                             if (++lv == nj) {
                                 lv = 0;
                                 if (++lu == ni) {
-                                    lu = 0;
+                                    lu = 0, lpos = 0;
                                     if (++lk < nround) decode(lk);
                                 }
                             }
-                        }
-#pragma unroll
-                        for (int q = 0; q < IB; ++q) {
-                            if (t0 + q < total) {
-                                item_finish<TAILS>(p, L[q], acc, fails, n_exact, n_exactv);
-                                if (++fr == npair) {
-                                    bool on;
-                                    const int e = slot_entry(fk, on);
-                                    finish_entry(e, on, acc, fails);
-                                    fr = 0, ++fk;
-                                    acc = 0.f, fails = 0;
-                                }
+                            return L;
+                        };
+                        auto finish_next = [&](const ItemLoad &L) {
+                            item_finish<TAILS>(p, L, acc, fails, n_exact, n_exactv);
+                            if (++fr == npair) {
+                                bool on;
+                                const int e = slot_entry(fk, on);
+                                finish_entry(e, on, acc, fails);
+                                fr = 0, ++fk;
+                                acc = 0.f, fails = 0;
                             }
+                        };
+                        int t0 = 0;
+                        for (; t0 + IB <= total; t0 += IB) { // whole batches: no test of the list's end inside
+                            ItemLoad L[IB];
+#pragma unroll
+                            for (int q = 0; q < IB; ++q) L[q] = load_next();
+#pragma unroll
+                            for (int q = 0; q < IB; ++q) finish_next(L[q]);
                         }
-                    }
+                        for (; t0 < total; ++t0) finish_next(load_next()); // what is left of the list, one at a time
+                    };
+                    if (staged) run_items(std::true_type{});
+                    else run_items(std::false_type{});
                     n_items += (uint32_t)total;
 #ifdef PMX_TABLE_FILL // instrumented builds: [1] wave-iterations of the pair items, [5] slot-items of them that belong to an entry
                     if (lane == 0) {
