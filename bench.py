@@ -213,7 +213,10 @@ def cpu_baseline(pockets, offsets, data, n_conf, budget_s=10.0):
     lib = sample(n)
     dt = timed(lib, cores)
     rate = n / dt
-    n1 = int(min(n, max(16, rate / cores * 2.0 * budget_s)))  # (threads share caches and clocks: one core alone is faster than 1 / cores)
+    # one core: sized from a short probe of its own (threads share caches and clocks: one core alone is far faster than 1 / cores of all)
+    probe1 = sample(min(64, n))
+    rate1 = len(probe1) / max(timed(probe1, 1), 1e-6)
+    n1 = int(min(n, max(len(probe1), rate1 * 0.8 * budget_s)))
     lib1 = sample(n1)
     dt1 = timed(lib1, 1)
     return {
