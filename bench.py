@@ -323,7 +323,7 @@ def main():
     entry.build()
     from pharmaconet_amd import PharmacophoreModel
     from pharmaconet_amd import engine
-    from pharmaconet_amd.distributed import TopkExchange, allgather_topk
+    from pharmaconet_amd.distributed import TopkExchange, allgather_topk_device
 
     model = PharmacophoreModel.load(REPO / "tests" / "golden" / model_file)
     pockets = [model]
@@ -342,7 +342,7 @@ def main():
                 if exchange is not None:  # RCCL all-gather + merge on the device through libpmx's C ABI; the ranking stays on the device
                     top = exchange.allgather(res.topk_scores, res.topk_indices, args.topk)
                 else:
-                    top = allgather_topk(res.topk_scores.cpu(), res.topk_indices.cpu(), args.topk)
+                    top = allgather_topk_device(res.topk_scores, res.topk_indices, args.topk)  # rehearsal transport, the device merge of the RCCL path
             else:
                 top = (res.topk_scores, res.topk_indices)
         return res, top
@@ -431,7 +431,7 @@ def main():
                 "conformers_per_ligand": args.conformers,
                 "parallelism": f"ligand-sharded x{world}" if world > 1 else "single GPU",
                 "exchange": None if world == 1 else ({"collective": "ncclAllGather of per-rank top-k (pmx_topk_allgather, merge on the device)", "rccl_ranks": exchange.world}
-                                                     if exchange is not None else {"collective": f"{backend} all_gather of per-rank top-k (rehearsal backend, merge on the host)", "ranks": world}),
+                                                     if exchange is not None else {"collective": f"{backend} all_gather of per-rank top-k (rehearsal transport) + the device merge of pmx_topk_allgather (pmx_topk over the gathered lists)", "ranks": world}),
             },
             "roofline": {
                 "bound": "hbm",

@@ -160,15 +160,18 @@ def load(need_torch: bool = True) -> ctypes.CDLL:
         if need_torch:
             import torch  # noqa: F401
 
-        if not LIB_PATH.exists():
+        import os
+
+        path = Path(os.environ["PMX_LIBPMX"]) if os.environ.get("PMX_LIBPMX") else LIB_PATH  # (A/B builds: tools/build_variant.py)
+        if not path.exists():
             raise PmxError(
-                f"{LIB_PATH} is missing: build the HIP extension with `python -m pharmaconet_amd.build` "
+                f"{path} is missing: build the HIP extension with `python -m pharmaconet_amd.build` "
                 "(hipcc, gfx950). There is no CPU scoring path."
             )
         try:
-            lib = ctypes.CDLL(str(LIB_PATH))
+            lib = ctypes.CDLL(str(path))
         except OSError as e:  # e.g. libamdhip64 not found
-            raise PmxError(f"cannot load {LIB_PATH}: {e}") from e
+            raise PmxError(f"cannot load {path}: {e}") from e
         for name, (restype, argtypes) in SIGNATURES.items():
             fn = getattr(lib, name)
             fn.restype = restype

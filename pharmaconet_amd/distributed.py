@@ -11,7 +11,7 @@ from __future__ import annotations
 
 import numpy as np
 
-__all__ = ["shard_range", "merge_topk", "allgather_topk", "screen_sharded", "TopkExchange"]
+__all__ = ["shard_range", "merge_topk", "allgather_topk", "allgather_topk_device", "screen_sharded", "TopkExchange"]
 
 
 def shard_range(n_total: int, rank: int, world: int) -> tuple[int, int]:
@@ -47,6 +47,27 @@ def allgather_topk(local_scores, local_indices, k: int, group=None) -> tuple[np.
     dist.all_gather_into_tensor(gathered_s, local_scores.contiguous(), group=group)
     dist.all_gather_into_tensor(gathered_i, local_indices.contiguous(), group=group)
     return merge_topk(gathered_s.cpu().numpy(), gathered_i.cpu().numpy(), k)
+
+
+def allgather_topk_device(local_scores, local_indices, k: int, group=None):
+    """The exchange with the transport swapped: the ranks' lists travel over whatever backend the process group has (gloo on a
+    box without one GPU per rank), the merge is the one `pmx_topk_allgather` runs behind its `ncclAllGather` - `pmx_topk` over the
+    gathered `(score, global index)` lists on this rank's device. Returns device tensors, identical on every rank."""
+    import torch
+    import torch.distributed as dist
+
+    from .engine import topk
+
+    world = dist.get_world_size(group)
+    dev = local_scores.device
+    host = dist.get_backend(group) != "nccl"
+    ls = local_scores.contiguous().cpu() if host else local_scores.contiguous()
+    li = local_indices.contiguous().cpu() if host else local_indices.contiguous()
+    gs = torch.empty(world * ls.numel(), dtype=ls.dtype, device=ls.device)
+    gi = torch.empty(world * li.numel(), dtype=li.dtype, device=li.device)
+    dist.all_gather_into_tensor(gs, ls, group=group)
+    dist.all_gather_into_tensor(gi, li, group=group)
+    return topk(gs.to(dev), int(k), indices=gi.to(dev))
 
 
 class TopkExchange:

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""An A/B build of libpmx.so with extra compile flags, next to the product build:
+
+    python tools/build_variant.py w7 -DPMX_SCREEN_WAVES=7 -DPMX_TASK_WAVES=7 -DPMX_TC_LEVELS=2
+    PMX_LIBPMX=$PWD/variants/libpmx_w7.so python tools/knob_sweep.py
+
+(variants/*.so are git-ignored and travel to the GPU box like the product's .so)."""
+import subprocess
+import sys
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(REPO))
+from pharmaconet_amd.build import CSRC, FLAGS, SOURCES, hipcc  # noqa: E402
+
+
+def main():
+    name, extra = sys.argv[1], sys.argv[2:]
+    out = REPO / "variants"
+    out.mkdir(exist_ok=True)
+    objs = []
+    for src in SOURCES:
+        obj = out / f"{name}_{src.rsplit('.', 1)[0]}.o"
+        if src.endswith(".hip") and src != "pmx_api.hip" and (out / f"base_{src.rsplit('.', 1)[0]}.o").exists():
+            obj = out / f"base_{src.rsplit('.', 1)[0]}.o"  # (only pmx_api.hip holds the screening kernels)
+        else:
+            subprocess.run([hipcc(), *FLAGS, *extra, f"-I{REPO / 'include'}", f"-I{CSRC}", "-c", str(CSRC / src), "-o", str(obj)], check=True)
+        objs.append(str(obj))
+    lib = out / f"libpmx_{name}.so"
+    subprocess.run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", str(lib), "-L/opt/rocm/lib", "-lrccl"], check=True)
+    print(lib)
+
+
+if __name__ == "__main__":
+    main()
