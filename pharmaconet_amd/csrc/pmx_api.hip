@@ -741,9 +741,12 @@ static int score_screen(const pmx_model *const *models, int n_models, const pmx_
     bool tails = false;
     {
         float wmin = INFINITY, wmax = 0.f;
+        bool present[PMX_NUM_TYPES] = {};
+        for (int m = 0; m < n_models; ++m)
+            for (int i = 0; i < models[m]->dm.Nm; ++i) present[models[m]->node_type[i]] = true; // (only the types the pockets hold can meet in an entry)
         for (int t = 0; t < PMX_NUM_TYPES; ++t) {
             const float a = std::fabs(W.w[t]);
-            if (a > 0.f && std::isfinite(a)) wmin = std::min(wmin, a), wmax = std::max(wmax, a);
+            if (present[t] && a > 0.f && std::isfinite(a)) wmin = std::min(wmin, a), wmax = std::max(wmax, a);
         }
         const char *rs = std::getenv("PMX_TAILS_RATIO");
         const double ratio = (rs && *rs) ? std::atof(rs) : 16.0;
