@@ -74,9 +74,11 @@ def test_zero_type_weight_matches_oracle(oracle):
 @pytest.mark.parametrize("env", [{"PMX_TREE_FLAGS": "8"}, {"PMX_TREE_FLAGS": "4"}, {"PMX_BUDGET": "16", "PMX_MIN_LEVELS": "0"},
                                  {"PMX_SLICE_KB": "4"}, {"PMX_SLICE_KB": "4", "PMX_ARENA_MB": "16", "PMX_BUDGET": "64"},
                                  {"PMX_TREE_FLAGS": "128"}, {"PMX_TREE_FLAGS": "1024"}, {"PMX_PATH_KB": "2"}, {"PMX_TREE_FLAGS": "32768"},
-                                 {"PMX_TREE_FLAGS": "65536"}, {"PMX_DEAD_MIN_ENTRIES": "1"}, {"PMX_TREE_FLAGS": "131072"}],
+                                 {"PMX_TREE_FLAGS": "65536"}, {"PMX_DEAD_MIN_ENTRIES": "1"}, {"PMX_TREE_FLAGS": "131072"}, {"PMX_PAIR_TAILS": "1"},
+                                 {"PMX_TASK_DECAY_FROM": "1", "PMX_TASK_BUDGET_MIN": "8", "PMX_BUDGET": "32"}],
                          ids=["exact-terms", "no-bound-test", "tiny-budget", "tiny-slices", "tiny-slices-and-arena", "no-candidate-filter",
-                              "no-path-bound", "tiny-path-buffer", "no-chain-lengths", "no-dead-entry-test", "dead-entry-test-everywhere", "no-wide-path-test"])
+                              "no-path-bound", "tiny-path-buffer", "no-chain-lengths", "no-dead-entry-test", "dead-entry-test-everywhere", "no-wide-path-test",
+                              "pair-items-honour-rough-cells", "decaying-task-budget"])
 @pytest.mark.parametrize("name", GOLDEN_SETS)
 def test_engine_settings_match_reference_golden(name, env, monkeypatch):
     """The golden sets under settings that force the rarely taken paths of the engine: Gaussian terms evaluated one by
