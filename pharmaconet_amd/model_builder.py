@@ -162,6 +162,39 @@ def voxel_components_device(masks: Sequence[np.ndarray], device: int = 0) -> lis
     return out
 
 
+_DEVICE_SEARCH_OK: dict[int, bool] = {}
+
+
+def device_search_agrees(device: int) -> bool:
+    """Once per process and device: does `voxel_components_device` list the components of a synthetic map (four blobs, some 3 000 active
+    voxels: large enough for the interpreter's set to resize and collect dummies) in the order the reference's own loop
+    (`voxel_components`) does? Discarding a popped seed's component voxel by voxel gives every later `pop()` what the reference's gives
+    on CPython 3.8-3.12 as tested; on an interpreter whose `set` behaves differently the model would still be a valid model, but not
+    the reference's state - so the device search is used only where this check passes (`build_model_state` falls back to the host loop)."""
+    if device not in _DEVICE_SEARCH_OK:
+        rng = np.random.default_rng(20250930)
+        size = 32
+        grid = np.indices((size, size, size)).astype(np.float32)
+        mask = np.zeros((size, size, size), dtype=np.float32)
+        for centre, radius in (((8, 8, 8), 5.2), ((22, 9, 20), 5.8), ((10, 23, 21), 4.6), ((24, 24, 6), 3.3)):
+            d2 = sum((grid[k] - centre[k]) ** 2 for k in range(3))
+            mask[d2 < radius * radius] = 1.0
+        mask *= rng.uniform(0.05, 1.0, size=mask.shape).astype(np.float32)
+        try:
+            host = [(np.asarray(m, dtype=np.int64), np.asarray(v, dtype=np.float64)) for m, v in voxel_components(mask)]
+            dev = voxel_components_device([mask], device)[0]
+            ok = len(host) == len(dev) and all(np.array_equal(hm, dm) and np.array_equal(hv, dv) for (hm, hv), (dm, dv) in zip(host, dev))
+        except Exception:
+            ok = False
+        _DEVICE_SEARCH_OK[device] = ok
+        if not ok:
+            import warnings
+
+            warnings.warn("pharmaconet_amd: the device voxel search does not reproduce this interpreter's set.pop() order; "
+                          "PharmacophoreModel.create uses the host search")
+    return _DEVICE_SEARCH_OK[device]
+
+
 def _grid_to_world(coords, center, resolution: float, size: int) -> tuple[float, float, float]:
     """density_map.py:16-25: voxel coordinates -> Angstrom, the box being centred on `center`."""
     half = resolution * (size - 1) / 2
@@ -190,6 +223,8 @@ def build_model_state(
     nodes: list[dict[str, Any]] = []
     edges: list[dict[str, Any]] = []
     mean_of: dict[tuple[int, int], float] = {}
+    if device is not None and not device_search_agrees(device):
+        device = None
     searched = voxel_components_device([info["point_map"] for info in hotspot_infos], device) if device is not None and len(hotspot_infos) else None
     for h, info in enumerate(hotspot_infos):
         kind = info["nci_type"]

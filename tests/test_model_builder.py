@@ -126,3 +126,14 @@ def test_components_are_26_connected_and_small_ones_are_dropped():
     assert len(st["nodes"]) == 1 and len(st["edges"]) == 1
     assert st["nodes"][0]["overlapped_nodes"] == [0, 0]  # the self loop registers the node twice (density_map.py:247-249)
     assert [len(v) for v in st["node_cluster_dict"].values()] == [0, 0, 0, 0, 1, 0]
+
+
+@pytest.mark.gpu
+def test_device_search_checks_itself_against_the_interpreter():
+    """`device_search_agrees`: the one-time comparison of the device search with the reference's own loop on a synthetic map passes
+    on this interpreter (and is what `build_model_state` consults before it trusts the device with a model's state)."""
+    from pharmaconet_amd import model_builder
+
+    model_builder._DEVICE_SEARCH_OK.clear()
+    assert model_builder.device_search_agrees(0) is True
+    assert model_builder._DEVICE_SEARCH_OK == {0: True}
