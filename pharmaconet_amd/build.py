@@ -27,6 +27,11 @@ FLAGS = (
     "-fno-fast-math",
     "-Wall",
     "-Wno-unused-function",
+    # [MI355X] configs[1] 117.6 -> 106.7 ms per pass (ligand kernel 90 -> 79 ms): SimplifyCFG's sinking of common instructions into the
+    # blocks where the many paths of the table and walker loops meet costs these kernels copies at every join; loop strength reduction
+    # trades address arithmetic for live registers they do not have (tools/build_variant.py A/B runs, HISTORY.md round 5)
+    "-mllvm", "-simplifycfg-sink-common=false",
+    "-mllvm", "-disable-lsr",
 )
 
 
