@@ -53,7 +53,9 @@ def csrc_digest():
     """sha256 over the device sources (csrc/*.hip, csrc/*.h): a committed profile summary is quoted only for the kernels it was taken on."""
     import hashlib
 
-    h = hashlib.sha256()
+    from pharmaconet_amd.build import FLAGS
+
+    h = hashlib.sha256(" ".join(FLAGS).encode())  # (the compile flags are part of the build: two -mllvm switches are worth 10 % of a pass)
     for f in sorted((REPO / "pharmaconet_amd" / "csrc").iterdir()):
         if f.suffix in (".hip", ".h"):
             h.update(f.name.encode() + b"\0" + f.read_bytes())

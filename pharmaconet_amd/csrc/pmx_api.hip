@@ -696,7 +696,7 @@ static int grow(T **ptr, size_t *have, size_t want, hipStream_t stream, hipStrea
 struct PocketPlan {
     ScreenParams p;
     size_t lds = 0;
-    uint32_t waves_per_cu = 0;
+    uint32_t waves_per_cu = 0, task_waves_per_cu = 0;
     uint32_t slice_bytes = 0, big_bytes = 0, big_grid = 0;
     uint64_t worst_bytes = 0;
     uint32_t super = 0;
@@ -790,7 +790,9 @@ static int score_screen(const pmx_model *const *models, int n_models, const pmx_
         const WaveShape<G> shape = wave_shape<G>(model->dm.K, (int)max_nodes);
         pl.lds = shape.bytes;
         pl.waves_per_cu = (uint32_t)std::max<long>(2, std::min<long>({(long)(kLdsPerCu / shape.bytes), 4L * PMX_SCREEN_WAVES, env_long("PMX_WAVES_PER_CU", 32)}));
-        const uint32_t grid = (uint32_t)ws.num_cu * pl.waves_per_cu;
+        // the task kernel is the walker alone: it may be built for more waves per SIMD than the ligand kernel (PMX_TASK_WAVES)
+        pl.task_waves_per_cu = (uint32_t)std::max<long>(2, std::min<long>({(long)(kLdsPerCu / shape.bytes), 4L * PMX_TASK_WAVES, env_long("PMX_TASK_WAVES_PER_CU", 32)}));
+        const uint32_t grid = (uint32_t)ws.num_cu * std::max(pl.waves_per_cu, pl.task_waves_per_cu); // (sizes the per-wavefront buffers of both kernels)
         // per-wavefront slice: 112 KB at 8 conformer lanes (every ligand of the bench library fits, path_bound()'s table included), scaled with the lanes
         // (table bytes grow with the square of the model's cluster count: the 11-cluster 6OIM-like model is the reference point)
         const long k_scale = std::max(1L, std::min(16L, ((long)model->dm.K * model->dm.K + 60) / 121));
@@ -916,7 +918,7 @@ static int score_screen(const pmx_model *const *models, int n_models, const pmx_
             ws.ctl_used[ci] = true;
             // the first chunk's ligand kernel has the device to itself, the others share it with the rounds of the chunk before
             const uint32_t lig_grid = (uint32_t)ws.num_cu * ((overlap && !first_chunk) ? lig_waves : full);
-            const uint32_t task_grid = (uint32_t)ws.num_cu * std::min<uint32_t>(4u * PMX_TASK_WAVES, (overlap && !last_chunk) ? full - lig_waves : full);
+            const uint32_t task_grid = (uint32_t)ws.num_cu * ((overlap && !last_chunk) ? std::min<uint32_t>(pl.task_waves_per_cu, full - lig_waves) : pl.task_waves_per_cu);
             auto launch = [&](int mode, uint32_t blocks, hipStream_t on) {
                 p.mode = mode;
                 if (exact) ligand_kernel<G, true, false><<<dim3(blocks), dim3(64), pl.lds, on>>>(p);
