@@ -531,7 +531,7 @@ constexpr double kBoundSlack = 1.0 + 1e-9;
 #endif
 constexpr int kPathMinLevels = PMX_PATH_MIN_LEVELS;
 #ifndef PMX_PATH_WINDOWS
-#define PMX_PATH_WINDOWS 2
+#define PMX_PATH_WINDOWS 3
 #endif
 constexpr int kPathWindows = PMX_PATH_WINDOWS; // windows of 64 / G candidates whose loads go out together in path_bound() // path_bound() is asked where the frame's level and at least this many - 1 more lie below // covers the float64 rounding of the sums the bound is compared with
 
