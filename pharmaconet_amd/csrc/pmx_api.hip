@@ -865,6 +865,15 @@ static int score_screen(const pmx_model *const *models, int n_models, const pmx_
         // (32 / 64 conformer lanes: records of megabytes - 16 GB held the split trees of a 16 384-ligand chunk of the stress configuration
         // to within 3 %, and every tree past the end is walked by one wavefront alone)
         size_t arena_want = (size_t)std::max<long>(1, env_long("PMX_ARENA_MB", G >= 32 ? 32768 : 16384)) << 20;
+        if (!c.arena && !std::getenv("PMX_ARENA_MB")) { // first allocation, no explicit size: at most a third of what the device has free
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b / 3 < arena_want) {
+                arena_want = std::max<size_t>((size_t)1 << 30, (free_b / 3) & ~(((size_t)1 << 20) - 1));
+                c.arena_shrunk_to = arena_want;
+            } else {
+                (void)hipGetLastError();
+            }
+        }
         const size_t arena_min = std::min<size_t>((size_t)1 << 30, arena_want);
         if (c.arena_shrunk_to) arena_want = std::min(arena_want, std::max(c.arena_shrunk_to, arena_min));
         const size_t asked = arena_want;
