@@ -191,3 +191,55 @@ def test_screening_reads_a_directory_in_one_batch(golden, tmp_path, monkeypatch)
         desc = golden["molecules"][i]
         one = Ligand(fake_openbabel.Molecule(desc), np.asarray(desc["coords"], dtype=np.float32), conformer_axis=0)
         assert lib.record(k) == bytes(pack_ligand(one.features))
+
+
+def test_native_rules_equal_the_python_restatement_on_random_molecules(golden):
+    """4 000 random molecular graphs with random toolkit answers (elements, bonds, hybridisation, acceptor / donor flags, ring sets -
+    chemically meaningless on purpose: every rule sees neighbourhoods the fixture generator never drew): the native rules
+    (`pmx_perceive_features`) against the Python restatement that the 600 reference outputs pin as well (tests/perception_rules.py)."""
+    import perception_rules
+
+    from pharmaconet_amd.ligand import features_of, perceive_batch, toolkit_answers
+
+    # (the restatement is itself held to the reference first)
+    for desc, want in list(zip(golden["molecules"], golden["reference"]))[:100]:
+        pb = fake_openbabel.Molecule(desc)
+        pb.removeh()
+        assert [[t, _plain(a), _plain(c)] for t, a, c in perception_rules.perceive_features(pb)[2]] == want
+    rng = np.random.default_rng(20250930)
+    elements = np.array([6, 6, 6, 6, 7, 7, 8, 8, 9, 15, 16, 17, 35, 53])
+    descs = []
+    for _ in range(4000):
+        n = int(rng.integers(1, 24))
+        z = rng.choice(elements, size=n).tolist()
+        bonds = set()
+        for i in range(1, n):  # a random tree, then a few ring closures
+            if rng.random() < 0.9:
+                bonds.add((int(rng.integers(0, i)), i))
+        for _ in range(int(rng.integers(0, 4))):
+            a, b = sorted(rng.integers(0, n, size=2).tolist())
+            if a != b:
+                bonds.add((a, b))
+        order = list(bonds)
+        rng.shuffle(order)
+        rings = []
+        for _ in range(int(rng.integers(0, 3))):
+            if n >= 3:
+                ring = rng.choice(n, size=int(rng.integers(3, min(n, 7) + 1)), replace=False).tolist()
+                rings.append([ring, bool(rng.random() < 0.6)])
+        descs.append(dict(z=z, bonds=[list(b) if rng.random() < 0.5 else [b[1], b[0]] for b in order],
+                          acceptor=(rng.random(n) < 0.3).tolist(), donor=(rng.random(n) < 0.25).tolist(),
+                          hyb=rng.integers(1, 4, size=n).tolist(), rings=rings, rotors=0, coords=[np.zeros((n, 3)).tolist()]))
+    answers, want = [], []
+    for desc in descs:
+        pb = fake_openbabel.Molecule(desc)
+        pb.removeh()
+        want.append(perception_rules.perceive_features(pb)[2])
+        answers.append(toolkit_answers(pb))
+    flat = perceive_batch(answers, threads=4)
+    n_feat = 0
+    for i, w in enumerate(want):
+        assert features_of(flat, i) == w, f"molecule {i}: {descs[i]}"
+        n_feat += len(w)
+    kinds = {t for w in want for t, _, _ in w}
+    assert kinds == {"Hydrophobic", "Aromatic", "Cation", "Anion", "HBond_donor", "HBond_acceptor", "Halogen"} and n_feat > 20000
