@@ -1604,20 +1604,36 @@ struct Pos3 {
 // address arithmetic per load)
 typedef const __attribute__((address_space(1))) float *GlobalFloats;
 __device__ __forceinline__ void center_size(GlobalFloats xyz, int C, int start, int end, int cc, Pos3 &center, float &size) {
+    // (four nodes' coordinates per trip, added in node order as before: a load per coordinate, each waited for, made this two memory
+    // round trips per node of the cluster)
     float sx = 0.f, sy = 0.f, sz = 0.f;
-    for (int u = start; u < end; ++u) {
-        const uint32_t o = (uint32_t)(u * 3 * C + cc);
-        sx = sx + xyz[o];
-        sy = sy + xyz[o + C];
-        sz = sz + xyz[o + 2 * C];
+    for (int u0 = start; u0 < end; u0 += 4) {
+        float x[4], y[4], z[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t o = (uint32_t)(min(u0 + k, end - 1) * 3 * C + cc);
+            x[k] = xyz[o], y[k] = xyz[o + C], z[k] = xyz[o + 2 * C];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool in = u0 + k < end;
+            sx = in ? sx + x[k] : sx;
+            sy = in ? sy + y[k] : sy;
+            sz = in ? sz + z[k] : sz;
+        }
     }
     const float cnt = (float)(end - start);
     center = Pos3{sx / cnt, sy / cnt, sz / cnt};
     float mx = 0.f;
-    for (int u = start; u < end; ++u) {
-        const uint32_t o = (uint32_t)(u * 3 * C + cc);
-        const float r = norm3f(xyz[o] - center.x, xyz[o + C] - center.y, xyz[o + 2 * C] - center.z);
-        mx = (u == start || r > mx) ? r : mx;
+    for (int u0 = start; u0 < end; u0 += 4) {
+        float r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t o = (uint32_t)(min(u0 + k, end - 1) * 3 * C + cc);
+            r[k] = norm3f(xyz[o] - center.x, xyz[o + C] - center.y, xyz[o + 2 * C] - center.z);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) mx = (u0 + k == start || (u0 + k < end && r[k] > mx)) ? r[k] : mx;
     }
     size = mx;
 }
@@ -1667,9 +1683,13 @@ __device__ __forceinline__ void build_tables(const ScreenParams &p, unsigned cha
     auto stage_distances = [&](int a0, int na, int b0, int nb) { // dl[(u * nb + v) * G + c] = |x_(a0 + u) - x_(b0 + v)|
         lds_sync();                                              // (readers of the last pair's distances are done)
         const float inv_nb = 1.0f / (float)nb;
-        for (int pr = s; pr < na * nb; pr += SLOTS) {
+        for (int pr = s; pr < na * nb; pr += 2 * SLOTS) { // (two node pairs per trip: twelve coordinate loads in flight instead of six)
+            const int pr2 = pr + SLOTS < na * nb ? pr + SLOTS : pr;
             const int u = (int)(((float)pr + 0.5f) * inv_nb), v = pr - u * nb;
-            dl[pr * G + c] = node_distance(a0, u, b0, v);
+            const int u2 = (int)(((float)pr2 + 0.5f) * inv_nb), v2 = pr2 - u2 * nb;
+            const float d1 = node_distance(a0, u, b0, v), d2 = node_distance(a0, u2, b0, v2);
+            dl[pr * G + c] = d1;
+            dl[pr2 * G + c] = d2;
         }
         if (kStageLds) lds_sync();
         else wave_sync();
@@ -2057,15 +2077,25 @@ __device__ __forceinline__ void chain_lengths(const ScreenParams &p, unsigned ch
         const uint32_t kj = (uint32_t)uni(lk[j]), ksj = (uint32_t)uni((int)ksum[j]), ks1 = (uint32_t)uni((int)ksum[j + 1]);
         const uint32_t nd = L.ksumtot - ks1, row = (uint32_t)uni((int)rowbase[j]);
         const float inv_nd = 1.0f / (float)nd;
-        for (uint32_t e = (uint32_t)lane; e < kj * nd; e += 64u) {
-            const uint32_t a = (uint32_t)(((float)e + 0.5f) * inv_nd), xo = e - a * nd;
-            const unsigned char *ve = Vt + (size_t)(row + e) * VB;
-            bool v;
-            if (VB == 1) v = *ve != 0;
-            else if (VB == 2) v = *reinterpret_cast<const uint16_t *>(ve) != 0;
-            else if (VB == 4) v = *reinterpret_cast<const uint32_t *>(ve) != 0u;
-            else v = *reinterpret_cast<const unsigned long long *>(ve) != 0ull;
-            if (v) atomicMax(&dpl[ksj + a], dpl[ks1 + xo] + 1u);
+        for (uint32_t e0 = (uint32_t)lane; e0 < kj * nd; e0 += 256u) { // (four masks per lane and trip: their loads in flight together)
+            bool v[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; ++u) {
+                const uint32_t e = min(e0 + 64u * u, kj * nd - 1u);
+                const unsigned char *ve = Vt + (size_t)(row + e) * VB;
+                if (VB == 1) v[u] = *ve != 0;
+                else if (VB == 2) v[u] = *reinterpret_cast<const uint16_t *>(ve) != 0;
+                else if (VB == 4) v[u] = *reinterpret_cast<const uint32_t *>(ve) != 0u;
+                else v[u] = *reinterpret_cast<const unsigned long long *>(ve) != 0ull;
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; ++u) {
+                const uint32_t e = e0 + 64u * u;
+                if (e < kj * nd && v[u]) {
+                    const uint32_t a = (uint32_t)(((float)e + 0.5f) * inv_nd), xo = e - a * nd;
+                    atomicMax(&dpl[ksj + a], dpl[ks1 + xo] + 1u);
+                }
+            }
         }
     }
     sync();
@@ -2112,17 +2142,34 @@ __device__ __forceinline__ void build_bounds(const ScreenParams &p, unsigned cha
             // the levels above l from the nearest one up: what has been added when level j is reached is what (l, b) can add
             // apart from its pair entries with levels <= j - OB[j][(l, b)], path_bound()'s table
             double v = (double)St[(size_t)(ksl + b) * G + c];
-            for (int j = l - 1; j >= 0; --j) {
-                const int kj = uni(lk[j]);
-                const uint32_t nd_j = L.ksumtot - (uint32_t)uni((int)ksum[j + 1]);
+            // (two levels above l per trip, eight entries of each in flight: a maximum does not mind the last candidate being read again where
+            // fewer are left. One load at a time, each waited for, this loop was a memory round trip per candidate of every level above.)
+            for (int j = l - 1; j >= 0; j -= 2) {
+                const int j2 = j - 1; // (-1: level j is the last one)
+                const int kj = uni(lk[j]), kj2 = j2 >= 0 ? uni(lk[j2]) : 0;
+                const uint32_t nd_j = L.ksumtot - (uint32_t)uni((int)ksum[j + 1]), nd_j2 = L.ksumtot - (uint32_t)uni((int)ksum[j2 + 1]);
                 const uint32_t e0 = (uint32_t)uni((int)rowbase[j]) + (uint32_t)(ksl - uni((int)ksum[j + 1])) + (uint32_t)b; // entry((j, 0) -> (l, b))
-                if (cand_bounds<G>()) OBt[((size_t)j * L.ksumtot + (size_t)(ksl + b)) * G + c] = float_up(v);
-                float m = 0.f;
-                for (int a = 0; a < kj; ++a) {
-                    const float pv = Pt[(size_t)(e0 + (uint32_t)a * nd_j) * G + c];
-                    m = pv > m ? pv : m;
+                const uint32_t e02 = j2 >= 0 ? (uint32_t)uni((int)rowbase[j2]) + (uint32_t)(ksl - uni((int)ksum[j2 + 1])) + (uint32_t)b : e0;
+                float m = 0.f, m2 = 0.f;
+                for (int a0 = 0; a0 < max(kj, kj2); a0 += 8) {
+                    float pv[8], pw[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        pv[u] = Pt[(size_t)(e0 + (uint32_t)min(a0 + u, kj - 1) * nd_j) * G + c];
+                        pw[u] = j2 >= 0 ? Pt[(size_t)(e02 + (uint32_t)min(a0 + u, kj2 - 1) * nd_j2) * G + c] : 0.f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        m = pv[u] > m ? pv[u] : m;
+                        m2 = pw[u] > m2 ? pw[u] : m2;
+                    }
                 }
+                if (cand_bounds<G>()) OBt[((size_t)j * L.ksumtot + (size_t)(ksl + b)) * G + c] = float_up(v);
                 v += (double)m;
+                if (j2 >= 0) {
+                    if (cand_bounds<G>()) OBt[((size_t)j2 * L.ksumtot + (size_t)(ksl + b)) * G + c] = float_up(v);
+                    v += (double)m2;
+                }
             }
             if (cand_bounds<G>()) Wt[(size_t)(ksl + b) * G + c] = v; // base(l, b), replaced by the candidate's own bound below
             else OBt[(size_t)(ksl + b) * G + c] = float_up(v);          // BF: base(l, b) for path_bound_wide()
@@ -2171,23 +2218,39 @@ __device__ __forceinline__ void build_bounds(const ScreenParams &p, unsigned cha
                 const uint32_t nd_f = L.ksumtot - (uint32_t)uni((int)ksum[f + 1]);
                 const uint32_t e_fl = (uint32_t)uni((int)rowbase[f]) + (uint32_t)(ksl - uni((int)ksum[f + 1])); // entry((f, 0) -> (l, 0))
                 double uA = 0.0, uB = 0.0;
-                for (int b1 = 0; b1 < kl; ++b1) {
-                    const double base = Wt[(size_t)(ksl + b1) * G + c];
+                // (four candidates b1 of level l per trip, their loads in flight together - a maximum does not mind the last one being
+                // taken again where fewer are left; one at a time this loop was a memory round trip per deeper candidate and window)
+                constexpr int B1 = 4;
+                for (int b10 = 0; b10 < kl; b10 += B1) {
+                    double base[B1];
+                    float mf[B1], pA[B1], pB[B1];
+#pragma unroll
+                    for (int u = 0; u < B1; ++u) {
+                        base[u] = Wt[(size_t)(ksl + min(b10 + u, kl - 1)) * G + c];
+                        mf[u] = 0.f, pA[u] = 0.f, pB[u] = 0.f;
+                    }
                     // level f's entries against (l, b1): every slot reads its own candidates', the largest of all is what
                     // base(l, b1) counted for level f
-                    float mf = 0.f, pA = 0.f, pB = 0.f;
                     for (int a0 = 0; a0 < kf; a0 += SLOTS) {
                         const int a = a0 + s;
-                        const float pv = a < kf ? Pt[(size_t)(e_fl + (uint32_t)a * nd_f + (uint32_t)b1) * G + c] : 0.f;
-                        mf = pv > mf ? pv : mf;
-                        pA = a0 == b0 ? pv : pA;
-                        pB = a0 == b0 + SLOTS ? pv : pB;
+                        float pv[B1];
+#pragma unroll
+                        for (int u = 0; u < B1; ++u) pv[u] = a < kf ? Pt[(size_t)(e_fl + (uint32_t)a * nd_f + (uint32_t)min(b10 + u, kl - 1)) * G + c] : 0.f;
+#pragma unroll
+                        for (int u = 0; u < B1; ++u) {
+                            mf[u] = pv[u] > mf[u] ? pv[u] : mf[u];
+                            pA[u] = a0 == b0 ? pv[u] : pA[u];
+                            pB[u] = a0 == b0 + SLOTS ? pv[u] : pB[u];
+                        }
                     }
-                    mf = slot_max_f32<G>(mf); // (a NaN entry is passed over here as by the comparisons above)
-                    const double rest = base - (double)mf;
-                    const double valA = rest + (double)pA, valB = rest + (double)pB;
-                    uA = (pA > 0.f && valA > uA) ? valA : uA;
-                    uB = (pB > 0.f && valB > uB) ? valB : uB;
+#pragma unroll
+                    for (int u = 0; u < B1; ++u) {
+                        const float mfu = slot_max_f32<G>(mf[u]); // (a NaN entry is passed over here as by the comparisons above)
+                        const double rest = base[u] - (double)mfu;
+                        const double valA = rest + (double)pA[u], valB = rest + (double)pB[u];
+                        uA = (pA[u] > 0.f && valA > uA) ? valA : uA;
+                        uB = (pB[u] > 0.f && valB > uB) ? valB : uB;
+                    }
                 }
                 accA += uA;
                 accB += uB;
