@@ -16,8 +16,8 @@ REPO = PKG.parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libpmx.so"
 PACK_LIB = PKG / "libpmx_pack.so"  # the packer alone, host-only (no HIP / RCCL runtime)
-SOURCES = ("pmx_api.hip", "pmx_topk.hip", "pmx_density.hip", "pmx_pack.cpp", "pmx_sdf.cpp", "pmx_perceive.cpp")
-DEPS = ("pmx_screen.hip", "pmx_device.h")
+SOURCES = ("pmx_api.hip", "pmx_screen_debug.hip", "pmx_topk.hip", "pmx_density.hip", "pmx_pack.cpp", "pmx_sdf.cpp", "pmx_perceive.cpp")
+DEPS = ("pmx_screen.hip", "pmx_device.h", "pmx_debug.h")
 FLAGS = (
     "--offload-arch=gfx950",
     "-O3",
@@ -68,15 +68,21 @@ def build_native(force: bool = False, verbose: bool = False) -> Path:
 
 def _build(verbose: bool) -> Path:
     cc = hipcc()
-    objs = []
-    for src in SOURCES:
+    from concurrent.futures import ThreadPoolExecutor
+
+    extra = os.environ.get("PMX_CXXFLAGS", "").split()
+
+    def compile_one(src: str) -> str:
         obj = CSRC / (src.rsplit(".", 1)[0] + ".o")
-        extra = os.environ.get("PMX_CXXFLAGS", "").split()
         cmd = [cc, *FLAGS, *extra, f"-I{REPO / 'include'}", f"-I{CSRC}", "-c", str(CSRC / src), "-o", str(obj)]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
-        objs.append(str(obj))
+        return str(obj)
+
+    # (the two translation units that hold the screening kernels take a minute each: side by side)
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as pool:
+        objs = list(pool.map(compile_one, SOURCES))
     tmp = LIB.with_suffix(".so.tmp")
     rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
     # librccl is linked without an rpath: a process that has imported torch already holds torch's bundled RCCL / HIP runtime

@@ -20,6 +20,7 @@
 
 #include "pmx.h"
 #include "pmx_screen.hip"
+#include "pmx_debug.h"
 
 using namespace pmx;
 
@@ -735,6 +736,9 @@ static int score_screen(const pmx_model *const *models, int n_models, const pmx_
     const int task_decay_from = (int)std::max<long>(1, env_long("PMX_TASK_DECAY_FROM", 99));
     const uint32_t task_budget_min = (uint32_t)std::max<long>(8, env_long("PMX_TASK_BUDGET_MIN", 48));
     const bool exact = (flags & 8) != 0;
+    // any validation switch: the kernels of pmx_screen_debug.hip (libpmx's own read those bits as zero, pmx_screen.hip PMX_WFLAGS)
+    const bool debug_kernels = (flags & ~PMX_PRODUCT_FLAGS) != 0;
+    bool debug_ok = true;
     // Type weights further apart than PMX_TAILS_RATIO (default 16; the reference's defaults are 8 : 1, graph_match.py:32-40): pair items
     // evaluate rough cells term by term like self items do (item_finish<TAILS>, pmx_screen.hip) - slower, and only then.
     // PMX_PAIR_TAILS = 0 / 1 forces it off / on.
@@ -930,7 +934,7 @@ static int score_screen(const pmx_model *const *models, int n_models, const pmx_
             const uint32_t task_grid = (uint32_t)ws.num_cu * ((overlap && !last_chunk) ? std::min<uint32_t>(pl.task_waves_per_cu, full - lig_waves) : pl.task_waves_per_cu);
             auto launch = [&](int mode, uint32_t blocks, hipStream_t on) {
                 p.mode = mode;
-                if (exact) ligand_kernel<G, true, false><<<dim3(blocks), dim3(64), pl.lds, on>>>(p);
+                if (debug_kernels) debug_ok &= pmx_debug::launch_ligand(G, exact, tails, blocks, pl.lds, on, &p, sizeof p);
                 else if (tails) ligand_kernel<G, false, true><<<dim3(blocks), dim3(64), pl.lds, on>>>(p);
                 else ligand_kernel<G, false, false><<<dim3(blocks), dim3(64), pl.lds, on>>>(p);
             };
@@ -966,7 +970,8 @@ static int score_screen(const pmx_model *const *models, int n_models, const pmx_
                     p.budget = r < task_decay_from ? task_budget : std::max<uint32_t>(task_budget_min, task_budget >> std::min(r - task_decay_from + 1, 16));
                     p.last_round = r + 1 == rounds ? 1u : 0u;
                     round_kernel<<<dim3(1), dim3(64), 0, side>>>(c.ctl, p.qcap);
-                    task_kernel<G><<<dim3(task_grid), dim3(64), pl.lds, side>>>(p);
+                    if (debug_kernels) debug_ok &= pmx_debug::launch_task(G, task_grid, pl.lds, side, &p, sizeof p);
+                    else task_kernel<G><<<dim3(task_grid), dim3(64), pl.lds, side>>>(p);
                 }
                 finalize_kernel<G><<<dim3((super + 255) / 256), dim3(256), 0, side>>>(p);
                 p.last_round = 0;
@@ -999,6 +1004,7 @@ static int score_screen(const pmx_model *const *models, int n_models, const pmx_
         }
     }
     HIPCHECK(hipGetLastError());
+    if (!debug_ok) return fail(PMX_ERR_INVALID, "the validation kernels (pmx_screen_debug.hip) do not match this build's parameter block");
     if (overlap) // the call ends on the caller's stream
         for (ChunkSet &c : ws.set)
             if (c.pending) HIPCHECK(hipStreamWaitEvent(stream, c.tasks_done, 0));

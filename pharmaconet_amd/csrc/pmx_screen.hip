@@ -35,11 +35,26 @@
 // Everything is ordered on the caller's stream.
 #include <type_traits>
 
+// The kernels are compiled twice. libpmx's own (namespace pmx, pmx_api.hip) know two PMX_TREE_FLAGS switches - no budget (2) and tables
+// alone (16384) - and read every other bit as zero, so the walker and the table loops carry none of the validation switches (1.5 % of the
+// pass; as a template parameter in one translation unit the two sets of kernels cost each other registers). pmx_screen_debug.hip compiles
+// this file again as namespace pmx_dbg with every switch live; a call with any other bit set launches those.
+#ifndef PMX_NS
+#define PMX_NS pmx
+#endif
+#define PMX_PRODUCT_FLAGS (2u | 16384u)
+#ifdef PMX_DEBUG_KERNELS
+#define PMX_WFLAGS(p) ((p).flags)
+#else
+#define PMX_WFLAGS(p) ((p).flags & PMX_PRODUCT_FLAGS)
+#endif
+
 #include "pmx_device.h"
 
 #pragma clang fp contract(off)
 
-namespace pmx {
+namespace PMX_NS {
+using namespace pmx; // (pmx_device.h)
 
 // One cell of a tabulated pair function: value(t) = c0 + t (c1 + t (c2 + t (c3 + t (c4 + t c5)))), t in [0, 1) the position
 // inside the cell; the item passes the 2-sigma majority test of match_utils.py:56-61 iff lo <= d <= hi (lo = NaN: the pass
@@ -837,8 +852,8 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
     const uint32_t lane_off = (uint32_t)lane * 4u; // (s * G + c) floats: candidate nb + s, conformer c
     const int nl = w.nl;
     const unsigned char *Sb = w.Sb, *Pb = w.Pb, *Wb = w.Wb, *Vb = w.Vb;
-    const int bound_from = (p.flags & 4) ? 255 : 4; // matches on the path from which children are bound-tested
-    const bool no_filter = (p.flags & 128) != 0;
+    const int bound_from = (PMX_WFLAGS(p) & 4) ? 255 : 4; // matches on the path from which children are bound-tested
+    const bool no_filter = (PMX_WFLAGS(p) & 128) != 0;
 
     const uint32_t budget32 = (export_mode || budget > 0xfffffff0ull) ? 0xffffffffu : (uint32_t)budget; // (a walk of 2^32 passes does not end in this life)
     const int f0 = w.f0;
@@ -870,7 +885,7 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
             flush_dbg();
             return kOverBudget;
         }
-        if (rec16 != 0u && w.passes >= next_share && !(p.flags & 8192)) {
+        if (rec16 != 0u && w.passes >= next_share && !(PMX_WFLAGS(p) & 8192)) {
             next_share = w.passes + kShareEvery;
             PMX_COUNT(7, 1);
             if (s == 0) {
@@ -894,7 +909,7 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
         // ordered frames: of the candidates of a pass (a window of the frame's candidates) the walker visits the surviving child
         // with the largest bound first; rem = the slots of the window not visited yet, in lane f of stB
         constexpr bool ORD = G >= 2 && G <= 32;
-        const bool ordered0 = ORD && !leaf_level && !(hv & kLvFuse) && !(p.flags & 2048);
+        const bool ordered0 = ORD && !leaf_level && !(hv & kLvFuse) && !(PMX_WFLAGS(p) & 2048);
         uint32_t rem = 0xffffffffu;
         if (ORD) rem = (uint32_t)rl(w.stB, f);
         if (nb < kf) {
@@ -1004,7 +1019,7 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
             // Children with fewer than 5 matches are bound-tested too where the frame is ordered: nothing below a child that
             // fails can raise a maximum, so all the frame still needs from it is whether it reaches 5 matches (tree.py:98) -
             // nothing at all once another child has (max_num_matches is a maximum), else what probe() answers.
-            const bool shallow = ordered && cand_bounds<G>() && nm < 4 && bound_from != 255 && !(p.flags & 4096);
+            const bool shallow = ordered && cand_bounds<G>() && nm < 4 && bound_from != 255 && !(PMX_WFLAGS(p) & 4096);
             if ((bounded || shallow) && vb) { // drop the children that cannot raise a maximum
                 const double bp = pooled > w.best ? pooled : w.best;
                 ab = __ballot(valid && (t + rbound) * kBoundSlack > bp);
@@ -1108,7 +1123,7 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
                     const uint32_t n = (uint32_t)__popcll(heads);
                     // all subtrees of a ligand go to one shard, and the task wavefronts of one XCD drain one group of
                     // shards (task_kernel): the walkers that share a ligand's tables run side by side under one L2
-                    const uint32_t sh = (p.flags & 256) ? ((wave_id + (uint32_t)(w.passes >> 4)) & (kShards - 1)) : ((rec16 * 2654435761u) >> 26);
+                    const uint32_t sh = (PMX_WFLAGS(p) & 256) ? ((wave_id + (uint32_t)(w.passes >> 4)) & (kShards - 1)) : ((rec16 * 2654435761u) >> 26);
                     static_assert(kShards == 64, "shard hash");
                     // one atomic add reserves the records (no retry loop: the walkers of one ligand export to one shard at
                     // the same time); a reservation that crosses the end of the shard fills its part below the end
@@ -1172,7 +1187,7 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
                         const float key = alive ? fmaxf((float)(t + rbound), 0.f) : -1.f; // (a NaN total orders as 0)
                         const float top = wave_max_f32(key);
                         ss = (__ffsll(__ballot(alive && key == top)) - 1) / G;
-                        if (cand_bounds<G>() && (flags & kPath) && nl - f >= kPathMinLevels && !(p.flags & 1024)) {
+                        if (cand_bounds<G>() && (flags & kPath) && nl - f >= kPathMinLevels && !(PMX_WFLAGS(p) & 1024)) {
                             // the child with the largest W bound, against the bound its actual path gives (path_bound())
                             if (s == ss) tch[c] = t;
                             lds_sync();
@@ -1202,8 +1217,8 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
                         const unsigned long long before = ss == 0 ? 0ull : (vb & ((1ull << (ss * G)) - 1ull));
                         if (before) mx = mx > 1 ? mx : 1; // existing children dropped by the bound test return at least 1
                         if constexpr (G >= 32) {
-                            const bool shallow_w = nm < 4 && bound_from != 255 && !(p.flags & 4096) && !(p.flags & 262144);
-                            if ((bounded || shallow_w) && !(p.flags & 131072)) { // the path-aware test of these shapes: children that passed the level bound, and children with fewer than 5 matches
+                            const bool shallow_w = nm < 4 && bound_from != 255 && !(PMX_WFLAGS(p) & 4096) && !(PMX_WFLAGS(p) & 262144);
+                            if ((bounded || shallow_w) && !(PMX_WFLAGS(p) & 131072)) { // the path-aware test of these shapes: children that passed the level bound, and children with fewer than 5 matches
                                 go = path_bound_wide<G>(w, t, s == ss, pool, f, nm, rl(bvec, ss * G), (vb >> (ss * G)) & GM);
                                 ++w.npath;
                                 if (!go) {
@@ -1769,7 +1784,7 @@ __device__ __forceinline__ void build_tables(const ScreenParams &p, unsigned cha
                 pf[G + c] = lsize;
             }
             const bool staged = ni * nj <= dcap;
-            const bool dead_test = staged && ni <= 64 && nj <= 64 && !(p.flags & 65536u);
+            const bool dead_test = staged && ni <= 64 && nj <= 64 && !(PMX_WFLAGS(p) & 65536u);
             PMX_TICK(1);
             if (staged) stage_distances(si, ni, sj, nj);
             else lds_sync();
@@ -2061,7 +2076,7 @@ __device__ __forceinline__ void chain_lengths(const ScreenParams &p, unsigned ch
     constexpr bool kInLds = totals_in_lds<G>();
     uint32_t *dpl = kInLds ? reinterpret_cast<uint32_t *>(lds + ws.off_tch) : reinterpret_cast<uint32_t *>(p.totbuf + (size_t)blockIdx.x * kTotBufBytes);
     const uint32_t cap = kInLds ? (ws.bytes - ws.off_tch) / 4u : kTotBufBytes / 4u;
-    if (L.ksumtot > cap || (p.flags & (4u | 32768u))) {
+    if (L.ksumtot > cap || (PMX_WFLAGS(p) & (4u | 32768u))) {
         for (uint32_t x = (uint32_t)lane; x < L.ksumtot; x += 64u) DPt[x] = 255;
         return;
     }
@@ -2127,7 +2142,7 @@ __device__ __forceinline__ void build_bounds(const ScreenParams &p, unsigned cha
 #endif
     chain_lengths<G>(p, lds, ws, L, rec);
     PMX_TICK(5);
-    if (p.flags & 4) { // debug: nothing is ever dropped
+    if (PMX_WFLAGS(p) & 4) { // debug: nothing is ever dropped
         for (int l = s; l <= nl; l += SLOTS) Rt[(size_t)l * G + c] = __builtin_inf();
         if (cand_bounds<G>())
             for (uint32_t e = s; e < L.ksumtot; e += SLOTS) Wt[(size_t)e * G + c] = __builtin_inf();
@@ -2196,7 +2211,7 @@ __device__ __forceinline__ void build_bounds(const ScreenParams &p, unsigned cha
         const uint32_t wf = ((uint32_t)uni(lk[f]) + SLOTS - 1) / SLOTS;
         cost += wf * wf * (L.ksumtot - (uint32_t)uni((int)ksum[f + 1]));
     }
-    if ((p.flags & 512) || cost > p.bound_cost) {
+    if ((PMX_WFLAGS(p) & 512) || cost > p.bound_cost) {
         for (int f = 0; f < nl; ++f) {
             const int kf = uni(lk[f]), ksf = uni(ksum[f]);
             const double r = Rt[(size_t)(f + 1) * G + c];
@@ -2423,13 +2438,13 @@ __device__ __forceinline__ bool prepare_walk(const ScreenParams &p, unsigned cha
     w.ksumtot = ksumtot;
     // path_bound() keeps a row of pair sums per candidate and match count in the wave's buffer: used when they fit
     // (and the table word X holds a pair entry number in 20 bits)
-    w.path_on = cand_bounds<G>() && !(p.flags & (4u | 1024u)) && (uint64_t)(nl + 1) * ksumtot * G * 4u <= (uint64_t)p.pa_bytes && T < (1u << 20);
+    w.path_on = cand_bounds<G>() && !(PMX_WFLAGS(p) & (4u | 1024u)) && (uint64_t)(nl + 1) * ksumtot * G * 4u <= (uint64_t)p.pa_bytes && T < (1u << 20);
     {
         const int kl = lane < nl ? (int)H->k[lane] : 0, knext = lane + 1 < nl ? (int)H->k[lane + 1] : 0;
         const int tci = nl - 3 - lane;
         int kind = lane == nl - 1 ? kLvLeaf : 0;
-        if (lane == nl - 2 && knext <= 64 / G && !(p.flags & 32)) kind |= kLvFuse;
-        if (totals_in_lds<G>() && tci >= 0 && tci < kTcLevels && kl <= 64 / G && !(p.flags & 64)) kind |= kLvCache | (tci << 12);
+        if (lane == nl - 2 && knext <= 64 / G && !(PMX_WFLAGS(p) & 32)) kind |= kLvFuse;
+        if (totals_in_lds<G>() && tci >= 0 && tci < kTcLevels && kl <= 64 / G && !(PMX_WFLAGS(p) & 64)) kind |= kLvCache | (tci << 12);
         w.hk = kl | kind;
     }
     w.hks = lane <= nl ? (int)H->ksum[lane] : 0;
@@ -2452,7 +2467,7 @@ __device__ __forceinline__ bool prepare_walk(const ScreenParams &p, unsigned cha
     else w.stB = -1;
     w.stC = wl(w.stC, f0, (((nm0 ? (int)kMatched : 0) | (w.path_on ? (int)kPath : 0)) << 16) | (nm0 << 24));
     wave_sync();
-    if (!(p.flags & 4) && f0 < nl && nm0 >= 5) {
+    if (!(PMX_WFLAGS(p) & 4) && f0 < nl && nm0 >= 5) {
         const double r = *reinterpret_cast<const double *>(w.Rb + ((size_t)f0 * G + c) * 8);
         const double t = tot[nm0 * G + c];
         if (__ballot(((mask0 >> c) & 1ull) && (t + r) * kBoundSlack > __longlong_as_double((long long)pool[c])) == 0) return false;
@@ -2480,7 +2495,7 @@ __device__ __forceinline__ void run_job(const ScreenParams &p, unsigned char *ld
     float *pa = reinterpret_cast<float *>(p.pabuf + (size_t)blockIdx.x * p.pa_bytes);
     float *ub = reinterpret_cast<float *>(lds + ws.off_ub);
     const unsigned long long t_d = __builtin_amdgcn_s_memtime();
-    unsigned long long budget = ((p.flags & 2) || p.last_round) ? ~0ull : (unsigned long long)p.budget;
+    unsigned long long budget = ((PMX_WFLAGS(p) & 2) || p.last_round) ? ~0ull : (unsigned long long)p.budget;
     bool export_mode = false, split = is_task;
     for (;;) {
         const int rc = walk<G>(w, p, tot, pool, pathbuf, tch, tc, cbl, pa, ub, rec16, export_mode, budget, wave_id, stat);
@@ -2602,7 +2617,7 @@ __global__ __launch_bounds__(64, PMX_SCREEN_WAVES) void ligand_kernel(const Scre
         const unsigned char *root = lds + ws.off_task;
         const uint32_t rec16 = (uint32_t)uni((int)reinterpret_cast<const TaskRec *>(root)->rec16);
         Walk<G> w;
-        if (!(p.flags & 16384) && prepare_walk<G>(p, lds, ws, root, rec, w)) run_job<G>(p, lds, ws, w, rec, rec16, false, wave_id, stat);
+        if (!(PMX_WFLAGS(p) & 16384) && prepare_walk<G>(p, lds, ws, root, rec, w)) run_job<G>(p, lds, ws, w, rec, rec16, false, wave_id, stat);
     }
     wave_sync();
     if (lane0 == 0) flush_wave_stats(p, stat, wave_id, __builtin_amdgcn_s_memtime() - t_start);
@@ -2803,4 +2818,4 @@ __global__ void library_stats_kernel(DevLibrary lib, uint8_t *data_rw, uint64_t 
     }
 }
 
-} // namespace pmx
+} // namespace PMX_NS
