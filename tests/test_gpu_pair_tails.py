@@ -185,6 +185,11 @@ def test_pair_entries_with_one_item_in_the_tails_match_the_oracle(name, max_pair
     dmax = float(np.nanmax(flat.edge_mean.astype(np.float64) + 7.0 * flat.edge_std.astype(np.float64))) + 5.0
     rng = np.random.default_rng(20250929)
     pairs = [(a, b) for a in range(flat.num_clusters) for b in range(a + 1, flat.num_clusters)]
+    # The suite takes a seeded sample of the cluster pairs (the whole sweep - 55 + 153 + 160 pairs, four minutes with the oracle on 256 host
+    # threads - runs with PMX_FULL_SWEEPS=1 and is what DESIGN.md section 5 quotes).
+    if not os.environ.get("PMX_FULL_SWEEPS"):
+        max_pairs = min(max_pairs, 36)
+    n_all = len(pairs)
     if len(pairs) > max_pairs:
         pairs = [pairs[i] for i in sorted(rng.choice(len(pairs), size=max_pairs, replace=False))]
     threads = os.cpu_count() or 8
@@ -215,7 +220,7 @@ def test_pair_entries_with_one_item_in_the_tails_match_the_oracle(name, max_pair
         print(f"{name} [{wname}]: {len(pairs)} cluster pairs, {st['n_scores']} scores above {FLOOR:g}, {st['n_valid']} ligands with a valid pair entry, "
               f"{st['n_exactv']} items term by term; max rel err {st['worst']:.2e} at {st['at']}")
     for wname, st in acc.items():
-        assert st["n_valid"] >= 1000, f"[{wname}] the sweep does not reach valid pair entries"
+        assert st["n_valid"] >= 1000 * len(pairs) // n_all, f"[{wname}] the sweep does not reach valid pair entries"
         assert st["worst"] <= RTOL, f"[{wname}] max rel err {st['worst']:.3e} at (a, b, oracle score) = {st['at']}"
 
 
