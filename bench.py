@@ -267,8 +267,16 @@ def issue_block(n_lig, pass_ms):
     cus, clock_hz = 256, 2.4e9
     scalar_ms = salu * n_lig / cus / clock_hz * 1e3          # one scalar wave-instruction per cycle and CU
     vector_ms = valu * n_lig * 2 / (4 * cus) / clock_hz * 1e3  # a wave64 VALU instruction holds one of 4 SIMD-32s for 2 cycles
-    return {"scalar_insts_per_ligand": salu, "vector_insts_per_ligand": valu, "scalar_unit_busy": scalar_ms / pass_ms,
-            "vector_units_busy": vector_ms / pass_ms, "pass_ms": pass_ms,
+    out = {"scalar_insts_per_ligand": salu, "vector_insts_per_ligand": valu, "scalar_unit_busy": scalar_ms / pass_ms,
+           "vector_units_busy": vector_ms / pass_ms, "pass_ms": pass_ms, "priced_at_clock_hz": clock_hz}
+    # the same against the clock the profile measured under this load, with the branches (they are issued from the same scalar stream)
+    if all("SQ_INSTS_BRANCH" in v for v in prof["counters"].values()) and prof.get("clock", {}).get("clock_hz"):
+        branches = sum(v["SQ_INSTS_BRANCH"] for v in prof["counters"].values()) / per
+        measured = float(prof["clock"]["clock_hz"])
+        out.update({"branches_per_ligand": branches, "measured_clock_hz": measured,
+                    "scalar_unit_busy_at_measured_clock": salu * n_lig / cus / measured * 1e3 / pass_ms,
+                    "scalar_and_branch_issue_at_measured_clock": (salu + branches) * n_lig / cus / measured * 1e3 / pass_ms})
+    return {**out,
             "from_profile": src,
             "note": "instruction counts are NOT measured in this run: they come from the committed rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_VALU pass of the same build of csrc/ (checked by content hash), priced at this run's pass time"}
 

@@ -89,7 +89,20 @@ def main():
         k = row["Kernel_Name"]
         if "pmx::" in k and ("ligand_kernel" in k or "task_kernel" in k):
             sq[short(k).replace("pmx::", "")][row["Counter_Name"]] += float(row["Counter_Value"])
-    json.dump({"source": "rocprofv3 --pmc SQ_* (one profiler run) of bench.py --ligands 200000 --steps 1 --warmup 0; SQ_WAVE_CYCLES, "
+    clock = None
+    grbm_dir = sq_dir.parent / "pmc_GRBM"  # (tools/profile_round.sh; absent in older sets)
+    if grbm_dir.is_dir():
+        cyc = ms = 0.0
+        for row in csv.DictReader(open(next(grbm_dir.glob("*counter_collection.csv")))):
+            if "pmx::ligand_kernel" in row["Kernel_Name"] and row["Counter_Name"] == "GRBM_GUI_ACTIVE":
+                cyc += float(row["Counter_Value"])
+        for row in csv.DictReader(open(next(grbm_dir.glob("*kernel_trace.csv")))):
+            if "pmx::ligand_kernel" in row["Kernel_Name"]:
+                ms += (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6
+        if cyc and ms:
+            clock = {"GRBM_GUI_ACTIVE": cyc, "kernel_ms": ms, "kernel": "ligand_kernel launches of the same command under --pmc GRBM_GUI_ACTIVE --kernel-trace", "xcds": 8,
+                     "clock_hz": cyc / 8 / (ms * 1e-3), "note": "GRBM_GUI_ACTIVE summed over the 8 XCDs / kernel time: an upper estimate of the shader clock under this load"}
+    json.dump({**({"clock": clock} if clock else {}), "source": "rocprofv3 --pmc SQ_* (one profiler run) of bench.py --ligands 200000 --steps 1 --warmup 0; SQ_WAVE_CYCLES, "
                          "SQ_WAIT_* and SQ_ACTIVE_* count quad-cycles; totals over the run's engine passes (SQ_WAVES / 18432 = passes)",
                "ligands": n_lig, "passes": n_pass, "csrc_sha16": sha, "counters": sq},
               open(PROF / f"{TAG}_pmc_sq_summary.json", "w"), indent=1)

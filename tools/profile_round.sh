@@ -15,7 +15,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- pytho
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -o p -- python $ROOT/bench.py --ligands 200000 --steps 1 --warmup 0 --no-cpu-baseline --no-serial-leg --no-parity-sample > $OUT/pmc_$c.log 2>&1
 done
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES --output-format csv -d $OUT/pmc_SQ -o p -- python $ROOT/bench.py --ligands 200000 --steps 1 --warmup 0 --no-cpu-baseline --no-serial-leg --no-parity-sample > $OUT/pmc_SQ.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_BRANCH SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES --output-format csv -d $OUT/pmc_SQ -o p -- python $ROOT/bench.py --ligands 200000 --steps 1 --warmup 0 --no-cpu-baseline --no-serial-leg --no-parity-sample > $OUT/pmc_SQ.log 2>&1
+# the shader clock under this load: GRBM_GUI_ACTIVE (summed over the XCDs) over the kernels' time (collect_profiles.py: "clock" of the SQ summary)
+rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_GRBM -o p -- python $ROOT/bench.py --ligands 200000 --steps 1 --warmup 0 --no-cpu-baseline --no-serial-leg --no-parity-sample > $OUT/pmc_GRBM.log 2>&1
 # BASELINE configs[3] (16 pockets, per-GPU shard) and configs[4] (stress model, 64 conformers): the driver-reproducible lines
 python $ROOT/bench.py --model stress64 --steps 3 --warmup 1 > $OUT/bench_stress64.json 2> $OUT/bench_stress64.err
 python $ROOT/bench.py --pockets 16 --ligands 200000 --steps 1 --warmup 1 --no-serial-leg > $OUT/bench_pockets16.json 2> $OUT/bench_pockets16.err
