@@ -715,7 +715,15 @@ __device__ __forceinline__ bool path_bound(const Walk<G> &w, const ScreenParams 
     const unsigned char *LV = w.OBb + (size_t)nl * ksumtot * G * 4u;
     const float *pin = pa + (size_t)nm * ksumtot * G;
     float *pout = pa + (size_t)(nm + 1) * ksumtot * G;
+#ifdef PMX_PATH_FLATSUM
+    // (every level's maximum cleared and added up with the lanes spread over the array - no loop over the levels in the scalar unit; the
+    // levels down to f stay 0)
+#pragma unroll
+    for (int i = 0; i < PMX_MAX_LEVELS * G; i += 64)
+        if (i + lane < PMX_MAX_LEVELS * G) ub[i + lane] = 0.f;
+#else
     for (int i = lane; i < (nl - f - 1) * G; i += 64) ub[(f + 1) * G + i] = 0.f;
+#endif
     lds_sync();
     // kPathWindows windows of SLOTS candidates per trip, everything of a window in one round of loads (the entries of Y with the deeper
     // candidates are one contiguous run: no lookup in front of the pair rows)
@@ -744,7 +752,14 @@ __device__ __forceinline__ bool path_bound(const Walk<G> &w, const ScreenParams 
     }
     lds_sync();
     float below = 0.f;
+#ifdef PMX_PATH_FLATSUM
+#pragma unroll
+    for (int i = 0; i < PMX_MAX_LEVELS * G; i += 64) below = below + (i + lane < PMX_MAX_LEVELS * G ? ub[i + lane] : 0.f); // (element i + lane is conformer lane % G: 64 is a multiple of G)
+#pragma unroll
+    for (int st = G; st < 64; st <<= 1) below = below + __shfl_xor(below, st); // non-negative terms in another order: still an upper bound under the factor below
+#else
     for (int l = f + 1; l < nl; ++l) below = below + ub[l * G + c];
+#endif
     const double bound = (double)below * (1.0 + 4e-6);
     const double pooled = __longlong_as_double((long long)pool[c]);
     const double bp = pooled > w.best ? pooled : w.best;
@@ -1183,11 +1198,15 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
                     bool go = true;           // (false: the chosen child fails the path-aware bound test and is dropped)
                     unsigned child_path = 0u; // kPath if the child's path sums are in the wave's buffer
                     if (ordered) {
+                      // A child that fails the path-aware test is dropped and the next survivor of the same pass is tried at once: nothing the
+                      // next trip round the loop would work out again (the pass from the cache or the tables, its bound test) has changed.
+                      const bool path_test = cand_bounds<G>() && (flags & kPath) && nl - f >= kPathMinLevels && !(PMX_WFLAGS(p) & 1024);
+                      for (;;) {
                         const bool alive = (ab >> lane) & 1ull;
                         const float key = alive ? fmaxf((float)(t + rbound), 0.f) : -1.f; // (a NaN total orders as 0)
                         const float top = wave_max_f32(key);
                         ss = (__ffsll(__ballot(alive && key == top)) - 1) / G;
-                        if (cand_bounds<G>() && (flags & kPath) && nl - f >= kPathMinLevels && !(PMX_WFLAGS(p) & 1024)) {
+                        if (path_test) {
                             // the child with the largest W bound, against the bound its actual path gives (path_bound())
                             if (s == ss) tch[c] = t;
                             lds_sync();
@@ -1212,6 +1231,10 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
                             probe_slot = ss;
                             probe_rem_done = true;
                         }
+                        if (go || probe_slot >= 0 || !(ab & ~(GM << (ss * G)))) break;
+                        ab &= ~(GM << (ss * G)); // (the dropped child leaves the survivors; the trip this saves counts as a pass)
+                        ++w.passes;
+                      }
                     } else {
                         ss = (__ffsll(ab) - 1) / G;
                         const unsigned long long before = ss == 0 ? 0ull : (vb & ((1ull << (ss * G)) - 1ull));
