@@ -715,15 +715,7 @@ __device__ __forceinline__ bool path_bound(const Walk<G> &w, const ScreenParams 
     const unsigned char *LV = w.OBb + (size_t)nl * ksumtot * G * 4u;
     const float *pin = pa + (size_t)nm * ksumtot * G;
     float *pout = pa + (size_t)(nm + 1) * ksumtot * G;
-#ifdef PMX_PATH_FLATSUM
-    // (every level's maximum cleared and added up with the lanes spread over the array - no loop over the levels in the scalar unit; the
-    // levels down to f stay 0)
-#pragma unroll
-    for (int i = 0; i < PMX_MAX_LEVELS * G; i += 64)
-        if (i + lane < PMX_MAX_LEVELS * G) ub[i + lane] = 0.f;
-#else
     for (int i = lane; i < (nl - f - 1) * G; i += 64) ub[(f + 1) * G + i] = 0.f;
-#endif
     lds_sync();
     // kPathWindows windows of SLOTS candidates per trip, everything of a window in one round of loads (the entries of Y with the deeper
     // candidates are one contiguous run: no lookup in front of the pair rows)
@@ -752,14 +744,7 @@ __device__ __forceinline__ bool path_bound(const Walk<G> &w, const ScreenParams 
     }
     lds_sync();
     float below = 0.f;
-#ifdef PMX_PATH_FLATSUM
-#pragma unroll
-    for (int i = 0; i < PMX_MAX_LEVELS * G; i += 64) below = below + (i + lane < PMX_MAX_LEVELS * G ? ub[i + lane] : 0.f); // (element i + lane is conformer lane % G: 64 is a multiple of G)
-#pragma unroll
-    for (int st = G; st < 64; st <<= 1) below = below + __shfl_xor(below, st); // non-negative terms in another order: still an upper bound under the factor below
-#else
     for (int l = f + 1; l < nl; ++l) below = below + ub[l * G + c];
-#endif
     const double bound = (double)below * (1.0 + 4e-6);
     const double pooled = __longlong_as_double((long long)pool[c]);
     const double bp = pooled > w.best ? pooled : w.best;

@@ -69,6 +69,8 @@ def main():
             print(f"{setting or '(default)':60s} {best * 1e3:8.2f} ms {n_conf / best / 1e6:7.2f} M/s | lig {st['ms_ligand']:6.1f} tasks {st['ms_tasks']:5.1f} | "
                   f"frames {st['n_frames'] / n:6.1f} passes {st['n_passes'] / n:6.1f} tasks/lig {st['n_tasks'] / n:5.2f} over {st['n_heavy'] / n:5.3f} max {st['max_passes']} "
                   f"qovf {st['queue_overflow']} | {same}", flush=True)
+            if any(st.get("dbg", [])):  # instrumented builds (-DPMX_COUNTERS / _TICKS): the walker's counters per ligand
+                print("    dbg/ligand:", [round(x / n, 2) for x in st["dbg"]], "path tests", round(st.get("n_path_bounds", 0) / n, 1), "drops", round(st.get("n_path_drops", 0) / n, 1), flush=True)
         finally:
             for k, v in saved.items():
                 if v is None:
