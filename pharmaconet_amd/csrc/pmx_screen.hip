@@ -427,7 +427,7 @@ __global__ void fn_build_kernel(DevModel M, Weights W, const uint32_t *sub_off, 
 // Frames nl - 3 .. nl - 2 - kTcLevels keep their children's totals in LDS: when the walker comes back to such a frame the
 // remaining candidates are taken from there instead of being evaluated again (a third of all passes were re-evaluations).
 #ifndef PMX_TC_LEVELS
-#define PMX_TC_LEVELS 3
+#define PMX_TC_LEVELS 4
 #endif
 constexpr int kTcLevels = PMX_TC_LEVELS;
 static_assert(kTcLevels >= 1 && kTcLevels <= 8, "cache slot number is three bits of Walk::hk");
@@ -461,13 +461,18 @@ __host__ __device__ inline WaveShape<G> wave_shape(int K, int max_nodes) {
     o += task_rec_bytes<G>();
     o = (o + 15u) & ~15u;
     w.off_tch = o; // totals of a frame's children (fused last two levels)
-    o += 64 * 8;
+    // path_bound() keeps the tested child's totals in the first G entries and nothing else of this block: its level maxima live behind them
+    // (the fused block, which fills all 64 entries, and path_bound() never run inside one another) - the room that saves is a fourth cached level
+    {
+        uint32_t blk = 64 * 8;
+        if (cand_bounds<G>()) blk = blk > (uint32_t)(G * 8 + PMX_MAX_LEVELS * G * 4) ? blk : (uint32_t)(G * 8 + PMX_MAX_LEVELS * G * 4);
+        o += blk;
+    }
     w.off_tc = o; // the children's totals of the kTcLevels deepest unfused frames + their validity ballots
     if (totals_in_lds<G>()) o += kTcLevels * (64 * 8 + 8);
     w.off_cb = o; // candidates of a filtered frame that are still to visit, one 64-bit set per level (32 / 64 conformer lanes)
     if (64 / G <= 2) o += PMX_MAX_LEVELS * 8;
-    w.off_ub = o; // path_bound(): the most a level can add, per conformer
-    if (cand_bounds<G>()) o += PMX_MAX_LEVELS * G * 4;
+    w.off_ub = w.off_tch + G * 8; // path_bound(): the most a level can add, per conformer (inside the block of the children's totals, see above)
     w.bytes = o;
     return w;
 }
