@@ -32,6 +32,11 @@ FLAGS = (
     # trades address arithmetic for live registers they do not have (tools/build_variant.py A/B runs, HISTORY.md round 5)
     "-mllvm", "-simplifycfg-sink-common=false",
     "-mllvm", "-disable-lsr",
+    # [MI355X] 100.5-100.7 -> 99.3-99.7 ms: the greedy allocator takes the register class of a live range before its globalness
+    # (the scalar ranges of the walker's loop are assigned before the many short vector ones; A/B twice on one box, HISTORY.md round 5)
+    "-mllvm", "-greedy-regclass-priority-trumps-globalness",
+    # [MI355X] 99.5-99.9 -> 99.0 ms (twice): SimplifyCFG folds a two-entry phi into a select only when one instruction has to be speculated
+    "-mllvm", "-phi-node-folding-threshold=1",
 )
 
 

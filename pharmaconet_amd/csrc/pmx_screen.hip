@@ -871,7 +871,10 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
     // The walkers of a split ligand (its subtrees, and the walk that queued them) trade maxima through the ligand's record
     // while they run, not only when they end: one returning atomic maximum per conformer every kShareEvery passes gives this
     // wave's maxima to the others and theirs to this wave's bound test. (Maxima of leaves of the same tree: exact.)
-    constexpr uint32_t kShareEvery = 16;
+#ifndef PMX_SHARE_EVERY
+#define PMX_SHARE_EVERY 16
+#endif
+    constexpr uint32_t kShareEvery = PMX_SHARE_EVERY;
     uint32_t next_share = w.passes + kShareEvery;
 #ifdef PMX_COUNTERS
     uint32_t dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // fused passes | fused children | cached passes | leaf passes | other passes from the tables | descents | ancestors over table passes | shares
