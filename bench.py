@@ -50,16 +50,15 @@ WORKLOADS = {
 
 
 def csrc_digest():
-    """sha256 over the device sources (csrc/*.hip, csrc/*.h): a committed profile summary is quoted only for the kernels it was taken on."""
-    import hashlib
+    """Content hash of the device sources (csrc/*.hip, csrc/*.h) + compile flags libpmx.so was BUILT from - the stamp pharmaconet_amd/build.py
+    writes next to the library - so that a committed profile summary is quoted only for the kernels it was taken on. An A/B library
+    (PMX_LIBPMX) has no stamp of its own: "variant", which matches no committed profile."""
+    from pharmaconet_amd.build import read_stamp
 
-    from pharmaconet_amd.build import FLAGS
-
-    h = hashlib.sha256(" ".join(FLAGS).encode())  # (the compile flags are part of the build: two -mllvm switches are worth 10 % of a pass)
-    for f in sorted((REPO / "pharmaconet_amd" / "csrc").iterdir()):
-        if f.suffix in (".hip", ".h"):
-            h.update(f.name.encode() + b"\0" + f.read_bytes())
-    return h.hexdigest()[:16]
+    if os.environ.get("PMX_LIBPMX"):
+        return "variant:" + Path(os.environ["PMX_LIBPMX"]).name
+    stamp = read_stamp()
+    return stamp["csrc_sha16"] if stamp else "unstamped"
 
 
 def committed_profile(name):
@@ -98,6 +97,27 @@ def start_ranks(args):
     log("bench.py: starting", args.gpus, "ranks:", " ".join(cmd))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     sys.exit(subprocess.call(cmd, env=env))
+
+
+def build_survey_library(model, n_ligands, n_conf, rank, device, active_fraction=0.1):
+    """`--library survey`: SURVEY.md 8d-2's generator (tools/survey_library.py) - every ligand an independent draw from its own
+    counter-based stream, n ~ clip(N(20, 6), 4, 32), conformer sigma 0.5 A, 10 % on the model's nodes (sigma 0.7 A) - made on the device;
+    rank r holds ligands [r N, (r + 1) N) of the one library."""
+    import torch
+
+    from pharmaconet_amd.constants import TYPE_ID
+    from pharmaconet_amd.engine import DeviceLibrary
+    from tools.survey_library import survey_library
+
+    st = model.__getstate__()
+    centers = np.array([n["center"] for n in st["nodes"]], dtype=np.float64)
+    types = np.array([TYPE_ID[n["type"]] for n in st["nodes"]])
+    t0 = time.time()
+    offsets, data, stats = survey_library(centers, types, n_ligands, n_conf, device, first=rank * n_ligands, active_fraction=active_fraction)
+    lib = DeviceLibrary.from_device_buffers(offsets, data, device)
+    torch.cuda.synchronize()
+    log(f"[rank {rank}] survey library: {n_ligands} independent ligands, {lib.num_bytes / 1e9:.2f} GB, {stats}, built in {time.time() - t0:.1f}s")
+    return lib, offsets, data, stats
 
 
 def build_library(model, n_ligands, n_conf, base_count, rank, device, active_fraction=0.1, seed=None):
@@ -182,14 +202,61 @@ def host_sample(offsets, data, index):
     return PackedLibrary.from_records(recs)
 
 
-def cpu_baseline(pockets, offsets, data, n_conf, budget_s=10.0):
+def host_cores():
+    """Cores this process may actually use: the affinity mask capped by the cgroup's CPU quota (cpu.max = "quota period": the GPU
+    boxes show 256 hardware threads and grant 16 cores' worth of time - os.cpu_count() is not what OpenMP gets)."""
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except Exception:
+        affinity = os.cpu_count() or 1
+    info = {"hardware_threads": os.cpu_count() or 1, "affinity": affinity, "cgroup_cpu_max": None}
+    cores = affinity
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            text = Path(path).read_text().split()
+            if path.endswith("cpu.max"):
+                info["cgroup_cpu_max"] = " ".join(text)
+                if text[0] != "max":
+                    cores = min(cores, max(1, int(int(text[0]) / int(text[1]) + 0.5)))
+            else:
+                quota = int(text[0])
+                period = int(Path("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read_text())
+                info["cgroup_cpu_max"] = f"{quota} {period}"
+                if quota > 0:
+                    cores = min(cores, max(1, int(quota / period + 0.5)))
+            break
+        except Exception:
+            continue
+    try:
+        for ln in Path("/proc/cpuinfo").read_text().splitlines():
+            if ln.startswith("model name"):
+                info["cpu_model"] = ln.split(":", 1)[1].strip()
+                break
+    except Exception:
+        pass
+    info["usable_cores"] = cores
+    return cores, info
+
+
+def reference_rate():
+    """The reference's own NumPy path (`GraphMatcher.run()` imported from /root/reference, one process) timed in the BUILD container on the
+    golden ligands - it cannot run on the GPU box (tools/reference_rate.py writes the file). A quoted, static number."""
+    try:
+        return json.loads((REPO / "profiles" / "reference_numpy_rate.json").read_text())
+    except Exception:
+        return None
+
+
+def cpu_baseline(pockets, offsets, data, n_conf, budget_s=12.0):
     """Time the CPU oracle (oracle/, a port of the reference's algorithm pinned to its outputs) on a bounded sample of the same
-    library: with every host core, and with one (`screening.py --cpus N` / `--cpus 1`)."""
+    library: with every core this process may use (`host_cores`), and with one (`screening.py --cpus N` /
+    `--cpus 1`). The all-core sample holds at least 256 ligands per thread so that no thread idles behind a heavy ligand for long
+    (the top 1 % of the ligands are a third of the tree nodes)."""
     from oracle import oracle as orc
     from pharmaconet_amd.constants import weights_vector
     from pharmaconet_amd.library import PackedLibrary
 
-    cores = os.cpu_count() or 1
+    cores, host = host_cores()
     n_all = offsets.numel() - 1
 
     def sample(n):
@@ -211,24 +278,31 @@ def cpu_baseline(pockets, offsets, data, n_conf, budget_s=10.0):
         "gaussian_terms_per_ligand_conformer": float(probe_stats["n_terms"].mean()),
         "tree_nodes_per_ligand_without_bound_test": float(probe_stats["n_tree"].mean()),
     }
-    n = int(min(n_all, max(len(probe), rate * budget_s)))
+    per_thread = 256 if n_conf <= 16 else 32
+    n = int(min(n_all, max(len(probe), rate * budget_s, per_thread * cores)))
     lib = sample(n)
     dt = timed(lib, cores)
-    rate = n / dt
-    # one core: sized from a short probe of its own (threads share caches and clocks: one core alone is far faster than 1 / cores of all)
+    # one core: sized from a short probe of its own (threads share caches and clocks: one core alone is faster than 1 / cores of all)
     probe1 = sample(min(64, n))
     rate1 = len(probe1) / max(timed(probe1, 1), 1e-6)
-    n1 = int(min(n, max(len(probe1), rate1 * 0.8 * budget_s)))
+    n1 = int(min(n, max(len(probe1), rate1 * 0.6 * budget_s)))
     lib1 = sample(n1)
     dt1 = timed(lib1, 1)
-    return {
-        "value": n * n_conf * len(pockets) / dt,
+    all_rate, one_rate = n * n_conf * len(pockets) / dt, n1 * n_conf * len(pockets) / dt1
+    out = {
+        "value": all_rate,
         "unit": "ligand-conformers/s" if len(pockets) == 1 else "pocket-ligand-conformers/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"first {n} ligands of the same library" + (f" against the {len(pockets)} pockets" if len(pockets) > 1 else "") + f", OpenMP over ligands, {dt:.1f}s",
-        "one_core": {"value": n1 * n_conf * len(pockets) / dt1, "cores": 1, "sample": f"first {n1} ligands, {dt1:.1f}s"},
-    }, work
+        "sample": f"first {n} ligands of the same library ({n // max(cores, 1)} per thread)" + (f" against the {len(pockets)} pockets" if len(pockets) > 1 else "")
+                  + f", OpenMP over ligands (dynamic schedule), {cores} threads, {dt:.1f}s",
+        "host": host,
+        "one_core": {"value": one_rate, "cores": 1, "sample": f"first {n1} ligands, {dt1:.1f}s"},
+        # thread-seconds spent per unit of one-core work: 1.0 = the threads scale perfectly
+        "parallel_efficiency": all_rate / max(one_rate * cores, 1e-9),
+        "reference_numpy_path": reference_rate(),
+    }
+    return out, work
 
 
 def parity_sample(pocket, scores, offsets, data, n=512):
@@ -242,7 +316,7 @@ def parity_sample(pocket, scores, offsets, data, n=512):
     import torch
 
     got = scores[torch.from_numpy(index).to(scores.device)].cpu().numpy().astype(np.float64)
-    ref = orc.oracle_score(pocket.flat, lib, weights_vector(None), num_threads=min(os.cpu_count() or 1, 64))
+    ref = orc.oracle_score(pocket.flat, lib, weights_vector(None), num_threads=host_cores()[0])
     nz = ref > 0
     err = np.abs(got[nz] - ref[nz]) / ref[nz]
     return {
@@ -291,6 +365,8 @@ def main():
     ap.add_argument("--conformers", type=int, default=0)
     ap.add_argument("--topologies", type=int, default=0, help="distinct synthetic molecules per GPU")
     ap.add_argument("--topk", type=int, default=1000)
+    ap.add_argument("--library", choices=("expanded", "survey"), default="expanded",
+                    help="expanded: molecule topologies x jittered copies (tools/synthetic.py; the default line); survey: SURVEY.md 8d-2's generator, every ligand an independent draw (tools/survey_library.py)")
     ap.add_argument("--pockets", type=int, default=1, help="score this many distinct pockets (1..16) against the shared library (BASELINE configs[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-serial-leg", action="store_true", help="skip the end-to-end (pack + copy) side measurement")
@@ -312,21 +388,25 @@ def main():
     args.conformers = args.conformers or wl_conf
     args.topologies = args.topologies or wl_topo
     if world != args.gpus:
-        log(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}: the line reports n_gpus = {world}")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}")
     # PMX_BENCH_DEVICE / PMX_BENCH_BACKEND exist to rehearse the multi-rank path on a 1-GPU box (all ranks on one
     # device, gloo); the driver's runs use one GPU per rank and RCCL ("nccl").
     dev_index = int(os.environ.get("PMX_BENCH_DEVICE", local_rank))
     backend = os.environ.get("PMX_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
+    # Control plane (barrier, the maximum of the ranks' times, the hand-over of the RCCL id) on gloo: the one RCCL user of the process
+    # is libpmx's own communicator, which carries the data path (pmx_topk_allgather). PMX_BENCH_CONTROL=nccl puts torch's process group
+    # on RCCL as well.
+    control = os.environ.get("PMX_BENCH_CONTROL", "gloo")
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        if backend == "nccl":
+        if control == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group("gloo")
 
     import __graft_entry__ as entry
 
@@ -339,8 +419,16 @@ def main():
     pockets = [model]
     if args.pockets > 1:
         pockets = [PharmacophoreModel.load(REPO / "tests" / "golden" / "pockets16" / f"model_{k:02d}.pm") for k in range(min(args.pockets, 16))]
+    # (TopkExchange raises unless RCCL itself reports WORLD_SIZE ranks, pmx_comm_info: a line that says n_gpus = N is an N-rank exchange)
     exchange = TopkExchange(device) if (world > 1 and backend == "nccl") else None
-    lib, offsets, data, molecules = build_library(model, args.ligands, args.conformers, args.topologies, rank, device, wl_active, wl_seed)
+    if exchange is not None and exchange.rccl_ranks != world:
+        raise SystemExit(f"bench.py: RCCL communicator spans {exchange.rccl_ranks} rank(s), WORLD_SIZE is {world}")
+    survey_stats = None
+    if args.library == "survey":
+        lib, offsets, data, survey_stats = build_survey_library(model, args.ligands, args.conformers, rank, device, wl_active)
+        molecules = None  # (packed records are generated directly: there are no molecules for the packer leg)
+    else:
+        lib, offsets, data, molecules = build_library(model, args.ligands, args.conformers, args.topologies, rank, device, wl_active, wl_seed)
     n_lig = len(lib)
     n_conf_total = lib.total_conformers
     index_base = rank * n_lig
@@ -388,7 +476,7 @@ def main():
         finally:
             engine.set_profiling(False)
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device if (world > 1 and control == "nccl") else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -409,7 +497,7 @@ def main():
         # HBM traffic per launch from the committed PMC passes (FETCH_SIZE / WRITE_SIZE, collected separately with
         # rocprofv3 --pmc and corrected as MI355X_MICROARCH.md prescribes), scaled to this launch's ligands - quoted only
         # when the summary was taken on this build of csrc/ and on this workload
-        bench_shape = args.model == "6oim" and args.conformers == 8 and len(pockets) == 1
+        bench_shape = args.model == "6oim" and args.conformers == 8 and len(pockets) == 1 and args.library == "expanded"
         traffic, traffic_src = None, "profiled on the 6OIM-like model at 8 conformers only: not quoted for this workload"
         if bench_shape:
             pmc, traffic_src = committed_profile("hbm_traffic")
@@ -432,15 +520,22 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": (model_words if len(pockets) == 1 else f"{len(pockets)} fixture pockets (pockets16)")
-                            + f" vs {n_lig} synthetic ligands per GPU = {min(args.topologies, n_lig)} molecule topologies x "
-                            f"{-(-n_lig // min(args.topologies, n_lig))} copies with every node displaced (sigma 0.35 A) and every conformer "
-                            f"coordinate jittered (sigma 0.30 A); mean {lib.num_bytes / n_lig / (12.0 * args.conformers):.1f} pharmacophore nodes "
-                            f"(<= 32), {args.conformers} conformers each, {100 * wl_active:.0f} % drawn on the model's nodes; top-{args.topk}",
+                            + (f" vs {n_lig} synthetic ligands per GPU = {min(args.topologies, n_lig)} molecule topologies x "
+                               f"{-(-n_lig // min(args.topologies, n_lig))} copies with every node displaced (sigma 0.35 A) and every conformer "
+                               f"coordinate jittered (sigma 0.30 A); mean {lib.num_bytes / n_lig / (12.0 * args.conformers):.1f} pharmacophore nodes "
+                               f"(<= 32), {args.conformers} conformers each, {100 * wl_active:.0f} % drawn on the model's nodes; top-{args.topk}"
+                               if survey_stats is None else
+                               f" vs {n_lig} synthetic ligands per GPU, SURVEY.md 8d-2's generator (tools/survey_library.py): every ligand an independent draw "
+                               f"from its own counter-based stream, n ~ clip(N(20, 6), 4, 32) nodes (mean {survey_stats['mean_nodes']:.1f}, "
+                               f"{survey_stats['mean_clusters']:.1f} clusters), {args.conformers} conformers = base + N(0, 0.5 A), "
+                               f"{100 * survey_stats['active_share']:.0f} % on the model's nodes (sigma 0.7 A, random rigid motion), the rest random walks; top-{args.topk}"),
+                "library": args.library,
+                "library_stats": survey_stats,
                 "pockets": len(pockets),
                 "ligands_per_gpu": n_lig,
                 "conformers_per_ligand": args.conformers,
                 "parallelism": f"ligand-sharded x{world}" if world > 1 else "single GPU",
-                "exchange": None if world == 1 else ({"collective": "ncclAllGather of per-rank top-k (pmx_topk_allgather, merge on the device)", "rccl_ranks": exchange.world}
+                "exchange": None if world == 1 else ({"collective": "ncclAllGather of per-rank top-k (pmx_topk_allgather, merge on the device)", "rccl_ranks": exchange.rccl_ranks, "control_plane": control}
                                                      if exchange is not None else {"collective": f"{backend} all_gather of per-rank top-k (rehearsal transport) + the device merge of pmx_topk_allgather (pmx_topk over the gathered lists)", "ranks": world}),
             },
             "roofline": {
@@ -494,7 +589,7 @@ def main():
             out["work"]["reference_terms_per_table_item"] = terms_per_conf / max(out["work"]["table_items_per_ligand_conformer"], 1e-9)
         else:
             out["cpu_baseline"] = None
-        if world == 1 and not args.no_serial_leg:
+        if world == 1 and not args.no_serial_leg and molecules is not None:
             try:
                 out["end_to_end"] = end_to_end(molecules, lib, data, ms_per_step, n_conf_total * len(pockets))
             except Exception as e:  # never lose the bench line over the side measurement

@@ -128,6 +128,18 @@ int pmx_library_destroy(pmx_library *lib);
 int pmx_score(const pmx_model *model, const pmx_library *lib, const float weights[PMX_NUM_TYPES], uint64_t first,
               uint64_t count, float *scores_dev, int32_t *status_dev, void *stream);
 
+/*
+ * pmx_score with the score as a float64: the value `GraphMatcher.run()` returns is `float(np.mean(...))` of float64 per-conformer maxima
+ * (graph_match.py:103-109); pmx_score rounds it to float32, this entry point hands it over as it is (scores_dev = double[count]), so that a
+ * CSV written from it (screening.py:70-75) carries the reference's digits as far as the tabulated pair functions allow (relative 1e-7) and
+ * two ligands closer than a float32 ulp keep the order the float64 values give them. Same work, same kernels.
+ */
+int pmx_score_f64(const pmx_model *model, const pmx_library *lib, const float weights[PMX_NUM_TYPES], uint64_t first,
+                  uint64_t count, double *scores_dev, int32_t *status_dev, void *stream);
+int pmx_score_multi_f64(const pmx_model *const *models, int n_models, const pmx_library *lib,
+                        const float weights[PMX_NUM_TYPES], uint64_t first, uint64_t count, double *scores_dev,
+                        int32_t *status_dev, void *stream);
+
 /* The same for several models over one library: the pockets' chunks are one sequence of one call (one pocket after the other
  * on `stream` by default; PMX_OVERLAP=2 lets a pocket's last task rounds run beside the next pocket's ligand kernel);
  * scores_dev is [n_models][count], status_dev[count] is written once. */
@@ -158,6 +170,7 @@ int pmx_topk(const float *scores_dev, const uint64_t *index_dev, uint64_t n, uin
 typedef struct pmx_comm pmx_comm;
 int pmx_comm_unique_id(char id_out[PMX_COMM_ID_BYTES]);
 int pmx_comm_create(const char id[PMX_COMM_ID_BYTES], int rank, int nranks, int device, pmx_comm **out);
+int pmx_comm_info(pmx_comm *comm, int *rank_out, int *nranks_out, int *device_out); /* as RCCL reports them (ncclCommCount / UserRank / CuDevice) */
 int pmx_comm_destroy(pmx_comm *comm);
 int pmx_topk_allgather(pmx_comm *comm, const float *scores_k_dev, const uint64_t *index_k_dev, int k, float *out_scores_dev,
                        uint64_t *out_index_dev, void *stream);
@@ -305,6 +318,8 @@ typedef struct {
     uint64_t n_path_bounds, n_path_drops; /* children tested against the bound their actual path gives (path_bound()), and dropped by it */
     uint64_t n_dead_entries;    /* pair-table entries settled as -1 without computing their items: more than half of their node pairs lie
                                    outside every 2-sigma window of the two model clusters, for every conformer */
+    uint64_t arena_capacity;    /* bytes of the table arena this workspace obtained (PMX_ARENA_MB, or a third of the free device memory at its first
+                                   allocation, halved until it fit): which ligands can get PMX_LIGAND_TOO_LARGE depends on it */
 } pmx_score_stats;
 int pmx_score_stats_get(pmx_score_stats *out);
 int pmx_set_profiling(int enabled); /* when enabled pmx_score records HIP events around its phases (no synchronisation) */

@@ -85,7 +85,7 @@ class ScoreStats(ctypes.Structure):
             "n_slice_overflow", "n_probes", "n_probe_passes", "max_passes", "queue_overflow", "arena_bytes",
             "ticks_scan", "ticks_tables", "ticks_bounds", "ticks_walk", "ticks_alive", "n_exact_values")]
         + [("dbg", ctypes.c_uint64 * 8), ("n_path_bounds", ctypes.c_uint64), ("n_path_drops", ctypes.c_uint64),
-           ("n_dead_entries", ctypes.c_uint64)]
+           ("n_dead_entries", ctypes.c_uint64), ("arena_capacity", ctypes.c_uint64)]
     )
 
 
@@ -108,6 +108,16 @@ SIGNATURES = {
         [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float),
          ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p],
     ),
+    "pmx_score_f64": (
+        ctypes.c_int,
+        [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float), ctypes.c_uint64, ctypes.c_uint64,
+         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p],
+    ),
+    "pmx_score_multi_f64": (
+        ctypes.c_int,
+        [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float),
+         ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p],
+    ),
     "pmx_topk": (
         ctypes.c_int,
         [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, ctypes.c_void_p,
@@ -115,6 +125,7 @@ SIGNATURES = {
     ),
     "pmx_comm_unique_id": (ctypes.c_int, [ctypes.c_char_p]),
     "pmx_comm_create": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
+    "pmx_comm_info": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "pmx_comm_destroy": (ctypes.c_int, [ctypes.c_void_p]),
     "pmx_topk_allgather": (
         ctypes.c_int,

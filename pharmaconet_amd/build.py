@@ -47,12 +47,50 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found")
 
 
+STAMP = PKG / "libpmx.stamp"  # what libpmx.so was built from: written by _build(), read by _stale() and by bench.py's csrc_digest()
+
+
+def hipcc_version() -> str:
+    try:
+        out = subprocess.run([hipcc(), "--version"], capture_output=True, text=True, timeout=60).stdout
+    except Exception as e:  # (informational only)
+        return f"unknown ({e!r})"
+    lines = [ln.strip() for ln in out.splitlines() if "HIP version" in ln or "clang version" in ln]
+    return "; ".join(lines) or out.strip()[:200]
+
+
+def build_digest() -> dict:
+    """Content hash of everything that decides what the kernels are: the device and host sources, include/pmx.h, the compile flags and
+    PMX_CXXFLAGS. (Not the compiler's version: the GPU box's hipcc may differ from the build container's and must not trigger a rebuild
+    there - the .so travels with the tree; the version the build was made with is recorded in the stamp.)"""
+    import hashlib
+
+    extra = os.environ.get("PMX_CXXFLAGS", "").split()
+    h = hashlib.sha256((" ".join(FLAGS) + "\0" + " ".join(extra)).encode())
+    dev = hashlib.sha256((" ".join(FLAGS) + "\0" + " ".join(extra)).encode())
+    for f in sorted([CSRC / s for s in SOURCES + DEPS] + [REPO / "include" / "pmx.h"]):
+        blob = f.name.encode() + b"\0" + f.read_bytes()
+        h.update(blob)
+        if f.suffix in (".hip", ".h"):
+            dev.update(blob)
+    return {"digest": h.hexdigest()[:16], "csrc_sha16": dev.hexdigest()[:16], "flags": list(FLAGS), "cxxflags": extra}
+
+
+def read_stamp() -> dict | None:
+    try:
+        import json
+
+        return json.loads(STAMP.read_text())
+    except Exception:
+        return None
+
+
 def _stale() -> bool:
     if not LIB.exists() or not PACK_LIB.exists():
         return True
-    built = min(LIB.stat().st_mtime, PACK_LIB.stat().st_mtime)
-    inputs = [CSRC / s for s in SOURCES + DEPS] + [REPO / "include" / "pmx.h"]
-    return any(p.stat().st_mtime > built for p in inputs)
+    stamp = read_stamp()
+    # (a change of FLAGS or PMX_CXXFLAGS alone rebuilds: four -mllvm switches are worth 15 % of a pass - ADVICE r5)
+    return stamp is None or stamp.get("digest") != build_digest()["digest"]
 
 
 def build_native(force: bool = False, verbose: bool = False) -> Path:
@@ -73,6 +111,7 @@ def build_native(force: bool = False, verbose: bool = False) -> Path:
 
 def _build(verbose: bool) -> Path:
     cc = hipcc()
+    digest = build_digest()  # (of the sources as they are when the compile starts)
     from concurrent.futures import ThreadPoolExecutor
 
     extra = os.environ.get("PMX_CXXFLAGS", "").split()
@@ -105,6 +144,9 @@ def _build(verbose: bool) -> Path:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
     os.replace(tmp, PACK_LIB)
+    import json
+
+    STAMP.write_text(json.dumps({**digest, "hipcc": hipcc_version()}, indent=1) + "\n")
     return LIB
 
 

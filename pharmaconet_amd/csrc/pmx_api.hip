@@ -706,7 +706,7 @@ struct PocketPlan {
 
 template <int G>
 static int score_screen(const pmx_model *const *models, int n_models, const pmx_library *lib, const Weights &W, uint64_t first, uint64_t count,
-                        float *scores_dev, int32_t *status_dev, hipStream_t stream, ScreenWs &ws) {
+                        void *scores_dev, bool scores_f64, int32_t *status_dev, hipStream_t stream, ScreenWs &ws) {
     if (count > 0xfffffff0ull) return fail(PMX_ERR_INVALID, "more than 2^32 ligands in one call");
     if (!ws.num_cu) { // (num_cu is set last: a workspace whose events, stream or control blocks could not be made stays uninitialised)
         auto init = [&]() -> int {
@@ -739,7 +739,7 @@ static int score_screen(const pmx_model *const *models, int n_models, const pmx_
     // any validation switch: the kernels of pmx_screen_debug.hip (libpmx's own read those bits as zero, pmx_screen.hip PMX_WFLAGS)
     const bool debug_kernels = (flags & ~PMX_PRODUCT_FLAGS) != 0;
     bool debug_ok = true;
-    // Type weights further apart than PMX_TAILS_RATIO (default 16; the reference's defaults are 8 : 1, graph_match.py:32-40): pair items
+    // Type weights further apart than PMX_TAILS_RATIO (default 8 = the ratio of the reference's own defaults, graph_match.py:32-40: any override that spreads the weights further takes the exact tails): pair items
     // evaluate rough cells term by term like self items do (item_finish<TAILS>, pmx_screen.hip) - slower, and only then.
     // PMX_PAIR_TAILS = 0 / 1 forces it off / on.
     bool tails = false;
@@ -753,7 +753,7 @@ static int score_screen(const pmx_model *const *models, int n_models, const pmx_
             if (present[t] && a > 0.f && std::isfinite(a)) wmin = std::min(wmin, a), wmax = std::max(wmax, a);
         }
         const char *rs = std::getenv("PMX_TAILS_RATIO");
-        const double ratio = (rs && *rs) ? std::atof(rs) : 16.0;
+        const double ratio = (rs && *rs) ? std::atof(rs) : 8.0;
         tails = wmax > 0.f && (double)wmax > ratio * (double)wmin;
         const long force = env_long("PMX_PAIR_TAILS", -1);
         if (force == 0) tails = false;
@@ -783,13 +783,13 @@ static int score_screen(const pmx_model *const *models, int n_models, const pmx_
         p.sub_nodes = model->sub_nodes;
         p.W = W;
         p.first = first;
-        p.flags = flags;
+        p.flags = flags | (scores_f64 ? PMX_SCORES_F64 : 0u);
         p.max_nodes = max_nodes;
         p.budget = lig_budget;
         p.min_levels = (uint32_t)std::max<long>(0, env_long("PMX_MIN_LEVELS", 3));
         p.bound_cost = (uint32_t)std::max<long>(0, env_long("PMX_BOUND_COST", 8192));
         p.dead_min_entries = (uint32_t)std::max<long>(1, env_long("PMX_DEAD_MIN_ENTRIES", 32));
-        p.scores = scores_dev + (size_t)m * count;
+        p.scores = scores_f64 ? reinterpret_cast<float *>(static_cast<double *>(scores_dev) + (size_t)m * count) : static_cast<float *>(scores_dev) + (size_t)m * count;
         p.status = m == 0 ? status_dev : nullptr;
         const WaveShape<G> shape = wave_shape<G>(model->dm.K, (int)max_nodes);
         pl.lds = shape.bytes;
@@ -1033,6 +1033,7 @@ static int screen_stats(pmx_score_stats *out) {
             for (int i = 0; i < kStatWords; ++i) st[i] = (i == 5) ? std::max(st[i], c->stats[sh][i]) : st[i] + c->stats[sh][i];
         out->queue_overflow |= c->qflag;
         out->arena_bytes = std::max<uint64_t>(out->arena_bytes, c->arena_top);
+        out->arena_capacity = std::max<uint64_t>(out->arena_capacity, w->set[ci].arena_bytes);
     }
     out->n_frames = st[0];
     out->n_passes = st[1];
@@ -1070,9 +1071,8 @@ static int next_pow2(int x) {
     return g;
 }
 
-extern "C" int pmx_score_multi(const pmx_model *const *models, int n_models, const pmx_library *lib,
-                               const float weights[PMX_NUM_TYPES], uint64_t first, uint64_t count, float *scores_dev,
-                               int32_t *status_dev, void *stream_) {
+static int score_any(const pmx_model *const *models, int n_models, const pmx_library *lib, const float weights[PMX_NUM_TYPES], uint64_t first,
+                     uint64_t count, void *scores_dev, bool scores_f64, int32_t *status_dev, void *stream_) {
     if (!models || n_models < 0 || !lib || !weights || (!scores_dev && count && n_models)) return fail(PMX_ERR_INVALID, "null argument");
     for (int i = 0; i < n_models; ++i) {
         if (!models[i]) return fail(PMX_ERR_INVALID, "null model");
@@ -1097,23 +1097,42 @@ extern "C" int pmx_score_multi(const pmx_model *const *models, int n_models, con
         lock.unlock(); // released while this call waited: the map holds a fresh one (or will make one)
     }
     switch (G) {
-    case 1: rc = score_screen<1>(models, n_models, lib, W, first, count, scores_dev, status_dev, stream, *ws); break;
-    case 2: rc = score_screen<2>(models, n_models, lib, W, first, count, scores_dev, status_dev, stream, *ws); break;
-    case 4: rc = score_screen<4>(models, n_models, lib, W, first, count, scores_dev, status_dev, stream, *ws); break;
-    case 8: rc = score_screen<8>(models, n_models, lib, W, first, count, scores_dev, status_dev, stream, *ws); break;
-    case 16: rc = score_screen<16>(models, n_models, lib, W, first, count, scores_dev, status_dev, stream, *ws); break;
-    case 32: rc = score_screen<32>(models, n_models, lib, W, first, count, scores_dev, status_dev, stream, *ws); break;
-    default: rc = score_screen<64>(models, n_models, lib, W, first, count, scores_dev, status_dev, stream, *ws); break;
+    case 1: rc = score_screen<1>(models, n_models, lib, W, first, count, scores_dev, scores_f64, status_dev, stream, *ws); break;
+    case 2: rc = score_screen<2>(models, n_models, lib, W, first, count, scores_dev, scores_f64, status_dev, stream, *ws); break;
+    case 4: rc = score_screen<4>(models, n_models, lib, W, first, count, scores_dev, scores_f64, status_dev, stream, *ws); break;
+    case 8: rc = score_screen<8>(models, n_models, lib, W, first, count, scores_dev, scores_f64, status_dev, stream, *ws); break;
+    case 16: rc = score_screen<16>(models, n_models, lib, W, first, count, scores_dev, scores_f64, status_dev, stream, *ws); break;
+    case 32: rc = score_screen<32>(models, n_models, lib, W, first, count, scores_dev, scores_f64, status_dev, stream, *ws); break;
+    default: rc = score_screen<64>(models, n_models, lib, W, first, count, scores_dev, scores_f64, status_dev, stream, *ws); break;
     }
     g_last_screen = ws;
     g_last_device = lib->device;
     return rc;
 }
 
+extern "C" int pmx_score_multi(const pmx_model *const *models, int n_models, const pmx_library *lib,
+                               const float weights[PMX_NUM_TYPES], uint64_t first, uint64_t count, float *scores_dev,
+                               int32_t *status_dev, void *stream) {
+    return score_any(models, n_models, lib, weights, first, count, scores_dev, false, status_dev, stream);
+}
+
 extern "C" int pmx_score(const pmx_model *model, const pmx_library *lib, const float weights[PMX_NUM_TYPES], uint64_t first,
                          uint64_t count, float *scores_dev, int32_t *status_dev, void *stream) {
     if (!model) return fail(PMX_ERR_INVALID, "null argument");
-    return pmx_score_multi(&model, 1, lib, weights, first, count, scores_dev, status_dev, stream);
+    return score_any(&model, 1, lib, weights, first, count, scores_dev, false, status_dev, stream);
+}
+
+// The same with the score as the float64 the reference returns (graph_match.py:109: `float(np.mean(...))` of float64 maxima).
+extern "C" int pmx_score_multi_f64(const pmx_model *const *models, int n_models, const pmx_library *lib,
+                                   const float weights[PMX_NUM_TYPES], uint64_t first, uint64_t count, double *scores_dev,
+                                   int32_t *status_dev, void *stream) {
+    return score_any(models, n_models, lib, weights, first, count, scores_dev, true, status_dev, stream);
+}
+
+extern "C" int pmx_score_f64(const pmx_model *model, const pmx_library *lib, const float weights[PMX_NUM_TYPES], uint64_t first,
+                             uint64_t count, double *scores_dev, int32_t *status_dev, void *stream) {
+    if (!model) return fail(PMX_ERR_INVALID, "null argument");
+    return score_any(&model, 1, lib, weights, first, count, scores_dev, true, status_dev, stream);
 }
 
 

@@ -154,6 +154,10 @@ extern "C" int pmx_perceive_features(const pmx_atom_batch *b, int threads, uint6
                                      uint64_t *n_feat_centers, int32_t *status_out) {
     if (!b || !feat_off || !n_features || !n_feat_atoms || !n_feat_centers) return pmx_topk_fail(PMX_ERR_INVALID, "pmx_perceive_features: null argument");
     const uint64_t n = b->n_mols;
+    if (n && (!b->atom_off || !b->ring_off)) return pmx_topk_fail(PMX_ERR_INVALID, "pmx_perceive_features: null offset array in the batch");
+    if (n && b->atom_off[n] > b->atom_off[0] && (!b->atomic_num || !b->explicit_degree || !b->heavy_degree || !b->hyb || !b->h_count || !b->flags || !b->nbr_off))
+        return pmx_topk_fail(PMX_ERR_INVALID, "pmx_perceive_features: null per-atom array in the batch");
+    if (n && b->ring_off[n] > b->ring_off[0] && !b->ring_atom_off) return pmx_topk_fail(PMX_ERR_INVALID, "pmx_perceive_features: rings without ring_atom_off");
     for (uint64_t i = 0; i < n; ++i)
         if (b->atom_off[i + 1] < b->atom_off[i] || b->ring_off[i + 1] < b->ring_off[i])
             return pmx_topk_fail(PMX_ERR_INVALID, "pmx_perceive_features: offsets run backwards");
@@ -177,6 +181,10 @@ extern "C" int pmx_perceive_features(const pmx_atom_batch *b, int threads, uint6
                     m.ring_atom_off = b->ring_atom_off, m.ring_atoms = b->ring_atoms;
                     bool ok = true;
                     for (int k = 0; k < m.n && ok; ++k) ok = m.nbr_off[k + 1] >= m.nbr_off[k];
+                    // (a ring whose atom offsets run backwards would be a negative range in perceive_one; ring or neighbour lists without their arrays)
+                    for (uint64_t r = m.ring0; r < m.ring1 && ok; ++r) ok = m.ring_atom_off[r + 1] >= m.ring_atom_off[r];
+                    ok = ok && (m.ring0 == m.ring1 || m.ring_atom_off[m.ring1] == m.ring_atom_off[m.ring0] || m.ring_atoms != nullptr);
+                    ok = ok && (m.n == 0 || m.nbr_off[m.n] == m.nbr_off[0] || m.nbr != nullptr);
                     try {
                         ok = ok && perceive_one(m, all[i]);
                     } catch (...) {
@@ -191,7 +199,11 @@ extern "C" int pmx_perceive_features(const pmx_atom_batch *b, int threads, uint6
         };
         const int nt = std::max(1, std::min(threads, 256));
         std::vector<std::thread> pool;
-        for (int t = 1; t < nt; ++t) pool.emplace_back(work);
+        pool.reserve((size_t)nt);
+        try {
+            for (int t = 1; t < nt; ++t) pool.emplace_back(work);
+        } catch (...) { // a thread could not be started: the ones that run finish the work (joinable threads must not be unwound)
+        }
         work();
         for (auto &t : pool) t.join();
         uint64_t nf = 0, na = 0, nc = 0;

@@ -42,6 +42,7 @@
 #ifndef PMX_NS
 #define PMX_NS pmx
 #endif
+#define PMX_SCORES_F64 (1u << 30) // ScreenParams::flags: `scores` is a double array (pmx_score_f64); set by the host, not by PMX_TREE_FLAGS
 #define PMX_PRODUCT_FLAGS (2u | 16384u)
 #ifdef PMX_DEBUG_KERNELS
 #define PMX_WFLAGS(p) ((p).flags)
@@ -244,7 +245,7 @@ struct ScreenParams {
     uint32_t last_round;       // task_kernel: never queue (walk every subtree to its end)
     uint32_t bound_cost; // per-candidate bounds are built when their cost estimate stays below this (build_bounds)
     uint32_t dead_min_entries; // the dead-entry test (build_tables) runs for level pairs with at least this many entries
-    float *scores;
+    float *scores;             // float[count]; double[count] when flags & PMX_SCORES_F64 (put_score())
     int32_t *status;
     int mode;                  // 0: slice pass over [lo, hi); 1: large-slice pass over ovf_list; 2: arena pass over carry_list; 3: arena pass over retry_in
     const uint32_t *retry_in;  // mode 3: the ligands an earlier arena pass had no room for (count: ctl->retry_count[retry_slot ^ 1])
@@ -254,6 +255,13 @@ struct ScreenParams {
 
 
 // ------------------------------------------------------------------------------------------------ helpers
+
+// A ligand's score: the float32 of the float64 mean the reference returns (graph_match.py:109), or that float64 itself (pmx_score_f64).
+__device__ __forceinline__ void put_score(const ScreenParams &p, uint32_t li, double v) {
+    // ([MI355X] A/B: the kernels always writing the float64 and a conversion kernel per chunk for pmx_score: 99.8 ms against 98.7-98.9 for this branch)
+    if (p.flags & PMX_SCORES_F64) reinterpret_cast<double *>(p.scores)[li] = v;
+    else p.scores[li] = (float)v;
+}
 
 __device__ inline int rl(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 // lane `lane` (wave-uniform) of v := value (this clang has no v_writelane builtin; a compare + select does it)
@@ -2323,7 +2331,7 @@ __device__ __forceinline__ unsigned char *prepare_ligand(const ScreenParams &p, 
     if (p.mode == 0) {
         if (!record_supported(r)) {
             if (lane == 0) {
-                p.scores[li] = __builtin_nanf("");
+                put_score(p, li, __builtin_nan(""));
                 if (p.status) p.status[li] = PMX_LIGAND_UNSUPPORTED;
             }
             return nullptr;
@@ -2334,13 +2342,13 @@ __device__ __forceinline__ unsigned char *prepare_ligand(const ScreenParams &p, 
     const LevelInfo L = scan_ligand<G>(p, lds, ws, r);
     if (L.nl < 0) { // a ligand cluster with more than PMX_MAX_LEVEL_CANDIDATES candidate clusters
         if (lane == 0) {
-            p.scores[li] = __builtin_nanf("");
+            put_score(p, li, __builtin_nan(""));
             if (p.status) p.status[li] = PMX_LIGAND_UNSUPPORTED;
         }
         return nullptr;
     }
     if (L.nl == 0) { // no ligand cluster has a candidate (graph_match.py:95-99)
-        if (lane == 0) p.scores[li] = 0.f;
+        if (lane == 0) put_score(p, li, 0.0);
         return nullptr;
     }
     const uint64_t bytes64 = rec_bytes<G>(L.ksumtot, L.T, (uint32_t)L.nl);
@@ -2372,7 +2380,7 @@ __device__ __forceinline__ unsigned char *prepare_ligand(const ScreenParams &p, 
                     const uint32_t o = atomicAdd(&p.ctl->retry_count[p.retry_slot], 1u);
                     if (o < p.list_cap) p.retry_out[o] = li;
                 } else {
-                    p.scores[li] = __builtin_nanf("");
+                    put_score(p, li, __builtin_nan(""));
                     if (p.status) p.status[li] = PMX_LIGAND_TOO_LARGE;
                 }
             }
@@ -2565,7 +2573,7 @@ __device__ __forceinline__ void run_job(const ScreenParams &p, unsigned char *ld
         double sum = (s == 0 && c < C) ? __longlong_as_double((long long)bbits) : 0.0;
 #pragma unroll
         for (int d = 1; d < G; d <<= 1) sum += __shfl_xor(sum, d);
-        if (lane == 0) p.scores[uni((int)H->lig)] = (float)(sum / (double)C);
+        if (lane == 0) put_score(p, (uint32_t)uni((int)H->lig), sum / (double)C);
     }
     wave_sync();
 }
@@ -2728,7 +2736,7 @@ __global__ void finalize_kernel(const ScreenParams p) {
     const int C = (int)H->C;
     double sum = 0.0;
     for (int c = 0; c < C; ++c) sum += __longlong_as_double((long long)best[c]);
-    p.scores[H->lig] = (float)(sum / (double)C);
+    put_score(p, H->lig, sum / (double)C);
 }
 
 // In front of an arena pass over the ligands the last one had no room for: every subtree of the super-chunk is done and

@@ -257,6 +257,20 @@ extern "C" int pmx_comm_create(const char id[PMX_COMM_ID_BYTES], int rank, int n
     return PMX_OK;
 }
 
+// What RCCL itself says about the communicator (not what the caller passed in): ranks, this rank, its device.
+extern "C" int pmx_comm_info(pmx_comm *c, int *rank_out, int *nranks_out, int *device_out) {
+    if (!c || !c->comm) return pmx_topk_fail(PMX_ERR_INVALID, "null communicator");
+    int n = 0, r = 0, d = 0;
+    ncclResult_t e = ncclCommCount(c->comm, &n);
+    if (e == ncclSuccess) e = ncclCommUserRank(c->comm, &r);
+    if (e == ncclSuccess) e = ncclCommCuDevice(c->comm, &d);
+    if (e != ncclSuccess) return pmx_topk_fail(PMX_ERR_HIP, ncclGetErrorString(e));
+    if (rank_out) *rank_out = r;
+    if (nranks_out) *nranks_out = n;
+    if (device_out) *device_out = d;
+    return PMX_OK;
+}
+
 extern "C" int pmx_comm_destroy(pmx_comm *c) {
     if (!c) return PMX_OK;
     (void)hipSetDevice(c->device);

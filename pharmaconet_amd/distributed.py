@@ -96,6 +96,12 @@ class TopkExchange:
             dist.broadcast_object_list(payload, src=src, group=group)
         self._handle = ctypes.c_void_p()
         _ffi.check(self._lib.pmx_comm_create(payload[0], self.rank, self.world, self.device.index or 0, ctypes.byref(self._handle)))
+        # what RCCL itself reports: a communicator that does not span the job's ranks must not pass for one that does
+        r, n, d = ctypes.c_int(-1), ctypes.c_int(-1), ctypes.c_int(-1)
+        _ffi.check(self._lib.pmx_comm_info(self._handle, ctypes.byref(r), ctypes.byref(n), ctypes.byref(d)))
+        self.rccl_rank, self.rccl_ranks, self.rccl_device = r.value, n.value, d.value
+        if self.rccl_ranks != self.world or self.rccl_rank != self.rank:
+            raise _ffi.PmxError(f"RCCL communicator has {self.rccl_ranks} rank(s), this one is {self.rccl_rank}: expected rank {self.rank} of {self.world}")
 
     def allgather(self, local_scores, local_indices, k: int):
         """`local_scores` float32 [k], `local_indices` int64 [k] (global indices, -1 padding) on this rank's GPU ->

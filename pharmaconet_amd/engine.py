@@ -138,7 +138,7 @@ class DeviceLibrary:
 
 @dataclass
 class ScreeningResult:
-    scores: "object"  # torch.float32 [count] on the device, library order
+    scores: "object"  # torch.float32 (float64 with `screen(..., float64=True)`) [count] on the device, library order
     status: "object"  # torch.int32 [count]
     first: int
     topk_scores: "object | None" = None  # torch.float32 [k]
@@ -192,11 +192,14 @@ def screen(
     first: int = 0,
     count: int | None = None,
     index_base: int = 0,
+    float64: bool = False,
 ) -> ScreeningResult:
     """Score ligands `[first, first + count)` of `library` against `model` on the GPU.
 
     `library` is a `DeviceLibrary` (already in HBM) or anything `as_packed_library` accepts.
-    `index_base` is added to positions when reporting top-k indices (the shard's global offset)."""
+    `index_base` is added to positions when reporting top-k indices (the shard's global offset).
+    `float64`: scores as the float64 the reference returns (`pmx_score_f64`; `graph_match.py:109`) instead of its float32
+    rounding; the device top-k ranks float32 values, so it is not offered together with `topk`."""
     torch = _torch()
     lib = _ffi.load()
     owned = None
@@ -207,12 +210,14 @@ def screen(
     if count is None:
         count = len(library) - first
     tdev = torch.device("cuda", dev)
-    scores = torch.empty(count, dtype=torch.float32, device=tdev)
+    if float64 and topk is not None:
+        raise ValueError("float64 scores are ranked by the caller (the device top-k ranks float32 values)")
+    scores = torch.empty(count, dtype=torch.float64 if float64 else torch.float32, device=tdev)
     status = torch.empty(count, dtype=torch.int32, device=tdev)
     stream = torch.cuda.current_stream(tdev).cuda_stream
     try:
         _ffi.check(
-            lib.pmx_score(
+            (lib.pmx_score_f64 if float64 else lib.pmx_score)(
                 mh.handle, library.handle, _weights_array(weights), first, count,
                 scores.data_ptr(), status.data_ptr(), ctypes.c_void_p(stream),
             )
@@ -235,7 +240,7 @@ def score_one(model, ligand, weights: dict[str, float] | None = None, device=Non
     n, c, ncl = packed.header(0)
     if ncl == 0 and n == 0 and c > 0:
         return 0  # `GraphMatcher.run()` returns the int 0 for a ligand without clusters (graph_match.py:95-96)
-    result = screen(model, packed, weights=weights, device=device)
+    result = screen(model, packed, weights=weights, device=device, float64=True)  # (the reference returns a Python float: a float64)
     if int(result.status.cpu()[0]) != 0:
         raise ValueError(
             f"ligand outside the structural limits of the GPU engine (nodes={n}, conformers={c}); see include/pmx.h"

@@ -78,7 +78,8 @@ def load_library(library: Path, cpus: int) -> tuple[list[str], PackedLibrary]:
 
 def write_csv(out: Path, names: list[str], scores: np.ndarray, status: np.ndarray | None = None) -> None:
     """`result.sort(key=score, reverse=True)` (stable) then `path,score` lines (screening.py:70-75).
-    Scores print with Python's float repr of the float32 value the GPU returned. Ligands the engine could not score
+    Scores print with Python's float repr of the value the GPU returned - the float64 mean of `graph_match.py:109` when `main` asks
+    for it (`pmx_score_f64`), as the reference's CSV does. Ligands the engine could not score
     (`status != 0`: outside the structural limits of include/pmx.h) come last with score `nan`."""
     key = scores.astype(np.float64)
     bad = np.isnan(key) if status is None else (np.asarray(status) != 0)
@@ -105,7 +106,7 @@ def main(argv=None) -> None:
         Hydrophobic=args.hydrophobic,
     )
     names, lib = load_library(Path(args.library_dir), args.cpus)
-    result = model.screen(lib, weights=weight)
+    result = model.screen(lib, weights=weight, float64=True)  # (the reference writes the float64 `GraphMatcher.run()` returns)
     write_csv(Path(args.out), names, result.scores.cpu().numpy(), result.status.cpu().numpy())
 
 

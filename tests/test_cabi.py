@@ -45,7 +45,7 @@ def test_struct_sizes_match_the_header():
     assert ctypes.sizeof(_ffi.ModelDesc) == 8 + 7 * 8
     assert ctypes.sizeof(_ffi.LibraryView) == 32
     assert ctypes.sizeof(_ffi.LibraryInfo) == 24 + 16
-    assert ctypes.sizeof(_ffi.ScoreStats) == 3 * 8 + 19 * 8 + 8 + 8 * 8 + 16 + 8  # + n_exact_values, dbg[8], n_path_bounds, n_path_drops, n_dead_entries
+    assert ctypes.sizeof(_ffi.ScoreStats) == 3 * 8 + 19 * 8 + 8 + 8 * 8 + 16 + 8 + 8  # + n_exact_values, dbg[8], n_path_bounds, n_path_drops, n_dead_entries, arena_capacity
 
 
 def test_invalid_arguments_return_status_not_crash(libpmx):

@@ -166,6 +166,47 @@ def test_screening_cli_writes_the_reference_csv(tmp_path):
     assert rel_err(scores, ref[got_idx]).max() < 2e-6 + 6e-8
 
 
+def test_float64_scores_are_the_unrounded_float32_scores():
+    """`pmx_score_f64` / `pmx_score_multi_f64`: the float64 mean the reference returns (graph_match.py:109). Its float32 rounding IS
+    pmx_score's output bit for bit, it is closer to the reference's float64 than a float32 can be where the tables allow, `_scoring`
+    hands it out as a Python float, and `topk` is refused with it (the device ranking is a float32 ranking)."""
+    import ctypes
+
+    import torch
+
+    from pharmaconet_amd import _ffi
+    from pharmaconet_amd.constants import weights_vector
+    from pharmaconet_amd.engine import DeviceLibrary, device_model
+
+    for name in ("set_6oim_c8", "set_6oim_c1", "set_s64_c64"):
+        model, lib, weights, d = load_golden(name)
+        f32 = model.screen(lib, weights=weights).scores.cpu().numpy()
+        res = model.screen(lib, weights=weights, float64=True)
+        f64 = res.scores.cpu().numpy()
+        assert f64.dtype == np.float64 and f32.dtype == np.float32
+        np.testing.assert_array_equal(f64.astype(np.float32), f32)
+        np.testing.assert_array_equal(res.status.cpu().numpy(), 0)
+        ref = d["score"]
+        assert np.all(f64[ref == 0] == 0.0) and rel_err(f64[ref != 0], ref[ref != 0]).max() < 2e-6
+        assert not np.array_equal(f64, f32.astype(np.float64))  # (it does carry more than float32 digits)
+    with pytest.raises(ValueError):
+        model.screen(lib, topk=5, float64=True)
+    # the multi-model entry point, through the C ABI
+    model, lib, _, d = load_golden("set_6oim_c8")
+    other, _, _, _ = load_golden("set_c21_c8")
+    dev = DeviceLibrary(lib)
+    handles = (ctypes.c_void_p * 2)(device_model(model, dev.device).handle, device_model(other, dev.device).handle)
+    w = (ctypes.c_float * 7)(*weights_vector(None))
+    out = torch.full((2, len(lib)), -1.0, dtype=torch.float64, device="cuda")
+    _ffi.check(_ffi.load().pmx_score_multi_f64(handles, 2, dev.handle, w, 0, len(lib), out.data_ptr(), None, None))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(out[0].cpu().numpy(), model.screen(lib, float64=True).scores.cpu().numpy())
+    np.testing.assert_array_equal(out[1].cpu().numpy().astype(np.float32), other.screen(lib).scores.cpu().numpy())
+    # _scoring returns the float64
+    one = lib.slice(3, 1)
+    assert model._scoring(one) == float(out[0, 3])
+
+
 def test_sharded_screen_merges_to_the_global_ranking():
     """Two contiguous shards scored separately (as two ranks would), per-shard top-k merged: the same
     ranking as one pass over the whole library (screening.py:70 order)."""

@@ -67,27 +67,51 @@ def test_device_merge_of_several_ranks_lists(world, k, n_per_rank):
         assert np.all(out_i.cpu().numpy()[n_real:] == -1)
 
 
-def test_bench_starts_its_own_ranks(tmp_path):
-    """`python bench.py --gpus 2 ...` with no WORLD_SIZE: two ranks, one line, n_gpus 2, merged top-k == one-process sort."""
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    env.update(PMX_BENCH_DEVICE="0", PMX_BENCH_BACKEND="gloo")
-    k = 200
-    cmd = [sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--ligands", "20000", "--steps", "1", "--warmup", "1", "--topk", str(k),
+def _run_bench_ranks(tmp_path, world, ligands, k, env_extra):
+    env = {k_: v for k_, v in os.environ.items() if k_ not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra)
+    cmd = [sys.executable, str(REPO / "bench.py"), "--gpus", str(world), "--ligands", str(ligands), "--steps", "1", "--warmup", "1", "--topk", str(k),
            "--no-cpu-baseline", "--no-serial-leg", "--dump-dir", str(tmp_path)]
     run = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
     assert run.returncode == 0, run.stderr[-4000:]
     lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, run.stdout[-2000:]
     line = json.loads(lines[0])
-    assert line["n_gpus"] == 2 and line["config"]["exchange"]["ranks"] == 2
+    assert line["n_gpus"] == world
     assert line["parity_sample"]["above_1e-5"] == 0 and line["parity_sample"]["zero_nonzero_mismatches"] == 0
-    shards = [np.load(tmp_path / f"rank{r}.npz") for r in range(2)]
+    shards = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
     n = len(shards[0]["scores"])
-    assert int(shards[1]["index_base"]) == n and line["config"]["ligands_per_gpu"] == n
-    assert abs(line["value"] - 2 * n * 8 / (line["ms_per_step"] * 1e-3)) <= 1e-6 * line["value"]
+    for r, s in enumerate(shards):
+        assert int(s["index_base"]) == r * n and len(s["scores"]) == n
+    assert line["config"]["ligands_per_gpu"] == n
+    assert abs(line["value"] - world * n * 8 / (line["ms_per_step"] * 1e-3)) <= 1e-6 * line["value"]
     all_s = np.concatenate([s["scores"] for s in shards])
-    order = _ranking(all_s, np.arange(2 * n), k)
+    order = _ranking(all_s, np.arange(world * n), k)
     for s in shards:  # every rank holds the same merged ranking
         assert s["top_indices"].tolist() == order.tolist()
         np.testing.assert_array_equal(s["top_scores"], all_s[order])
     assert not np.array_equal(shards[0]["scores"], shards[1]["scores"])  # (the shards are different ligands)
+    return line
+
+
+@pytest.mark.parametrize("world,ligands", [(2, 20000), (8, 8192)])
+def test_bench_starts_its_own_ranks(tmp_path, world, ligands):
+    """`python bench.py --gpus N ...` with no WORLD_SIZE: N ranks (all on device 0 here, lists exchanged over gloo), one line, n_gpus N,
+    merged top-k == one-process sort. World 8 is the shape of the driver's last scaling point (small buffers: eight workspaces on one device)."""
+    extra = dict(PMX_BENCH_DEVICE="0", PMX_BENCH_BACKEND="gloo")
+    if world > 2:
+        extra.update(PMX_ARENA_MB="2048", PMX_BIG_TOTAL_MB="512", PMX_TASKQ_MB="128")
+    line = _run_bench_ranks(tmp_path, world, ligands, 200, extra)
+    assert line["config"]["exchange"]["ranks"] == world
+
+
+def test_bench_two_ranks_over_rccl(tmp_path):
+    """The real thing where the box has two GPUs: one rank per GPU, the per-rank top-k lists all-gathered by libpmx's own RCCL communicator
+    (`pmx_topk_allgather`), the count of ranks taken from RCCL itself (`pmx_comm_info`). Skipped on a 1-GPU box (RCCL refuses two ranks on one device)."""
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (one rank per GPU over RCCL)")
+    line = _run_bench_ranks(tmp_path, 2, 20000, 200, {})
+    ex = line["config"]["exchange"]
+    assert ex["rccl_ranks"] == 2 == line["n_gpus"] and "ncclAllGather" in ex["collective"]

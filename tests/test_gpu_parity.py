@@ -176,6 +176,51 @@ def test_bench_size_library_properties_and_oracle_sample(oracle, monkeypatch):
     assert rel_err(got[~zero], ref[~zero]).max() < RTOL + 6e-8
 
 
+def test_survey_library_at_full_size(oracle, monkeypatch):
+    """BASELINE.json configs[1] on SURVEY.md 8d-2's OWN generator (`bench.py --library survey`, tools/survey_library.py): 1 000 000 independent
+    ligands x 8 conformers, mean 20 nodes. Scores finite and non-negative; bit-identical when the pass is cut into chunks of 100 000 and when
+    a window is scored on its own; the first 20 000 ligands bit-identical with the bound test off (the whole tree walked, as the reference
+    walks it); 2 000 sampled ligands against the CPU oracle."""
+    import os
+
+    import torch
+
+    from pharmaconet_amd import PackedLibrary
+    from pharmaconet_amd.constants import TYPE_ID, weights_vector
+    from pharmaconet_amd.engine import DeviceLibrary
+    from tools.survey_library import survey_library
+
+    model, _, _, _ = load_golden("set_6oim_c8")
+    st = model.__getstate__()
+    centers = np.array([n["center"] for n in st["nodes"]], dtype=np.float64)
+    types = np.array([TYPE_ID[n["type"]] for n in st["nodes"]])
+    offsets, data, stats = survey_library(centers, types, 1_000_000, 8, "cuda")
+    assert abs(stats["mean_nodes"] - 20.0) < 0.1 and abs(stats["active_share"] - 0.1) < 0.005
+    lib = DeviceLibrary.from_device_buffers(offsets, data)
+    assert len(lib) == 1_000_000 and lib.num_unsupported == 0 and lib.max_nodes <= 32
+    res = model.screen(lib)
+    full = res.scores
+    assert torch.isfinite(full).all() and (full >= 0).all() and (res.status == 0).all()
+    with monkeypatch.context() as mp:
+        mp.setenv("PMX_SUPER", "100000")
+        assert torch.equal(model.screen(lib).scores, full)
+    first, count = 612_345, 50_000
+    assert torch.equal(model.screen(lib, first=first, count=count).scores, full[first : first + count])
+    with monkeypatch.context() as mp:
+        mp.setenv("PMX_TREE_FLAGS", "4")
+        assert torch.equal(model.screen(lib, first=0, count=20_000).scores, full[:20_000])
+    rng = np.random.default_rng(2025)
+    pick = np.sort(rng.choice(len(lib), size=2000, replace=False))
+    off = offsets[torch.from_numpy(np.concatenate([pick, pick + 1])).cuda()].cpu().numpy()
+    lo, hi = off[: pick.size], off[pick.size :]
+    sample = PackedLibrary.from_records([data[int(a) : int(b)].cpu().numpy().tobytes() for a, b in zip(lo, hi)])
+    ref = oracle.oracle_score(model.flat, sample, weights_vector(None), num_threads=min(os.cpu_count() or 8, 64))
+    got = full[torch.from_numpy(pick).cuda()].cpu().numpy()
+    zero = ref == 0
+    assert np.all(got[zero] == 0.0)
+    assert rel_err(got[~zero], ref[~zero]).max() < RTOL + 6e-8
+
+
 def test_config2_shard_size_properties(oracle):
     """BASELINE.json configs[2]'s per-GPU shard (100 M ligands over 8 GPUs = 12 500 992 per GPU, 20.6 GB resident): one pass;
     scores finite and non-negative; a 1 M-ligand window scored on its own gives the same bits (the window's first ligand is

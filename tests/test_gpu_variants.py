@@ -473,6 +473,7 @@ def test_topk_exchange_through_the_c_abi_single_rank():
     k = 40
     res = model.screen(lib, topk=k, index_base=5000)
     ex = TopkExchange("cuda:0")
+    assert (ex.rccl_rank, ex.rccl_ranks, ex.rccl_device) == (0, 1, 0)  # (pmx_comm_info: as RCCL reports them)
     top_s, top_i = ex.allgather(res.topk_scores, res.topk_indices, k)
     torch.cuda.synchronize()
     want_s, want_i = merge_topk(res.topk_scores.cpu().numpy(), res.topk_indices.cpu().numpy(), k)

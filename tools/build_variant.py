@@ -19,13 +19,20 @@ def main():
     out = REPO / "variants"
     out.mkdir(exist_ok=True)
     objs = []
+    procs = []
     for src in SOURCES:
         obj = out / f"{name}_{src.rsplit('.', 1)[0]}.o"
-        if src.endswith(".hip") and src != "pmx_api.hip" and (out / f"base_{src.rsplit('.', 1)[0]}.o").exists():
-            obj = out / f"base_{src.rsplit('.', 1)[0]}.o"  # (only pmx_api.hip holds the screening kernels)
-        else:
-            subprocess.run([hipcc(), *FLAGS, *extra, f"-I{REPO / 'include'}", f"-I{CSRC}", "-c", str(CSRC / src), "-o", str(obj)], check=True)
+        # (the two translation units that include pmx_screen.hip - the product kernels and the validation kernels - are always compiled
+        # with the variant's flags: a debug kernel built with the base macros under a host side built with the variant's would have
+        # another LDS layout and other launch bounds)
+        screening = src in ("pmx_api.hip", "pmx_screen_debug.hip")
+        if src.endswith(".hip") and not screening and (out / f"base_{src.rsplit('.', 1)[0]}.o").exists():
+            obj = out / f"base_{src.rsplit('.', 1)[0]}.o"
+        else:  # (the compiles run side by side: the two screening units take a minute each)
+            procs.append(subprocess.Popen([hipcc(), *FLAGS, *extra, f"-I{REPO / 'include'}", f"-I{CSRC}", "-c", str(CSRC / src), "-o", str(obj)]))
         objs.append(str(obj))
+    if any(pr.wait() != 0 for pr in procs):
+        sys.exit("build_variant: a compile failed")
     lib = out / f"libpmx_{name}.so"
     subprocess.run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", str(lib), "-L/opt/rocm/lib", "-lrccl"], check=True)
     print(lib)
