@@ -193,6 +193,145 @@ def end_to_end(molecules, lib, data, ms_per_step, n_conf_total):
     }
 
 
+def tile_features(flat, reps, rng, node_sigma=0.35, conf_sigma=0.30):
+    """`reps` copies of a flat feature batch (flatten_features) as ONE batch, every copy with its own geometry: each atom displaced by
+    N(0, node_sigma) in all conformers and every conformer coordinate by a further N(0, conf_sigma) - the host-side twin of
+    tools.synthetic.expand_library_on_device, so that what the pipeline packs and scores is the bench library's kind of ligand."""
+    n_mol = len(flat["atom_off"]) - 1
+    out = {}
+    for off_key, arrays in (("atom_off", ("atomic_num",)), ("nbr_off", ("nbr",)), ("feat_off", ("feat_type", "feat_flags")),
+                            ("feat_atom_off", ("feat_atoms",)), ("feat_center_off", ("feat_centers",)), ("pos_off", ())):
+        off = flat[off_key].astype(np.uint64)
+        total = off[-1]
+        out[off_key] = np.concatenate([(off[:-1][None, :] + (np.arange(reps, dtype=np.uint64) * total)[:, None]).reshape(-1), [reps * total]]).astype(np.uint64)
+        for a in arrays:
+            out[a] = np.tile(flat[a], reps)
+    out["n_conf"] = np.tile(flat["n_conf"], reps)
+    # positions [atoms][C][3] per molecule: per-atom shift + per-coordinate jitter
+    base = flat["positions"]
+    n_atoms = np.diff(flat["atom_off"].astype(np.int64))
+    conf = flat["n_conf"].astype(np.int64)
+    atom_of_float = np.repeat(np.arange(int(n_atoms.sum())), np.repeat(conf * 3, n_atoms))  # float -> atom (of the base batch)
+    axis = np.tile(np.arange(3), base.size // 3)
+    pos = np.empty(reps * base.size, dtype=np.float32)
+    for r in range(reps):
+        shift = rng.normal(scale=node_sigma, size=(int(n_atoms.sum()), 3)).astype(np.float32)
+        pos[r * base.size : (r + 1) * base.size] = base + shift[atom_of_float, axis] + rng.normal(scale=conf_sigma, size=base.size).astype(np.float32)
+    out["positions"] = pos
+    assert len(out["atom_off"]) == n_mol * reps + 1
+    return out
+
+
+def end_to_end_overlapped(molecules, pocket, n_lig_target, topk_k, device, n_chunks=4):
+    """The path of `screening.py:63-70` as ONE pipeline: host packer threads -> pinned double buffer -> H2D on a copy stream -> library
+    upload + `pmx_score` + `pmx_topk` on the compute stream, chunk by chunk, the packer running ahead of the GPU. Timed from the first
+    byte packed to the merged top-k on the host. (Perception is in front of this and needs the chemistry toolkit.)"""
+    import ctypes
+    import threading
+
+    import torch
+
+    from pharmaconet_amd import _ffi, engine
+    from pharmaconet_amd.engine import DeviceLibrary
+    from pharmaconet_amd.library import flatten_features
+
+    cores, host = host_cores()
+    threads = max(1, min(cores * 2, 64))  # (the packer waits on memory: two threads per granted core)
+    chunk_mols = max(len(molecules), (n_lig_target // n_chunks) // len(molecules) * len(molecules))
+    reps = chunk_mols // len(molecules)
+    flat = tile_features(flatten_features(molecules), reps, np.random.default_rng(12345))
+    lib = _ffi.load_packer()
+    n = chunk_mols
+    batch = _ffi.FeatureBatch(n, *(flat[k].ctypes.data for k in (
+        "atom_off", "atomic_num", "nbr_off", "nbr", "feat_off", "feat_type", "feat_flags", "feat_atom_off", "feat_atoms",
+        "feat_center_off", "feat_centers", "n_conf", "pos_off", "positions")))
+    need = ctypes.c_uint64(0)
+    off_probe = np.zeros(n + 1, dtype=np.uint64)
+    assert lib.pmx_pack_features(ctypes.byref(batch), threads, off_probe.ctypes.data, None, 0, ctypes.byref(need), None) == 0
+    cap = int(need.value)
+    pinned = [torch.empty(cap, dtype=torch.uint8).pin_memory() for _ in range(2)]
+    pinned_off = [torch.empty(n + 1, dtype=torch.int64).pin_memory() for _ in range(2)]
+    dev_data = [torch.empty(cap, dtype=torch.uint8, device=device) for _ in range(2)]
+    dev_off = [torch.empty(n + 1, dtype=torch.int64, device=device) for _ in range(2)]
+    copy_stream = torch.cuda.Stream(device)
+    compute = torch.cuda.current_stream(device)
+
+    def run(timed):
+        packed = [threading.Event() for _ in range(n_chunks)]
+        free = [threading.Event() for _ in range(n_chunks)]  # free[i]: pinned buffer of chunk i may be overwritten (its H2D is done)
+        nbytes = [0] * n_chunks
+        err = []
+
+        def producer():
+            try:
+                for i in range(n_chunks):
+                    if i >= 2:
+                        free[i - 2].wait()
+                    got = ctypes.c_uint64(0)
+                    rc = lib.pmx_pack_features(ctypes.byref(batch), threads, pinned_off[i % 2].data_ptr(), pinned[i % 2].data_ptr(), cap, ctypes.byref(got), None)
+                    if rc != 0:
+                        raise RuntimeError(lib.pmx_last_error().decode())
+                    nbytes[i] = int(got.value)
+                    packed[i].set()
+            except Exception as e:  # pragma: no cover
+                err.append(e)
+                for ev in packed:
+                    ev.set()
+
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        th = threading.Thread(target=producer)
+        th.start()
+        tops, libs, h2d_done, scored = [], [], [], []
+        for i in range(n_chunks):
+            packed[i].wait()
+            if err:
+                raise err[0]
+            b = i % 2
+            with torch.cuda.stream(copy_stream):
+                if i >= 2:
+                    copy_stream.wait_event(scored[i - 2])  # the device buffer's last reader
+                dev_data[b][: nbytes[i]].copy_(pinned[b][: nbytes[i]], non_blocking=True)
+                dev_off[b].copy_(pinned_off[b], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(copy_stream)
+            h2d_done.append(ev)
+            compute.wait_event(ev)
+            ev.synchronize()  # (the pinned buffer is free for the packer; pmx_library_upload reads the offsets on the host side of its checks)
+            free[i].set()
+            dlib = DeviceLibrary.from_device_buffers(dev_off[b], dev_data[b][: nbytes[i]], device)
+            res = engine.screen(pocket, dlib, topk=topk_k, index_base=i * n)
+            sev = torch.cuda.Event()
+            sev.record(compute)
+            scored.append(sev)
+            tops.append((res.topk_scores, res.topk_indices))
+            libs.append(dlib)
+        th.join()
+        top = engine.topk(torch.cat([t[0] for t in tops]), topk_k, indices=torch.cat([t[1] for t in tops]))
+        best = top[0].cpu()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        total_conf = sum(l.total_conformers for l in libs)
+        for l in libs:
+            l.close()
+        return dt, total_conf, best
+
+    run(False)  # warm: pinned pages touched, workspaces sized for the chunk
+    dt, total_conf, best = min((run(True) for _ in range(3)), key=lambda r: r[0])
+    return {
+        "overlapped_ligand_conformers_per_s": total_conf / dt,
+        "overlapped_s": dt,
+        "ligands": n * n_chunks,
+        "chunks": n_chunks,
+        "pack_threads": threads,
+        "host": host,
+        "best_score_of_the_run": float(best[0]),
+        "note": "packer threads -> pinned double buffer -> H2D on a copy stream -> pmx_library_upload + pmx_score + pmx_topk on the compute stream, per chunk, "
+                "the packer running ahead of the GPU; first byte packed to merged top-k on the host; best of three. Bound by the slower of the two "
+                "sides: the packer on the cores the box grants, or the GPU pass",
+    }
+
+
 def host_sample(offsets, data, index):
     """The records `index` (ascending ligand numbers) of the device library as a host `PackedLibrary`."""
     from pharmaconet_amd.library import PackedLibrary
@@ -592,8 +731,10 @@ def main():
         if world == 1 and not args.no_serial_leg and molecules is not None:
             try:
                 out["end_to_end"] = end_to_end(molecules, lib, data, ms_per_step, n_conf_total * len(pockets))
+                if len(pockets) == 1:
+                    out["end_to_end"].update(end_to_end_overlapped(molecules, pockets[0], n_lig, args.topk, device))
             except Exception as e:  # never lose the bench line over the side measurement
-                out["end_to_end"] = {"error": repr(e)}
+                out["end_to_end"] = {**(out.get("end_to_end") or {}), "error": repr(e)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

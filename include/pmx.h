@@ -117,8 +117,8 @@ int pmx_library_destroy(pmx_library *lib);
  * PMX_OVERLAP set and more than one chunk, the rounds of a chunk run on a side stream that the workspace owns, beside the
  * next chunk's ligand kernel: they start behind an event recorded on `stream` and `stream` waits for their last event before
  * the call's work counts as done, so a caller sees one stream-ordered operation either way. Work buffers are kept per (device, stream) for at most PMX_MAX_WORKSPACES (default 4) streams per device - the least recently used idle workspace is
- * freed when one more stream appears. At the defaults: about 24 GB for libraries of up to 8 conformers and an 11-cluster model (16 GB table arena,
- * 1 GB task queue, <= 4 GB large slices, 0.7 GB slices, 1.8 GB path sums), about 70 GB at 32 / 64 conformer lanes (32 GB arena, 8 GB queue, <= 16 GB
+ * freed when one more stream appears. At the defaults: about 73 GB for libraries of up to 8 conformers and an 11-cluster model (64 GB table arena,
+ * 2 GB task queue, <= 4 GB large slices, 0.7 GB slices, 1.8 GB path sums), about 70 GB at 32 / 64 conformer lanes (32 GB arena, 8 GB queue, <= 16 GB
  * large slices, slices that grow with the square of the model's cluster count); PMX_ARENA_MB, PMX_TASKQ_MB size one buffer set, and a second
  * set exists only while PMX_OVERLAP is in use. Without PMX_ARENA_MB the table arena takes at most a third of the device memory that is free when it is first allocated, and it shrinks when device memory is short - a smaller arena is slower, never
  * wrong - and keeps the size it got until pmx_release_workspaces. PMX_LIGAND_TOO_LARGE is reported for a ligand whose tables exceed a whole

@@ -730,8 +730,11 @@ static int score_screen(const pmx_model *const *models, int n_models, const pmx_
     }
     const uint32_t flags = (uint32_t)env_long("PMX_TREE_FLAGS", 0);
     const uint32_t max_nodes = (uint32_t)std::max(4, std::min(lib->info.max_nodes, PMX_MAX_LIGAND_NODES));
-    const uint32_t lig_budget = (uint32_t)std::max<long>(16, env_long("PMX_BUDGET", 384));
-    const uint32_t task_budget = (uint32_t)std::max<long>(16, env_long("PMX_TASK_BUDGET", lig_budget)); // a queued subtree's own budget
+    // [MI355X] round 6, passes a walk may take before it splits. On the bench library (92 passes per ligand, 7 % of the walks over 384) 384 / 384
+    // and 768 / 384 are the same 99.1 ms; on SURVEY 8d-2's own library (800 passes per ligand) 384 sends 57-74 % of the ligands to the arena and
+    // the queue (714 ms with a 64 GB arena, queue full), 768 a third of them (539 ms). A queued subtree keeps the smaller budget: the rounds' tail.
+    const uint32_t lig_budget = (uint32_t)std::max<long>(16, env_long("PMX_BUDGET", 768));
+    const uint32_t task_budget = (uint32_t)std::max<long>(16, env_long("PMX_TASK_BUDGET", std::min<long>(lig_budget, 384))); // a queued subtree's own budget
     const int rounds = (int)std::max<long>(1, env_long("PMX_ROUNDS", 12));
     const int task_decay_from = (int)std::max<long>(1, env_long("PMX_TASK_DECAY_FROM", 99));
     const uint32_t task_budget_min = (uint32_t)std::max<long>(8, env_long("PMX_TASK_BUDGET_MIN", 48));
@@ -868,7 +871,10 @@ static int score_screen(const pmx_model *const *models, int n_models, const pmx_
         // synchronise, free and fail again each time)
         // (32 / 64 conformer lanes: records of megabytes - 16 GB held the split trees of a 16 384-ligand chunk of the stress configuration
         // to within 3 %, and every tree past the end is walked by one wavefront alone)
-        size_t arena_want = (size_t)std::max<long>(1, env_long("PMX_ARENA_MB", G >= 32 ? 32768 : 16384)) << 20;
+        // ([MI355X] round 6: 64 GB at up to 16 lanes. SURVEY 8d-2's library puts 29 GB of split trees' tables into the arena per 1 M-ligand chunk at the old
+        // budget, 17 GB at the new one; with a 16 GB arena 200 000 trees found it full and were walked by one wavefront each - the longest for 1.2 M
+        // passes, the pass 3.4 s instead of 0.54 s. The part has 288 GB.)
+        size_t arena_want = (size_t)std::max<long>(1, env_long("PMX_ARENA_MB", G >= 32 ? 32768 : 65536)) << 20;
         if (!c.arena && !std::getenv("PMX_ARENA_MB")) { // first allocation, no explicit size: at most a third of what the device has free
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b / 3 < arena_want) {
@@ -884,7 +890,7 @@ static int score_screen(const pmx_model *const *models, int n_models, const pmx_
         int rc2 = grow(&c.arena, &c.arena_bytes, arena_want, stream, ws.side, arena_min);
         if (rc2) return rc2;
         if (c.arena_bytes < asked) c.arena_shrunk_to = c.arena_bytes;
-        rc2 = grow(&c.queue, &c.queue_bytes, (size_t)std::max<long>(1, env_long("PMX_TASKQ_MB", 1024L * std::max(1, G / 8))) << 20, stream, ws.side);
+        rc2 = grow(&c.queue, &c.queue_bytes, (size_t)std::max<long>(1, env_long("PMX_TASKQ_MB", (G >= 32 ? 1024L : 2048L) * std::max(1, G / 8))) << 20, stream, ws.side);
         if (rc2) return rc2;
         rc2 = grow(&c.lists, &c.lists_bytes, (size_t)super_max * 12, stream, ws.side);
         if (rc2) return rc2;

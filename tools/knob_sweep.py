@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--model", default="6oim")
     ap.add_argument("--pockets", type=int, default=1)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--library", choices=("expanded", "survey"), default="expanded")
     ap.add_argument("settings", nargs="*")
     args = ap.parse_args()
     import torch
@@ -36,7 +37,10 @@ def main():
     if args.pockets > 1:
         pockets = [PharmacophoreModel.load(REPO / "tests" / "golden" / "pockets16" / f"model_{k:02d}.pm") for k in range(args.pockets)]
     device = torch.device("cuda", 0)
-    lib, offsets, data, _ = bench.build_library(model, args.ligands or n_default, conf, topo, 0, device, active, seed)
+    if args.library == "survey":
+        lib, offsets, data, _ = bench.build_survey_library(model, args.ligands or n_default, conf, 0, device, active)
+    else:
+        lib, offsets, data, _ = bench.build_library(model, args.ligands or n_default, conf, topo, 0, device, active, seed)
     n_conf = lib.total_conformers * len(pockets)
     ref = None
     for setting in [""] + list(args.settings):
@@ -68,7 +72,7 @@ def main():
             n = len(lib)
             print(f"{setting or '(default)':60s} {best * 1e3:8.2f} ms {n_conf / best / 1e6:7.2f} M/s | lig {st['ms_ligand']:6.1f} tasks {st['ms_tasks']:5.1f} | "
                   f"frames {st['n_frames'] / n:6.1f} passes {st['n_passes'] / n:6.1f} tasks/lig {st['n_tasks'] / n:5.2f} over {st['n_heavy'] / n:5.3f} max {st['max_passes']} "
-                  f"qovf {st['queue_overflow']} | {same}", flush=True)
+                  f"qovf {st['queue_overflow']} arena {st['arena_bytes'] / 2**30:.1f}/{st.get('arena_capacity', 0) / 2**30:.0f} GB | {same}", flush=True)
             if any(st.get("dbg", [])):  # instrumented builds (-DPMX_COUNTERS / _TICKS): the walker's counters per ligand
                 print("    dbg/ligand:", [round(x / n, 2) for x in st["dbg"]], "path tests", round(st.get("n_path_bounds", 0) / n, 1), "drops", round(st.get("n_path_drops", 0) / n, 1), flush=True)
         finally:
