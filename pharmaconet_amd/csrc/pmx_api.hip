@@ -234,7 +234,7 @@ static int build_pair_functions(pmx_model *m, const pmx_model_desc *d, const std
             for (uint32_t i = 0; i < ncell; ++i) {
                 const float x0 = (float)i * h, x1 = (i + 1 == ncell) ? INF : (float)(i + 1) * h;
                 int hits = 0;
-                float2 w = make_float2(INF, -INF); // never passes
+                float2 w = make_float2(INF, INF); // never passes (no distance is >= INF; written so that lo <= hi holds for every window: the device's median-of-three test)
                 for (const auto &pr : pass)
                     if (pr.first < x1 && pr.second >= x0) {
                         ++hits;

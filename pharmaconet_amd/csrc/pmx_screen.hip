@@ -135,9 +135,37 @@ template <int G>
 __host__ __device__ constexpr bool cand_bounds() {
     return 64 / G >= 4;
 }
+// Upper bounds need no precision (round 6): W is float32 rounded up instead of float64, the OB rows bfloat16 rounded up instead of float32 -
+// 12 KB of a bench ligand's 25 KB of tables were these two. (PMX_SLIM_BOUNDS=0 builds the round-5 layout for A/B runs.)
+#ifndef PMX_SLIM_BOUNDS
+#define PMX_SLIM_BOUNDS 0 // ([MI355X] W as float32: tables 43.5 -> 43.0 ms, the walk 2 ms slower - 100.8 against 99.7 ms per pass, twice; not kept)
+#endif
+#ifndef PMX_SLIM_OB
+#define PMX_SLIM_OB 1 // ([MI355X] OB as bfloat16 rounded up: 99.7 -> 98.3 ms per pass, 200.6 -> 184.9 KB per ligand across the L2 <-> fabric boundary, frames 60.5 -> 60.7)
+#endif
+#ifndef PMX_SLIM_PA
+#define PMX_SLIM_PA 0 // path_bound()'s pair sums as bfloat16 rounded up
+#endif
+constexpr bool kSlimPA = PMX_SLIM_PA != 0;
+typedef std::conditional<kSlimPA, uint16_t, float>::type PaElt;
+constexpr bool kSlimBounds = PMX_SLIM_BOUNDS != 0; // W as float32
+constexpr bool kSlimOB = PMX_SLIM_OB != 0;         // OB as bfloat16
+template <int G>
+__host__ __device__ constexpr uint32_t ob_elt_bytes() {
+    return (kSlimOB && cand_bounds<G>()) ? 2u : 4u;
+}
+// bytes of the W region: a float (double before round 6) per candidate and conformer - and room for the cluster centres build_tables() parks there
+// (float2[nl][G]) until build_bounds() writes W
+template <int G>
+__host__ __device__ inline uint32_t rec_w_bytes(uint32_t ksumtot, uint32_t nl) {
+    if (!cand_bounds<G>()) return 0u;
+    if (!kSlimBounds) return ksumtot * G * 8u;
+    const uint32_t w = ksumtot * G * 4u, park = nl * G * 8u;
+    return (uint32_t)round16((uint64_t)(w > park ? w : park));
+}
 template <int G>
 __host__ __device__ inline uint32_t rec_v_off(uint32_t ksumtot, uint32_t T, uint32_t nl) {
-    return rec_w_off<G>(ksumtot, T, nl) + (cand_bounds<G>() ? ksumtot * G * 8u : 0u);
+    return rec_w_off<G>(ksumtot, T, nl) + rec_w_bytes<G>(ksumtot, nl);
 }
 template <int G>
 __host__ __device__ inline uint32_t rec_ob_off(uint32_t ksumtot, uint32_t T, uint32_t nl) {
@@ -151,13 +179,13 @@ __host__ __device__ constexpr uint32_t ob_rows(uint32_t nl) {
 }
 template <int G>
 __host__ __device__ inline uint32_t rec_ci_off(uint32_t ksumtot, uint32_t T, uint32_t nl) {
-    return rec_ob_off<G>(ksumtot, T, nl) + ob_rows<G>(nl) * ksumtot * G * 4u;
+    return rec_ob_off<G>(ksumtot, T, nl) + (uint32_t)round16((uint64_t)ob_rows<G>(nl) * ksumtot * G * ob_elt_bytes<G>());
 }
 template <int G>
 __host__ __device__ inline uint64_t rec_bytes(uint32_t ksumtot, uint32_t T, uint32_t nl) {
     return (uint64_t)rec_s_off<G>() + round16((uint64_t)ksumtot * G * 4) + round16((uint64_t)T * G * 4) + (uint64_t)(nl + 1) * G * 8 +
-           (cand_bounds<G>() ? (uint64_t)ksumtot * G * 8 : 0ull) + round16((uint64_t)T * vmask_bytes<G>()) +
-           (uint64_t)ob_rows<G>(nl) * ksumtot * G * 4 + 2 * round16((uint64_t)ksumtot);
+           (uint64_t)rec_w_bytes<G>(ksumtot, nl) + round16((uint64_t)T * vmask_bytes<G>()) +
+           round16((uint64_t)ob_rows<G>(nl) * ksumtot * G * ob_elt_bytes<G>()) + 2 * round16((uint64_t)ksumtot);
 }
 // (DP u8[ksumtot] follows LV: rec_ci_off + round16(ksumtot))
 template <int G>
@@ -255,6 +283,28 @@ struct ScreenParams {
 
 
 // ------------------------------------------------------------------------------------------------ helpers
+// Instruction injection (analysis builds only: -DPMX_INJECT_VALU_ITEM=n, -DPMX_INJECT_VALU_WALK=n, -DPMX_INJECT_SALU_WALK=n): n extra instructions of one
+// kind per table item batch / per trip of the walker's loop. The slope of the pass time against n says which issue port a phase is bound by.
+template <int N>
+__device__ __forceinline__ void inject_valu() {
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("v_nop");
+}
+template <int N>
+__device__ __forceinline__ void inject_salu() {
+    int x = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("s_add_u32 %0, %0, 1" : "+s"(x) : : "scc");
+}
+#ifndef PMX_INJECT_VALU_ITEM
+#define PMX_INJECT_VALU_ITEM 0
+#endif
+#ifndef PMX_INJECT_VALU_WALK
+#define PMX_INJECT_VALU_WALK 0
+#endif
+#ifndef PMX_INJECT_SALU_WALK
+#define PMX_INJECT_SALU_WALK 0
+#endif
 
 // A ligand's score: the float32 of the float64 mean the reference returns (graph_match.py:109), or that float64 itself (pmx_score_f64).
 __device__ __forceinline__ void put_score(const ScreenParams &p, uint32_t li, double v) {
@@ -330,6 +380,15 @@ __device__ inline float float_up(double x) {
     const uint32_t b = __float_as_uint(f);
     return __uint_as_float(f > 0.f ? b + 1u : (f < 0.f ? b - 1u : 1u));
 }
+// The smallest bfloat16 that is not below f, as its 16 bits (NaN stays NaN; +inf beyond the largest finite one - an upper bound either way).
+__device__ inline uint16_t bf16_up(float f) {
+    const uint32_t b = __float_as_uint(f);
+    if (f != f) return (uint16_t)0x7fc0u;
+    const uint32_t hi = b >> 16;
+    if ((b & 0xffffu) == 0u || (b >> 31)) return (uint16_t)hi; // exact, or negative: dropping low bits moves a negative value up
+    return (uint16_t)(hi + 1u);
+}
+__device__ inline float bf16_value(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
 __device__ inline float norm3f(float dx, float dy, float dz) { // np.linalg.norm of a float32 3-vector (ligand.py:349-351)
     float s = dx * dx;
     s = s + dy * dy;
@@ -615,7 +674,7 @@ __device__ __forceinline__ bool probe(Walk<G> &w, int f, int nm, int cand, uint6
     // DP[x]: no chain of pairwise compatible candidates that starts with x holds more than DP[x] of them (chain_lengths()), so a
     // node with 5 matches lies below a path of nm matches through x only if DP[x] >= 5 - nm. The child itself first, then every
     // candidate the search would try: what they rule out is not there to find.
-    const unsigned char *DP = w.OBb + ((size_t)ob_rows<G>((uint32_t)nl) * w.ksumtot * G * 4u + (size_t)round16((uint64_t)w.ksumtot));
+    const unsigned char *DP = w.OBb + (round16((uint64_t)ob_rows<G>((uint32_t)nl) * w.ksumtot * G * ob_elt_bytes<G>()) + (size_t)round16((uint64_t)w.ksumtot));
     if (uni((int)DP[rl(w.hks, f) + cand]) < 5 - nm) return false;
     // enter the child
     const int fbase = f;
@@ -714,8 +773,16 @@ __device__ __forceinline__ bool probe(Walk<G> &w, int f, int nm, int cand, uint6
 // factor covers) and extended by Y's entries here - they are the sums of Y's own frame when the walker goes there.
 // On the bench library the walker enters 4 times fewer frames with it (tests/bound_study: 272 -> 69 per ligand), 9-13 times
 // fewer on the fixture pockets.
+__device__ __forceinline__ float pa_get(const PaElt *row, size_t i) {
+    if constexpr (kSlimPA) return bf16_value(row[i]);
+    else return row[i];
+}
+__device__ __forceinline__ void pa_put(PaElt *row, size_t i, float v) { // (-inf stays -inf; sums are rounded up: an upper bound)
+    if constexpr (kSlimPA) row[i] = bf16_up(v);
+    else row[i] = v;
+}
 template <int G>
-__device__ __forceinline__ bool path_bound(const Walk<G> &w, const ScreenParams &p, float *pa, float *ub, const double *tch, const unsigned long long *pool,
+__device__ __forceinline__ bool path_bound(const Walk<G> &w, const ScreenParams &p, PaElt *pa, float *ub, const double *tch, const unsigned long long *pool,
                                            int f, int nm, int bsel, uint64_t cmask) {
     constexpr int SLOTS = 64 / G;
     const int lane = lane_id();
@@ -724,10 +791,10 @@ __device__ __forceinline__ bool path_bound(const Walk<G> &w, const ScreenParams 
     const uint32_t ksumtot = w.ksumtot;
     const uint32_t x0 = (uint32_t)rl(w.hks, f + 1); // first candidate of the levels below f
     const float *Pf = reinterpret_cast<const float *>(w.Pb) + (long)match_base<G>(w, f, bsel) * G; // Y's entries: Pf[x * G + c] (the base may be negative, base + x is not)
-    const float *OB = reinterpret_cast<const float *>(w.OBb) + (size_t)f * ksumtot * G;
-    const unsigned char *LV = w.OBb + (size_t)nl * ksumtot * G * 4u;
-    const float *pin = pa + (size_t)nm * ksumtot * G;
-    float *pout = pa + (size_t)(nm + 1) * ksumtot * G;
+    const unsigned char *OB = w.OBb + (size_t)f * ksumtot * G * ob_elt_bytes<G>();
+    const unsigned char *LV = w.OBb + round16((uint64_t)nl * ksumtot * G * ob_elt_bytes<G>());
+    const PaElt *pin = pa + (size_t)nm * ksumtot * G;
+    PaElt *pout = pa + (size_t)(nm + 1) * ksumtot * G;
     for (int i = lane; i < (nl - f - 1) * G; i += 64) ub[(f + 1) * G + i] = 0.f;
     lds_sync();
     // kPathWindows windows of SLOTS candidates per trip, everything of a window in one round of loads (the entries of Y with the deeper
@@ -741,15 +808,16 @@ __device__ __forceinline__ bool path_bound(const Walk<G> &w, const ScreenParams 
             on[u] = x + (uint32_t)(u * SLOTS + s) < ksumtot;
             xx[u] = on[u] ? x + (uint32_t)(u * SLOTS + s) : x0;
             lv[u] = LV[xx[u]];
-            ob[u] = OB[(size_t)xx[u] * G + c];
-            have[u] = nm ? pin[(size_t)xx[u] * G + c] : 0.f;
+            if (ob_elt_bytes<G>() == 2) ob[u] = bf16_value(reinterpret_cast<const uint16_t *>(OB)[(size_t)xx[u] * G + c]);
+            else ob[u] = reinterpret_cast<const float *>(OB)[(size_t)xx[u] * G + c];
+            have[u] = nm ? pa_get(pin, (size_t)xx[u] * G + c) : 0.f;
             pv[u] = Pf[(size_t)xx[u] * G + c];
         }
 #pragma unroll
         for (int u = 0; u < kPathWindows; ++u) {
             const float sum = pv[u] > 0.f ? have[u] + pv[u] : -__builtin_inff(); // (-inf stays -inf: a candidate out for this conformer stays out)
             if (on[u]) {
-                pout[(size_t)xx[u] * G + c] = sum;
+                pa_put(pout, (size_t)xx[u] * G + c, sum);
                 const float v = fmaxf(sum + ob[u], 0.f); // (a NaN self entry - zero weights - can raise no maximum: 0)
                 atomicMax(reinterpret_cast<unsigned int *>(ub) + lv[u] * G + (uint32_t)c, __float_as_uint(v));
             }
@@ -786,7 +854,7 @@ __device__ __forceinline__ bool path_bound_wide(const Walk<G> &w, const double t
     const uint32_t ksumtot = w.ksumtot;
     const uint32_t x0 = (uint32_t)rl(w.hks, f + 1); // first candidate of the levels below f
     const float *BF = reinterpret_cast<const float *>(w.OBb);
-    const unsigned char *LV = w.OBb + (size_t)ksumtot * G * 4u;
+    const unsigned char *LV = w.OBb + round16((uint64_t)ksumtot * G * 4u);
     const unsigned char *Vy = w.Vb + (long)match_base<G>(w, f, bsel) * (long)VB; // Y's masks: Vy + x * VB (the base may be negative, base + x is not)
     float below = 0.f, cur = 0.f;
     int cur_lv = -1;
@@ -831,7 +899,7 @@ __device__ __forceinline__ bool path_bound_wide(const Walk<G> &w, const double t
 // The path sums of the wave's buffer for a job that starts with matches on its path (a queued subtree): the rows of match
 // after match, as path_bound() would have left them.
 template <int G>
-__device__ __forceinline__ void path_sums_of_root(const Walk<G> &w, float *pa, int nm0) {
+__device__ __forceinline__ void path_sums_of_root(const Walk<G> &w, PaElt *pa, int nm0) {
     constexpr int SLOTS = 64 / G;
     const int lane = lane_id();
     const int s = lane / G, c = lane % G;
@@ -840,14 +908,14 @@ __device__ __forceinline__ void path_sums_of_root(const Walk<G> &w, float *pa, i
         const uint32_t jq = ((uint32_t)rl(w.matKA, q) >> 16) & 255u;
         const uint32_t x0 = (uint32_t)rl(w.hks, (int)jq + 1);
         const float *Pq = reinterpret_cast<const float *>(w.Pb) + (long)rl(w.matB, q) * G;
-        const float *pin = pa + (size_t)q * ksumtot * G;
-        float *pout = pa + (size_t)(q + 1) * ksumtot * G;
+        const PaElt *pin = pa + (size_t)q * ksumtot * G;
+        PaElt *pout = pa + (size_t)(q + 1) * ksumtot * G;
         for (uint32_t x = x0; x < ksumtot; x += SLOTS) {
             const bool on = x + (uint32_t)s < ksumtot;
             const uint32_t xx = on ? x + (uint32_t)s : x0;
             const float pv = Pq[(size_t)xx * G + c];
-            const float have = q ? pin[(size_t)xx * G + c] : 0.f;
-            if (on) pout[(size_t)xx * G + c] = pv > 0.f ? have + pv : -__builtin_inff();
+            const float have = q ? pa_get(pin, (size_t)xx * G + c) : 0.f;
+            if (on) pa_put(pout, (size_t)xx * G + c, pv > 0.f ? have + pv : -__builtin_inff());
         }
         wave_sync(); // (the next match reads what this one wrote)
     }
@@ -855,7 +923,7 @@ __device__ __forceinline__ void path_sums_of_root(const Walk<G> &w, float *pa, i
 
 template <int G>
 __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *tot, unsigned long long *pool, uint16_t *pathbuf, double *tch, double *tc,
-                                    unsigned long long *cbl, float *pa, float *ub, uint32_t rec16 /* arena record of the job (exports refer to it) */, bool export_mode,
+                                    unsigned long long *cbl, PaElt *pa, float *ub, uint32_t rec16 /* arena record of the job (exports refer to it) */, bool export_mode,
                                     unsigned long long budget, uint32_t wave_id, WaveStats *stat) {
     constexpr int SLOTS = 64 / G;
     constexpr int PSH = G == 1 ? 2 : G == 2 ? 3 : G == 4 ? 4 : G == 8 ? 5 : G == 16 ? 6 : G == 32 ? 7 : 8; // log2 bytes of an entry
@@ -896,6 +964,8 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
     auto flush_dbg = [&]() {};
 #endif
     for (;;) {
+        inject_valu<PMX_INJECT_VALU_WALK>();
+        inject_salu<PMX_INJECT_SALU_WALK>();
         if (w.passes > budget32) { // over budget: the caller moves the job's tables to the arena and resumes in export mode
             w.f = f;
             flush_dbg();
@@ -988,7 +1058,10 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
             // the candidate's bound goes out with the table loads (one memory round trip per pass, not two)
             double rbound = 0.0;
             if (bounded || (ordered && cand_bounds<G>())) { // (the bound also orders the children of frames it cannot drop yet)
-                if constexpr (cand_bounds<G>()) rbound = *reinterpret_cast<const double *>(Wb + (((uint32_t)(ksf + (on ? bvec : b_first))) << (PSH + 1)) + 8u * (uint32_t)c);
+                if constexpr (cand_bounds<G>()) {
+                    if (kSlimBounds) rbound = (double)*reinterpret_cast<const float *>(Wb + (((uint32_t)(ksf + (on ? bvec : b_first))) << PSH) + 4u * (uint32_t)c);
+                    else rbound = *reinterpret_cast<const double *>(Wb + (((uint32_t)(ksf + (on ? bvec : b_first))) << (PSH + 1)) + 8u * (uint32_t)c);
+                }
                 else rbound = *reinterpret_cast<const double *>(w.Rb + (((uint32_t)(f + 1) << (PSH + 1)) + 8u * (uint32_t)c));
             }
             double t;
@@ -1385,6 +1458,22 @@ __device__ __forceinline__ int walk(Walk<G> &w, const ScreenParams &p, double *t
 
 
 // ------------------------------------------------------------------------------------------ table phase
+// Round 6: instruction injection (inject_valu / inject_salu above) showed that every instruction of a table item costs its full issue price -
+// 16 / 32 v_nops per batch of two items: tables alone 43.5 -> 45.3 / 47.7 ms - so the item is on a diet: the function index of a symmetric model
+// (every model the reference can make) without the general form and its 64-bit multiply-add, the cell number kept as the integer it is, 24-bit
+// multiplies where an entry is decoded. PMX_ITEM_DIET=0 builds the round-5 item for A/B runs.
+#ifndef PMX_ITEM_DIET
+#define PMX_ITEM_DIET 1
+#endif
+// TRI: the caller has established that the table is triangular (FnTable::tri, wave-uniform)
+template <bool TRI>
+__device__ __forceinline__ uint32_t fn_index_t(const FnTable &F, uint32_t sidu, uint32_t sidv) {
+    if (TRI) {
+        const uint32_t hi = max(sidu, sidv), lo = min(sidu, sidv);
+        return ((__umul24(hi, hi) + hi) >> 1) + lo; // (subset ids are 16 bits)
+    }
+    return __umul24(sidu, F.NS) + sidv;
+}
 __device__ __forceinline__ uint32_t fn_index(const FnTable &F, uint32_t sidu, uint32_t sidv) {
     // (both forms and a bit select on the wave-uniform `tri`: a branch here is a branch per table item)
     const uint32_t hi = max(sidu, sidv), lo = min(sidu, sidv);
@@ -1491,6 +1580,21 @@ struct ItemLoad {
 __device__ __forceinline__ float cell_of(const ScreenParams &p, float d) {
     return (float)min((int)(d * p.F.inv_h), (int)p.F.ncell - 1); // (d * inv_h is exact: inv_h is a power of two)
 }
+// (the diet's form: the function index by the caller's knowledge of the table's shape, the cell number computed once)
+template <bool TRI>
+__device__ __forceinline__ ItemLoad item_load_t(const ScreenParams &p, uint32_t sidu, uint32_t sidv, float d) {
+    ItemLoad L;
+    L.d = d;
+    const int ci = min((int)(d * p.F.inv_h), (int)p.F.ncell - 1);
+    L.cell = (float)ci;
+    L.sids = sidu | (sidv << 16);
+    const uint32_t off = (__umul24(fn_index_t<TRI>(p.F, sidu, sidv), p.F.ncell) + (uint32_t)ci) << 4;
+    const unsigned char *pa = reinterpret_cast<const unsigned char *>(p.F.cells);
+    const unsigned char *pb = pa + (size_t)p.F.plane16 * 16u;
+    L.a = *reinterpret_cast<const float4 *>(pa + off);
+    L.b = *reinterpret_cast<const float4 *>(pb + off);
+    return L;
+}
 __device__ __forceinline__ ItemLoad item_load(const ScreenParams &p, uint32_t sidu, uint32_t sidv, float d, float cell) {
     ItemLoad L;
     L.d = d;
@@ -1528,12 +1632,25 @@ __device__ __forceinline__ void item_finish(const ScreenParams &p, const ItemLoa
     v = __builtin_fmaf(t, v, L.a.y);
     v = __builtin_fmaf(t, v, L.a.x);
     acc = acc + v;
+#if PMX_ITEM_DIET
+    // lo <= d <= hi as "d is the median of (d, lo, hi)" (every window has lo <= hi; pmx_api.hip fn_windows): one compare, no mask arithmetic. A cell whose
+    // pass set is not one interval (lo = NaN; 0.8 items per ligand) is put right behind one wave-wide test instead of an exec-mask detour per item.
+    const bool fail = __builtin_amdgcn_fmed3f(L.d, L.b.z, L.b.w) != L.d;
+    fails += fail ? 1 : 0;
+    if (__builtin_expect(__ballot(L.b.z != L.b.z) != 0ull, 0)) {
+        if (L.b.z != L.b.z) { // count the terms
+            fails += (majority_fails(p, L.sids & 0xffffu, L.sids >> 16, L.d) ? 1 : 0) - (fail ? 1 : 0);
+            ++n_exact;
+        }
+    }
+#else
     if (__builtin_expect(L.b.z != L.b.z, 0)) { // the pass set is not one interval inside this cell: count the terms
         fails += majority_fails(p, L.sids & 0xffffu, L.sids >> 16, L.d) ? 1 : 0;
         ++n_exact;
     } else {
         fails += (L.d >= L.b.z && L.d <= L.b.w) ? 0 : 1;
     }
+#endif
 }
 
 #ifndef PMX_ITEM_BATCH
@@ -1888,10 +2005,11 @@ __device__ __forceinline__ void build_tables(const ScreenParams &p, unsigned cha
                 const int npass = (int)__popcll(pbal);
                 // what is written for a finished entry: match_utils.py:71-74 (-1 unless num_fails <= L1 * L2 / 2), the row and its V mask
                 auto finish_entry = [&](int e, bool on, float acc, int fails) {
-                    const int sa = (int)(((float)e + 0.5f) * inv_kj), sb = e - sa * kj;
+                    const int sa = (int)(((float)e + 0.5f) * inv_kj), sb = PMX_ITEM_DIET ? e - __mul24(sa, kj) : e - sa * kj;
                     const int L1 = lcnt[i * ws.kp + sa], L2 = lcnt[j * ws.kp + sb]; // graph_match.py:164-171
                     const float value = 2 * fails <= L1 * L2 ? acc : -1.f;
-                    const uint32_t pe = row_i + (uint32_t)sa * nd_i + off_j + (uint32_t)sb; // entry((i, sa) -> (j, sb))
+                    const uint32_t pe = PMX_ITEM_DIET ? row_i + __umul24((uint32_t)sa, nd_i) + off_j + (uint32_t)sb
+                                                      : row_i + (uint32_t)sa * nd_i + off_j + (uint32_t)sb; // entry((i, sa) -> (j, sb)); sa < 64, nd_i <= 20 x 64
                     if (on) Pt[(size_t)pe * G + c] = value;
                     const unsigned long long pos = __ballot(on && value > 0.f);
                     if (on && c == 0) {
@@ -2016,8 +2134,9 @@ __device__ __forceinline__ void build_tables(const ScreenParams &p, unsigned cha
                     const int total = nround * npair;
                     // (The loop is instantiated for staged / computed distances: what is fixed per level pair is decided once, not per
                     // item, and the list's end is tested per batch, not per item. [MI355X] tables alone 57.4 -> 56.7 ms per 1 M ligands.)
-                    auto run_items = [&](auto staged_tag) {
+                    auto run_items = [&](auto staged_tag, auto tri_tag) {
                         constexpr bool STG = decltype(staged_tag)::value;
+                        constexpr bool TRI = decltype(tri_tag)::value; // (false: nothing is known, the general index)
                         int lk = 0, lu = 0, lv = 0, lpos = 0; // next item to load: entry round, node pair, its number
                         int fk = 0, fr = 0;                   // next item to finish: entry round, pair number
                         int rowa = 0, rowb = 0;               // node-candidate rows of this slot's entry of round lk
@@ -2028,15 +2147,24 @@ __device__ __forceinline__ void build_tables(const ScreenParams &p, unsigned cha
                         auto decode = [&](int k) {
                             bool on;
                             const int e = slot_entry(k, on);
-                            const int sa = (int)(((float)e + 0.5f) * inv_kj), sb = e - sa * kj;
-                            rowa = nci + sa * ni, rowb = ncj + sb * nj;
+                            const int sa = (int)(((float)e + 0.5f) * inv_kj);
+                            if (PMX_ITEM_DIET) { // (entries, candidates and nodes are far below 2^23: 24-bit multiplies are full rate, 32-bit ones a quarter)
+                                const int sb = e - __mul24(sa, kj);
+                                rowa = nci + __mul24(sa, ni), rowb = ncj + __mul24(sb, nj);
+                            } else {
+                                const int sb = e - sa * kj;
+                                rowa = nci + sa * ni, rowb = ncj + sb * nj;
+                            }
                         };
                         decode(0);
                         float acc = 0.f;
                         int fails = 0;
+                        uint32_t sidu_cur = nc[rowa]; // (diet: the first node's subset is read when the node changes, not per item)
                         auto load_next = [&]() {
                             const float d = STG ? dl[lpos * G + c] : node_distance(si, lu, sj, lv);
-                            const ItemLoad L = item_load(p, (uint32_t)nc[rowa + lu], (uint32_t)nc[rowb + lv], d, cell_of(p, d));
+                            const uint32_t sidu = PMX_ITEM_DIET ? sidu_cur : (uint32_t)nc[rowa + lu];
+                            const ItemLoad L = (PMX_ITEM_DIET && TRI) ? item_load_t<true>(p, sidu, (uint32_t)nc[rowb + lv], d)
+                                                                      : item_load(p, sidu, (uint32_t)nc[rowb + lv], d, cell_of(p, d));
                             ++lpos;
                             if (++lv == nj) {
                                 lv = 0;
@@ -2044,6 +2172,7 @@ __device__ __forceinline__ void build_tables(const ScreenParams &p, unsigned cha
                                     lu = 0, lpos = 0;
                                     if (++lk < nround) decode(lk);
                                 }
+                                if (PMX_ITEM_DIET) sidu_cur = nc[rowa + lu];
                             }
                             return L;
                         };
@@ -2059,6 +2188,7 @@ __device__ __forceinline__ void build_tables(const ScreenParams &p, unsigned cha
                         };
                         int t0 = 0;
                         for (; t0 + IB <= total; t0 += IB) { // whole batches: no test of the list's end inside
+                            inject_valu<PMX_INJECT_VALU_ITEM>();
                             ItemLoad L[IB];
 #pragma unroll
                             for (int q = 0; q < IB; ++q) L[q] = load_next();
@@ -2067,8 +2197,10 @@ __device__ __forceinline__ void build_tables(const ScreenParams &p, unsigned cha
                         }
                         for (; t0 < total; ++t0) finish_next(load_next()); // what is left of the list, one at a time
                     };
-                    if (staged) run_items(std::true_type{});
-                    else run_items(std::false_type{});
+                    // (the triangular index where the distances are staged - nearly every item of nearly every model; one more copy of the loop)
+                    if (staged && PMX_ITEM_DIET && p.F.tri) run_items(std::true_type{}, std::true_type{});
+                    else if (staged) run_items(std::true_type{}, std::false_type{});
+                    else run_items(std::false_type{}, std::false_type{});
                     n_items += (uint32_t)total;
 #ifdef PMX_TABLE_FILL // instrumented builds: [1] wave-iterations of the pair items, [5] slot-items of them that belong to an entry
                     if (lane == 0) {
@@ -2157,8 +2289,18 @@ __device__ __forceinline__ void build_bounds(const ScreenParams &p, unsigned cha
     const float *St = reinterpret_cast<const float *>(rec + rec_s_off<G>());
     const float *Pt = reinterpret_cast<const float *>(rec + rec_p_off<G>(L.ksumtot));
     double *Rt = reinterpret_cast<double *>(rec + rec_r_off<G>(L.ksumtot, L.T));
-    double *Wt = reinterpret_cast<double *>(rec + rec_w_off<G>(L.ksumtot, L.T, (uint32_t)L.nl));
-    float *OBt = reinterpret_cast<float *>(rec + rec_ob_off<G>(L.ksumtot, L.T, (uint32_t)L.nl));
+    unsigned char *Wraw = rec + rec_w_off<G>(L.ksumtot, L.T, (uint32_t)L.nl);
+    unsigned char *OBraw = rec + rec_ob_off<G>(L.ksumtot, L.T, (uint32_t)L.nl);
+    // W[i] (a bound: rounded up when it is kept as a float32) and OB[i] (bfloat16 rounded up where per-candidate bounds exist)
+    auto w_put = [&](size_t i, double v) {
+        if (kSlimBounds) reinterpret_cast<float *>(Wraw)[i] = float_up(v);
+        else reinterpret_cast<double *>(Wraw)[i] = v;
+    };
+    auto w_get = [&](size_t i) -> double { return kSlimBounds ? (double)reinterpret_cast<const float *>(Wraw)[i] : reinterpret_cast<const double *>(Wraw)[i]; };
+    auto ob_put = [&](size_t i, double v) {
+        if (ob_elt_bytes<G>() == 2) reinterpret_cast<uint16_t *>(OBraw)[i] = bf16_up(float_up(v));
+        else reinterpret_cast<float *>(OBraw)[i] = float_up(v);
+    };
     unsigned char *LVt = rec + rec_ci_off<G>(L.ksumtot, L.T, (uint32_t)L.nl);
     const int nl = L.nl;
 #ifdef PMX_TABLE_TICKS
@@ -2169,7 +2311,7 @@ __device__ __forceinline__ void build_bounds(const ScreenParams &p, unsigned cha
     if (PMX_WFLAGS(p) & 4) { // debug: nothing is ever dropped
         for (int l = s; l <= nl; l += SLOTS) Rt[(size_t)l * G + c] = __builtin_inf();
         if (cand_bounds<G>())
-            for (uint32_t e = s; e < L.ksumtot; e += SLOTS) Wt[(size_t)e * G + c] = __builtin_inf();
+            for (uint32_t e = s; e < L.ksumtot; e += SLOTS) w_put((size_t)e * G + c, __builtin_inf());
         return;
     }
     double suffix = 0.0;
@@ -2203,15 +2345,15 @@ __device__ __forceinline__ void build_bounds(const ScreenParams &p, unsigned cha
                         m2 = pw[u] > m2 ? pw[u] : m2;
                     }
                 }
-                if (cand_bounds<G>()) OBt[((size_t)j * L.ksumtot + (size_t)(ksl + b)) * G + c] = float_up(v);
+                if (cand_bounds<G>()) ob_put(((size_t)j * L.ksumtot + (size_t)(ksl + b)) * G + c, v);
                 v += (double)m;
                 if (j2 >= 0) {
-                    if (cand_bounds<G>()) OBt[((size_t)j2 * L.ksumtot + (size_t)(ksl + b)) * G + c] = float_up(v);
+                    if (cand_bounds<G>()) ob_put(((size_t)j2 * L.ksumtot + (size_t)(ksl + b)) * G + c, v);
                     v += (double)m2;
                 }
             }
-            if (cand_bounds<G>()) Wt[(size_t)(ksl + b) * G + c] = v; // base(l, b), replaced by the candidate's own bound below
-            else OBt[(size_t)(ksl + b) * G + c] = float_up(v);          // BF: base(l, b) for path_bound_wide()
+            if (cand_bounds<G>()) w_put((size_t)(ksl + b) * G + c, v); // base(l, b), replaced by the candidate's own bound below
+            else ob_put((size_t)(ksl + b) * G + c, v);                 // BF: base(l, b) for path_bound_wide()
             if (c == 0) LVt[ksl + b] = (unsigned char)l;
             u = v > u ? v : u;
         }
@@ -2240,7 +2382,7 @@ __device__ __forceinline__ void build_bounds(const ScreenParams &p, unsigned cha
             const int kf = uni(lk[f]), ksf = uni(ksum[f]);
             const double r = Rt[(size_t)(f + 1) * G + c];
             wave_sync();
-            for (int b = s; b < kf; b += SLOTS) Wt[(size_t)(ksf + b) * G + c] = r;
+            for (int b = s; b < kf; b += SLOTS) w_put((size_t)(ksf + b) * G + c, r);
         }
         return;
     }
@@ -2265,7 +2407,7 @@ __device__ __forceinline__ void build_bounds(const ScreenParams &p, unsigned cha
                     float mf[B1], pA[B1], pB[B1];
 #pragma unroll
                     for (int u = 0; u < B1; ++u) {
-                        base[u] = Wt[(size_t)(ksl + min(b10 + u, kl - 1)) * G + c];
+                        base[u] = w_get((size_t)(ksl + min(b10 + u, kl - 1)) * G + c);
                         mf[u] = 0.f, pA[u] = 0.f, pB[u] = 0.f;
                     }
                     // level f's entries against (l, b1): every slot reads its own candidates', the largest of all is what
@@ -2294,8 +2436,8 @@ __device__ __forceinline__ void build_bounds(const ScreenParams &p, unsigned cha
                 accA += uA;
                 accB += uB;
             }
-            if (bA < kf) Wt[(size_t)(ksf + bA) * G + c] = accA * (1.0 + 1e-12);
-            if (bB < kf) Wt[(size_t)(ksf + bB) * G + c] = accB * (1.0 + 1e-12);
+            if (bA < kf) w_put((size_t)(ksf + bA) * G + c, accA * (1.0 + 1e-12));
+            if (bB < kf) w_put((size_t)(ksf + bB) * G + c, accB * (1.0 + 1e-12));
         }
         wave_sync();
     }
@@ -2497,7 +2639,7 @@ __device__ __forceinline__ bool prepare_walk(const ScreenParams &p, unsigned cha
         if (__ballot(((mask0 >> c) & 1ull) && (t + r) * kBoundSlack > __longlong_as_double((long long)pool[c])) == 0) return false;
     }
     if (cand_bounds<G>() && w.path_on && nm0 > 0) // a queued subtree: the pair sums of the matches it starts with
-        path_sums_of_root<G>(w, reinterpret_cast<float *>(p.pabuf + (size_t)blockIdx.x * p.pa_bytes), nm0);
+        path_sums_of_root<G>(w, reinterpret_cast<PaElt *>(p.pabuf + (size_t)blockIdx.x * p.pa_bytes), nm0);
     return true;
 }
 
@@ -2516,7 +2658,7 @@ __device__ __forceinline__ void run_job(const ScreenParams &p, unsigned char *ld
     double *tch = reinterpret_cast<double *>(lds + ws.off_tch);
     double *tc = reinterpret_cast<double *>(lds + ws.off_tc);
     unsigned long long *cbl = reinterpret_cast<unsigned long long *>(lds + ws.off_cb);
-    float *pa = reinterpret_cast<float *>(p.pabuf + (size_t)blockIdx.x * p.pa_bytes);
+    PaElt *pa = reinterpret_cast<PaElt *>(p.pabuf + (size_t)blockIdx.x * p.pa_bytes);
     float *ub = reinterpret_cast<float *>(lds + ws.off_ub);
     const unsigned long long t_d = __builtin_amdgcn_s_memtime();
     unsigned long long budget = ((PMX_WFLAGS(p) & 2) || p.last_round) ? ~0ull : (unsigned long long)p.budget;

@@ -18,7 +18,13 @@ nconf = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 model = PharmacophoreModel.load(GOLDEN / name)
 st = (PharmacophoreModel.load(GOLDEN / "model_6oim_like.pm") if nconf == 8 else model).__getstate__()
 centers = np.array([x["center"] for x in st["nodes"]], dtype=np.float64); types = np.array([TYPE_ID[x["type"]] for x in st["nodes"]])
-if nconf == 8:
+survey = len(sys.argv) > 4 and sys.argv[4] == "survey"  # run_study.py model n 8 survey: SURVEY 8d-2's library (tools/survey_library.py)
+if survey:
+    from pharmaconet_amd import PackedLibrary
+    from tools.survey_library import survey_library
+    o_, d_, _ = survey_library(centers, types, n, nconf, "cpu")
+    lib = PackedLibrary(o_.numpy().astype(np.uint64), d_.numpy())
+elif nconf == 8:
     lib = synthetic_library(n, first=0, num_conformers=8, model_nodes=(centers, types), active_fraction=0.1, seed=BASE_SEED, max_nodes=32)
 else:
     lib = synthetic_library(n, num_conformers=nconf, model_nodes=(centers, types), active_fraction=0.2, seed=6464, max_nodes=32, conformer_noise=0.0)

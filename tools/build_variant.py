@@ -26,7 +26,9 @@ def main():
         # with the variant's flags: a debug kernel built with the base macros under a host side built with the variant's would have
         # another LDS layout and other launch bounds)
         screening = src in ("pmx_api.hip", "pmx_screen_debug.hip")
-        if src.endswith(".hip") and not screening and (out / f"base_{src.rsplit('.', 1)[0]}.o").exists():
+        base_obj = out / f"base_{src.rsplit('.', 1)[0]}.o"
+        fresh = base_obj.exists() and base_obj.stat().st_mtime > max((CSRC / src).stat().st_mtime, (REPO / "include" / "pmx.h").stat().st_mtime)
+        if src.endswith(".hip") and not screening and fresh and name != "base":
             obj = out / f"base_{src.rsplit('.', 1)[0]}.o"
         else:  # (the compiles run side by side: the two screening units take a minute each)
             procs.append(subprocess.Popen([hipcc(), *FLAGS, *extra, f"-I{REPO / 'include'}", f"-I{CSRC}", "-c", str(CSRC / src), "-o", str(obj)]))
