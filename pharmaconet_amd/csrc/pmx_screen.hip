@@ -2303,6 +2303,14 @@ __device__ __forceinline__ void build_bounds(const ScreenParams &p, unsigned cha
     };
     unsigned char *LVt = rec + rec_ci_off<G>(L.ksumtot, L.T, (uint32_t)L.nl);
     const int nl = L.nl;
+    // Round 6: the level maxima the base pass works out - MP[j][x] = max(0, max_a P[(j, a), x]) for a candidate x of a deeper level - are kept (in the
+    // wave's path-sum buffer, idle until the walk) for the W pass below, which used to work every one of them out again per window of level j's
+    // candidates: a loop over the level's candidates and a cross-slot maximum per deeper candidate ([MI355X] 5.4 of the table phase's 41.4 ms).
+#ifndef PMX_W_FROM_MAXIMA
+#define PMX_W_FROM_MAXIMA 1
+#endif
+    float *MP = reinterpret_cast<float *>(p.pabuf + (size_t)blockIdx.x * p.pa_bytes);
+    const bool mp_ok = PMX_W_FROM_MAXIMA && cand_bounds<G>() && p.pabuf != nullptr && (uint64_t)nl * L.ksumtot * G * 4u <= (uint64_t)p.pa_bytes;
 #ifdef PMX_TABLE_TICKS
     unsigned long long tick_ = __builtin_amdgcn_s_memtime();
 #endif
@@ -2346,9 +2354,11 @@ __device__ __forceinline__ void build_bounds(const ScreenParams &p, unsigned cha
                     }
                 }
                 if (cand_bounds<G>()) ob_put(((size_t)j * L.ksumtot + (size_t)(ksl + b)) * G + c, v);
+                if (mp_ok) MP[((size_t)j * L.ksumtot + (size_t)(ksl + b)) * G + c] = m;
                 v += (double)m;
                 if (j2 >= 0) {
                     if (cand_bounds<G>()) ob_put(((size_t)j2 * L.ksumtot + (size_t)(ksl + b)) * G + c, v);
+                    if (mp_ok) MP[((size_t)j2 * L.ksumtot + (size_t)(ksl + b)) * G + c] = m2;
                     v += (double)m2;
                 }
             }
@@ -2386,60 +2396,52 @@ __device__ __forceinline__ void build_bounds(const ScreenParams &p, unsigned cha
         }
         return;
     }
-    // Two windows of level f's candidates at a time (slot s <-> candidates b0 + s and b0 + SLOTS + s): what a deeper candidate's base
-    // counted for level f - the maximum over ALL of f's candidates, a load per window and a cross-slot maximum - is the same for
-    // every window, and was worked out again for each (levels of 9-16 candidates, the fixture pockets': half of this loop).
-    for (int f = 0; f < nl; ++f) {
-        const int kf = uni(lk[f]), ksf = uni(ksum[f]);
-        for (int b0 = 0; b0 < kf; b0 += 2 * SLOTS) {
-            const int bA = b0 + s, bB = b0 + SLOTS + s;
-            double accA = 0.0, accB = 0.0;
-            for (int l = f + 1; l < nl; ++l) {
-                const int kl = uni(lk[l]), ksl = uni(ksum[l]);
-                const uint32_t nd_f = L.ksumtot - (uint32_t)uni((int)ksum[f + 1]);
-                const uint32_t e_fl = (uint32_t)uni((int)rowbase[f]) + (uint32_t)(ksl - uni((int)ksum[f + 1])); // entry((f, 0) -> (l, 0))
-                double uA = 0.0, uB = 0.0;
-                // (four candidates b1 of level l per trip, their loads in flight together - a maximum does not mind the last one being
-                // taken again where fewer are left; one at a time this loop was a memory round trip per deeper candidate and window)
-                constexpr int B1 = 4;
-                for (int b10 = 0; b10 < kl; b10 += B1) {
-                    double base[B1];
-                    float mf[B1], pA[B1], pB[B1];
+    if (mp_ok) {
+        // Slot s <-> candidate b = b0 + s of level f, alone with its own entries: for every deeper candidate x = (l, b1) its base with level f's
+        // maximum taken out and (f, b)'s own entry put in - three loads and two additions - the largest per level, the levels added up. The same
+        // numbers in the same order as the loop this replaces: the same W to the last bit.
+        for (int f = 0; f < nl; ++f) {
+            const int kf = uni(lk[f]), ksf = uni(ksum[f]);
+            const uint32_t x0 = (uint32_t)uni((int)ksum[f + 1]), nd_f = L.ksumtot - x0;
+            const float *MPf = MP + (size_t)f * L.ksumtot * G;
+            for (int b0 = 0; b0 < kf; b0 += SLOTS) {
+                const int b = b0 + s;
+                const float *Pb_ = Pt + ((size_t)(uint32_t)uni((int)rowbase[f]) + (size_t)(uint32_t)min(b, kf - 1) * nd_f) * G; // entry((f, b) -> x) = rowbase[f] + b nd_f + (x - x0)
+                double acc = 0.0;
+                for (int l = f + 1; l < nl; ++l) {
+                    const int kl = uni(lk[l]), ksl = uni(ksum[l]);
+                    double u = 0.0;
+                    constexpr int B1 = 4; // (deeper candidates per trip, their loads in flight together; a maximum does not mind the last one being taken again)
+                    for (int b10 = 0; b10 < kl; b10 += B1) {
+                        double base[B1];
+                        float mp[B1], pv[B1];
 #pragma unroll
-                    for (int u = 0; u < B1; ++u) {
-                        base[u] = w_get((size_t)(ksl + min(b10 + u, kl - 1)) * G + c);
-                        mf[u] = 0.f, pA[u] = 0.f, pB[u] = 0.f;
-                    }
-                    // level f's entries against (l, b1): every slot reads its own candidates', the largest of all is what
-                    // base(l, b1) counted for level f
-                    for (int a0 = 0; a0 < kf; a0 += SLOTS) {
-                        const int a = a0 + s;
-                        float pv[B1];
+                        for (int q = 0; q < B1; ++q) {
+                            const uint32_t x = (uint32_t)(ksl + min(b10 + q, kl - 1));
+                            base[q] = w_get((size_t)x * G + c);
+                            mp[q] = MPf[(size_t)x * G + c];
+                            pv[q] = Pb_[(size_t)(x - x0) * G + c];
+                        }
 #pragma unroll
-                        for (int u = 0; u < B1; ++u) pv[u] = a < kf ? Pt[(size_t)(e_fl + (uint32_t)a * nd_f + (uint32_t)min(b10 + u, kl - 1)) * G + c] : 0.f;
-#pragma unroll
-                        for (int u = 0; u < B1; ++u) {
-                            mf[u] = pv[u] > mf[u] ? pv[u] : mf[u];
-                            pA[u] = a0 == b0 ? pv[u] : pA[u];
-                            pB[u] = a0 == b0 + SLOTS ? pv[u] : pB[u];
+                        for (int q = 0; q < B1; ++q) {
+                            const double val = (base[q] - (double)mp[q]) + (double)pv[q];
+                            u = (pv[q] > 0.f && val > u) ? val : u;
                         }
                     }
-#pragma unroll
-                    for (int u = 0; u < B1; ++u) {
-                        const float mfu = slot_max_f32<G>(mf[u]); // (a NaN entry is passed over here as by the comparisons above)
-                        const double rest = base[u] - (double)mfu;
-                        const double valA = rest + (double)pA[u], valB = rest + (double)pB[u];
-                        uA = (pA[u] > 0.f && valA > uA) ? valA : uA;
-                        uB = (pB[u] > 0.f && valB > uB) ? valB : uB;
-                    }
+                    acc += u;
                 }
-                accA += uA;
-                accB += uB;
+                if (b < kf) w_put((size_t)(ksf + b) * G + c, acc * (1.0 + 1e-12));
             }
-            if (bA < kf) w_put((size_t)(ksf + bA) * G + c, accA * (1.0 + 1e-12));
-            if (bB < kf) w_put((size_t)(ksf + bB) * G + c, accB * (1.0 + 1e-12));
         }
         wave_sync();
+        return;
+    }
+    // (no room for the maxima: every candidate gets its level's bound)
+    for (int f = 0; f < nl; ++f) {
+        const int kf = uni(lk[f]), ksf = uni(ksum[f]);
+        const double r = Rt[(size_t)(f + 1) * G + c];
+        wave_sync();
+        for (int b = s; b < kf; b += SLOTS) w_put((size_t)(ksf + b) * G + c, r);
     }
 }
 
