@@ -1870,7 +1870,10 @@ __device__ __forceinline__ void build_tables(const ScreenParams &p, unsigned cha
         const int si = uni(lstart[i]), ni = uni(lend[i]) - si, ki = uni(lk[i]), nci = uni(ncoff[i]), ksi = uni(ksum[i]);
         const uint32_t row_i = (uint32_t)uni((int)rowbase_l[i]), nd_i = L.ksumtot - (uint32_t)uni(ksum[i + 1]);
         // ---- self table S[i][a] (match_utils.py:77-122): node pairs u < v of the cluster
-        const bool self_staged = ni > 1 && ni * ni <= dcap;
+#ifndef PMX_SELF_STAGE_MIN
+#define PMX_SELF_STAGE_MIN 4 // (a cluster of two or three nodes has one or three self items: a staging trip - 16 node pairs wide, a round trip through LDS - costs more instructions than computing them in place)
+#endif
+        const bool self_staged = ni >= PMX_SELF_STAGE_MIN && ni * ni <= dcap;
         if (self_staged) stage_distances(si, ni, si, ni);
         for (int q0 = 0; q0 < ki; q0 += SLOTS) {
             const int q = q0 + s;
@@ -1939,7 +1942,13 @@ __device__ __forceinline__ void build_tables(const ScreenParams &p, unsigned cha
                     const int sa = (int)(((float)ee + 0.5f) * inv_kj), sb = ee - sa * kj;
                     const float2 mp = p.M.cpair[cand[i * ws.kp + sa] * K + cand[j * ws.kp + sb]];
                     bool pass = false;
-                    for (int k = 0; k < C; ++k) pass = pass || !((fabsf(pf[k] - mp.x) - pf[G + k]) > mp.y);
+                    {   // (eight conformers per trip - lanes past C hold copies of conformer C - 1, which an OR does not mind: the reads of a trip are two wide LDS loads)
+                        constexpr int KP = G < 8 ? G : 8;
+                        for (int k0 = 0; k0 < C; k0 += KP) {
+#pragma unroll
+                            for (int kk = 0; kk < KP; ++kk) pass = pass || !((fabsf(pf[k0 + kk] - mp.x) - pf[G + k0 + kk]) > mp.y);
+                        }
+                    }
                     pass = pass && in;
                     // Dead entries. An entry that passes the prefilter is still -1 for every conformer when more than half of
                     // its counted node pairs fail the 2-sigma majority test (match_utils.py:55-61, :71-74) - for a pocket of 20-40
@@ -2198,9 +2207,15 @@ __device__ __forceinline__ void build_tables(const ScreenParams &p, unsigned cha
                         for (; t0 < total; ++t0) finish_next(load_next()); // what is left of the list, one at a time
                     };
                     // (the triangular index where the distances are staged - nearly every item of nearly every model; one more copy of the loop)
-                    if (staged && PMX_ITEM_DIET && p.F.tri) run_items(std::true_type{}, std::true_type{});
-                    else if (staged) run_items(std::true_type{}, std::false_type{});
+#if PMX_ITEM_DIET
+                    // (two copies of the loop, not three: a table that is not triangular - a model whose edge matrix is not symmetric, which the
+                    // reference cannot make - takes the general loop, which computes its distances; the kernel is 63 KB beside a 64 KB instruction cache)
+                    if (staged && p.F.tri) run_items(std::true_type{}, std::true_type{});
                     else run_items(std::false_type{}, std::false_type{});
+#else
+                    if (staged) run_items(std::true_type{}, std::false_type{});
+                    else run_items(std::false_type{}, std::false_type{});
+#endif
                     n_items += (uint32_t)total;
 #ifdef PMX_TABLE_FILL // instrumented builds: [1] wave-iterations of the pair items, [5] slot-items of them that belong to an entry
                     if (lane == 0) {
