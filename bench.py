@@ -39,7 +39,7 @@ REPO = Path(__file__).resolve().parent
 sys.path.insert(0, str(REPO))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s HBM3E spec
-PROFILE_TAG = "r5"  # the committed rocprofv3 --pmc summaries (profiles/<tag>_*.json) the static blocks of the line are read from
+PROFILE_TAG = "r6"  # the committed rocprofv3 --pmc summaries (profiles/<tag>_*.json) the static blocks of the line are read from
 
 # name -> (model file under tests/golden, conformers, ligands on one GPU, topologies, fraction of ligands drawn on the model's nodes,
 #          (seed of the topologies | None = tools.synthetic.BASE_SEED, offset of the perturbation stream's seed))

@@ -18,7 +18,7 @@ import os
 
 REPO = Path(__file__).resolve().parents[1]
 PROF = REPO / "profiles"
-TAG = os.environ.get("PMX_PROFILE_TAG", "r5")  # file name prefix: the round the profiles belong to
+TAG = os.environ.get("PMX_PROFILE_TAG", "r6")  # file name prefix: the round the profiles belong to
 
 
 def short(name):
