@@ -1873,7 +1873,10 @@ __device__ __forceinline__ void build_tables(const ScreenParams &p, unsigned cha
 #ifndef PMX_SELF_STAGE_MIN
 #define PMX_SELF_STAGE_MIN 4 // (a cluster of two or three nodes has one or three self items: a staging trip - 16 node pairs wide, a round trip through LDS - costs more instructions than computing them in place)
 #endif
-        const bool self_staged = ni >= PMX_SELF_STAGE_MIN && ni * ni <= dcap;
+#ifndef PMX_CUT
+#define PMX_CUT 0 // analysis builds (tools/build_variant.py + PMX_TREE_FLAGS=16384): 1 no self items, 2 no bounds pass, 4 no pair items - the instruction budget of a section is what its absence takes out of SQ_INSTS_*; scores are meaningless
+#endif
+        const bool self_staged = !(PMX_CUT & 1) && ni >= PMX_SELF_STAGE_MIN && ni * ni <= dcap;
         if (self_staged) stage_distances(si, ni, si, ni);
         for (int q0 = 0; q0 < ki; q0 += SLOTS) {
             const int q = q0 + s;
@@ -1881,7 +1884,7 @@ __device__ __forceinline__ void build_tables(const ScreenParams &p, unsigned cha
             const int row = nci + (on ? q : 0) * ni;
             float acc = 0.f;
             int fails = 0;
-            for (int u = 0; u + 1 < ni; ++u) {
+            for (int u = 0; u + 1 < ((PMX_CUT & 1) ? 0 : ni); ++u) {
                 const uint32_t sidu = nc[row + u];
                 for (int v = u + 1; v < ni; ++v) {
                     const float d = self_staged ? dl[(u * ni + v) * G + c] : node_distance(si, u, si, v);
@@ -2210,7 +2213,8 @@ __device__ __forceinline__ void build_tables(const ScreenParams &p, unsigned cha
 #if PMX_ITEM_DIET
                     // (two copies of the loop, not three: a table that is not triangular - a model whose edge matrix is not symmetric, which the
                     // reference cannot make - takes the general loop, which computes its distances; the kernel is 63 KB beside a 64 KB instruction cache)
-                    if (staged && p.F.tri) run_items(std::true_type{}, std::true_type{});
+                    if (PMX_CUT & 4) {
+                    } else if (staged && p.F.tri) run_items(std::true_type{}, std::true_type{});
                     else run_items(std::false_type{}, std::false_type{});
 #else
                     if (staged) run_items(std::true_type{}, std::false_type{});
@@ -2329,6 +2333,7 @@ __device__ __forceinline__ void build_bounds(const ScreenParams &p, unsigned cha
 #ifdef PMX_TABLE_TICKS
     unsigned long long tick_ = __builtin_amdgcn_s_memtime();
 #endif
+    if (PMX_CUT & 2) return;
     chain_lengths<G>(p, lds, ws, L, rec);
     PMX_TICK(5);
     if (PMX_WFLAGS(p) & 4) { // debug: nothing is ever dropped
