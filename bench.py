@@ -509,6 +509,7 @@ def main():
     ap.add_argument("--pockets", type=int, default=1, help="score this many distinct pockets (1..16) against the shared library (BASELINE configs[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-serial-leg", action="store_true", help="skip the end-to-end (pack + copy) side measurement")
+    ap.add_argument("--no-survey-leg", action="store_true", help="skip the side measurement on SURVEY 8d-2's own library (the default line carries it as `survey_library`)")
     ap.add_argument("--no-parity-sample", action="store_true")
     ap.add_argument("--dump-dir", default=None, help="every rank writes its shard's scores and rank 0 the merged top-k here (tests)")
     args = ap.parse_args()
@@ -735,6 +736,29 @@ def main():
                     out["end_to_end"].update(end_to_end_overlapped(molecules, pockets[0], n_lig, args.topk, device))
             except Exception as e:  # never lose the bench line over the side measurement
                 out["end_to_end"] = {**(out.get("end_to_end") or {}), "error": repr(e)}
+        # The same pass on SURVEY.md 8d-2's OWN generator (`--library survey` makes it the line's workload): a side block of the default line, so that
+        # one driver run carries both libraries. Untimed for `value`; its own warm-up, two timed passes, its own parity sample.
+        if world == 1 and bench_shape and not args.no_survey_leg and args.ligands >= 1_000_000:
+            try:
+                slib, soff, sdata, sstats = build_survey_library(model, 1_000_000, args.conformers, 0, device, wl_active)
+                engine.screen(model, slib, topk=args.topk)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(2):
+                    sres = engine.screen(model, slib, topk=args.topk)
+                torch.cuda.synchronize()
+                sdt = (time.perf_counter() - t0) / 2
+                out["survey_library"] = {
+                    "value": slib.total_conformers / sdt, "unit": "ligand-conformers/s", "ms_per_step": sdt * 1e3, "ligands": len(slib),
+                    "library_stats": sstats, "command": "python bench.py --library survey",
+                    "parity_sample": None if args.no_parity_sample else parity_sample(model, sres.scores, soff, sdata),
+                    "note": "tools/survey_library.py: every ligand an independent draw (n ~ clip(N(20, 6), 4, 32), conformer sigma 0.5 A, 10 % on the model's nodes at 0.7 A); "
+                            "5.5 x the tree search per ligand of the default library",
+                }
+                slib.close()
+                del soff, sdata
+            except Exception as e:  # never lose the bench line over the side measurement
+                out["survey_library"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -11,7 +11,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python -c "import sys; sys.path.insert(0, '$ROOT'); import bench; print(bench.csrc_digest())" > $OUT/csrc_sha16.txt
 python $ROOT/bench.py --steps 5 --warmup 2 > $OUT/bench.json 2> $OUT/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-serial-leg --no-parity-sample > $OUT/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-serial-leg --no-survey-leg --no-parity-sample > $OUT/stats.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -o p -- python $ROOT/bench.py --ligands 200000 --steps 1 --warmup 0 --no-cpu-baseline --no-serial-leg --no-parity-sample > $OUT/pmc_$c.log 2>&1
 done
