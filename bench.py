@@ -710,6 +710,8 @@ def main():
                 "walks_over_budget_per_ligand": prof["n_heavy"] / max(n_lig, 1),
                 "ligands_with_tables_beyond_a_slice": prof["n_slice_overflow"],
                 "longest_walk_passes": prof["max_passes"],
+                # (above 1: split trees found the table arena full and were walked by one wavefront each - exact, slow: PMX_SUPER / PMX_ARENA_MB)
+                "arena_asked_over_capacity": prof["arena_bytes"] / max(prof.get("arena_capacity", 0), 1),
                 "wave_time_share": {k: prof["ticks_" + k] / max(prof["ticks_alive"], 1) for k in ("scan", "tables", "bounds", "walk")},
             },
             "csrc_sha16": csrc_digest(),
