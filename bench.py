@@ -222,7 +222,7 @@ def tile_features(flat, reps, rng, node_sigma=0.35, conf_sigma=0.30):
     return out
 
 
-def end_to_end_overlapped(molecules, pocket, n_lig_target, topk_k, device, n_chunks=4):
+def end_to_end_overlapped(molecules, pocket, n_lig_target, topk_k, device, shares=(1, 3, 4)):
     """The path of `screening.py:63-70` as ONE pipeline: host packer threads -> pinned double buffer -> H2D on a copy stream -> library
     upload + `pmx_score` + `pmx_topk` on the compute stream, chunk by chunk, the packer running ahead of the GPU. Timed from the first
     byte packed to the merged top-k on the host. (Perception is in front of this and needs the chemistry toolkit.)"""
@@ -236,15 +236,25 @@ def end_to_end_overlapped(molecules, pocket, n_lig_target, topk_k, device, n_chu
     from pharmaconet_amd.library import flatten_features
 
     cores, host = host_cores()
-    threads = max(1, min(cores * 2, 64))  # (the packer waits on memory: two threads per granted core)
-    chunk_mols = max(len(molecules), (n_lig_target // n_chunks) // len(molecules) * len(molecules))
-    reps = chunk_mols // len(molecules)
-    flat = tile_features(flatten_features(molecules), reps, np.random.default_rng(12345))
+    # (the box's quota - 16 cores' worth per 100 ms period - does not stop a burst of more threads from running side by side: [MI355X box] 262 144 molecules in 48 / 33 / 18.5 /
+    # 19.8 ms on 16 / 32 / 64 / 128 threads; the pipeline packs in bursts and idles in between)
+    threads = int(os.environ.get("PMX_BENCH_PACK_THREADS", max(1, min(host["hardware_threads"], 64))))
+    # Chunks of growing size - a small first one so that the GPU starts a few milliseconds after the packer, large later ones because every chunk of a scoring call
+    # ends in the same 6 ms of task-round tail - in the proportions `shares`. ONE tiled feature batch of the largest chunk's size is made;
+    # a chunk packs a prefix of it (the flat layout's offsets are prefix-compatible), so every chunk is real packer work and real, distinct-geometry ligands.
+    if os.environ.get("PMX_BENCH_E2E_SHARES"):
+        shares = tuple(int(x) for x in os.environ["PMX_BENCH_E2E_SHARES"].split(","))
+    total_reps = max(len(shares), n_lig_target // len(molecules))
+    chunk_reps = [max(1, total_reps * sh // sum(shares)) for sh in shares]
+    n_chunks = len(chunk_reps)
+    flat = tile_features(flatten_features(molecules), max(chunk_reps), np.random.default_rng(12345))
     lib = _ffi.load_packer()
-    n = chunk_mols
-    batch = _ffi.FeatureBatch(n, *(flat[k].ctypes.data for k in (
-        "atom_off", "atomic_num", "nbr_off", "nbr", "feat_off", "feat_type", "feat_flags", "feat_atom_off", "feat_atoms",
-        "feat_center_off", "feat_centers", "n_conf", "pos_off", "positions")))
+    n = max(chunk_reps) * len(molecules)
+    chunk_n = [r_ * len(molecules) for r_ in chunk_reps]
+    fields = ("atom_off", "atomic_num", "nbr_off", "nbr", "feat_off", "feat_type", "feat_flags", "feat_atom_off", "feat_atoms",
+              "feat_center_off", "feat_centers", "n_conf", "pos_off", "positions")
+    batch = _ffi.FeatureBatch(n, *(flat[k].ctypes.data for k in fields))
+    batches = [_ffi.FeatureBatch(cn, *(flat[k].ctypes.data for k in fields)) for cn in chunk_n]
     need = ctypes.c_uint64(0)
     off_probe = np.zeros(n + 1, dtype=np.uint64)
     assert lib.pmx_pack_features(ctypes.byref(batch), threads, off_probe.ctypes.data, None, 0, ctypes.byref(need), None) == 0
@@ -268,7 +278,7 @@ def end_to_end_overlapped(molecules, pocket, n_lig_target, topk_k, device, n_chu
                     if i >= 2:
                         free[i - 2].wait()
                     got = ctypes.c_uint64(0)
-                    rc = lib.pmx_pack_features(ctypes.byref(batch), threads, pinned_off[i % 2].data_ptr(), pinned[i % 2].data_ptr(), cap, ctypes.byref(got), None)
+                    rc = lib.pmx_pack_features(ctypes.byref(batches[i]), threads, pinned_off[i % 2].data_ptr(), pinned[i % 2].data_ptr(), cap, ctypes.byref(got), None)
                     if rc != 0:
                         raise RuntimeError(lib.pmx_last_error().decode())
                     nbytes[i] = int(got.value)
@@ -292,15 +302,15 @@ def end_to_end_overlapped(molecules, pocket, n_lig_target, topk_k, device, n_chu
                 if i >= 2:
                     copy_stream.wait_event(scored[i - 2])  # the device buffer's last reader
                 dev_data[b][: nbytes[i]].copy_(pinned[b][: nbytes[i]], non_blocking=True)
-                dev_off[b].copy_(pinned_off[b], non_blocking=True)
+                dev_off[b][: chunk_n[i] + 1].copy_(pinned_off[b][: chunk_n[i] + 1], non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(copy_stream)
             h2d_done.append(ev)
             compute.wait_event(ev)
             ev.synchronize()  # (the pinned buffer is free for the packer; pmx_library_upload reads the offsets on the host side of its checks)
             free[i].set()
-            dlib = DeviceLibrary.from_device_buffers(dev_off[b], dev_data[b][: nbytes[i]], device)
-            res = engine.screen(pocket, dlib, topk=topk_k, index_base=i * n)
+            dlib = DeviceLibrary.from_device_buffers(dev_off[b][: chunk_n[i] + 1], dev_data[b][: nbytes[i]], device)
+            res = engine.screen(pocket, dlib, topk=topk_k, index_base=sum(chunk_n[:i]))
             sev = torch.cuda.Event()
             sev.record(compute)
             scored.append(sev)
@@ -321,14 +331,14 @@ def end_to_end_overlapped(molecules, pocket, n_lig_target, topk_k, device, n_chu
     return {
         "overlapped_ligand_conformers_per_s": total_conf / dt,
         "overlapped_s": dt,
-        "ligands": n * n_chunks,
-        "chunks": n_chunks,
+        "ligands": sum(chunk_n),
+        "chunks": chunk_n,
         "pack_threads": threads,
         "host": host,
         "best_score_of_the_run": float(best[0]),
         "note": "packer threads -> pinned double buffer -> H2D on a copy stream -> pmx_library_upload + pmx_score + pmx_topk on the compute stream, per chunk, "
-                "the packer running ahead of the GPU; first byte packed to merged top-k on the host; best of three. Bound by the slower of the two "
-                "sides: the packer on the cores the box grants, or the GPU pass",
+                "the packer running ahead of the GPU, chunks of growing size; first byte packed to merged top-k on the host; best of three. The packer needs 2.7 CPU-seconds per "
+                "10^6 ligands (0.375 x 10^6 ligands/s per thread): on the 16 cores' worth of time the box grants that is 0.17 s sustained whatever the thread count - the floor of this leg",
     }
 
 
