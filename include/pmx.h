@@ -210,6 +210,21 @@ typedef struct {
 } pmx_feature_batch;
 int pmx_pack_features(const pmx_feature_batch *batch, int threads, uint64_t *offsets_out, uint8_t *data_out, uint64_t data_cap,
                       uint64_t *data_bytes, int32_t *status_out);
+/*
+ * The same packer on the device (pmx_pack_device.hip), for batches that are in device memory: every pointer of `batch`, offsets_out,
+ * data_out and status_out are DEVICE pointers; the struct itself and data_bytes are on the host. Records are byte-identical to
+ * pmx_pack_features'. The kernels run on `stream` (a hipStream_t; NULL = the default stream) and the call waits for the sizes (one
+ * 8-byte read) before it enqueues the record writer and returns: *data_bytes is the exact size, offsets_out and data_out are
+ * complete in stream order. A call with data_out = NULL only sizes (EXACTLY, unlike the host call's bound; the bound
+ * sum(((8 + 2 nf + 3 + 12 nf c + 15) & ~15) + 16) over the molecules' feature and conformer counts needs no call at all).
+ * status_out as above, plus 3: the molecule is outside the fixed scratch of the device builder (more than 256 atoms, 255 features,
+ * 1024 neighbour entries, 1024 feature-atom entries, or a feature of more than 16 atoms) and became a header-only record - pack
+ * such a batch with pmx_pack_features. Two differences in reporting, none in records: a molecule whose offsets run backwards is
+ * reported 2 (the host call fails as a whole), and a molecule of more than 64 nodes is reported 1 without looking further (the host
+ * packer reports 2 if the reference's builder would also raise on it).
+ */
+int pmx_pack_features_device(const pmx_feature_batch *batch, int device, void *stream, uint64_t *offsets_out, uint8_t *data_out,
+                             uint64_t data_cap, uint64_t *data_bytes, int32_t *status_out);
 
 /*
  * The rule half of ligand perception in native code (pmx_perceive.cpp): get_pharmacophore_nodes of

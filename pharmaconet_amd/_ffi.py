@@ -140,6 +140,11 @@ SIGNATURES = {
         ctypes.c_int,
         [ctypes.POINTER(FeatureBatch), ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64), ctypes.c_void_p],
     ),
+    "pmx_pack_features_device": (
+        ctypes.c_int,
+        [ctypes.POINTER(FeatureBatch), ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64),
+         ctypes.c_void_p],
+    ),
     "pmx_perceive_features": (
         ctypes.c_int,
         [ctypes.POINTER(AtomBatch), ctypes.c_int] + [ctypes.c_void_p] * 7 + [ctypes.c_uint64] * 3 + [ctypes.POINTER(ctypes.c_uint64)] * 3 + [ctypes.c_void_p],

@@ -16,7 +16,7 @@ REPO = PKG.parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libpmx.so"
 PACK_LIB = PKG / "libpmx_pack.so"  # the packer alone, host-only (no HIP / RCCL runtime)
-SOURCES = ("pmx_api.hip", "pmx_screen_debug.hip", "pmx_topk.hip", "pmx_density.hip", "pmx_pack.cpp", "pmx_sdf.cpp", "pmx_perceive.cpp")
+SOURCES = ("pmx_api.hip", "pmx_screen_debug.hip", "pmx_topk.hip", "pmx_density.hip", "pmx_pack_device.hip", "pmx_pack.cpp", "pmx_sdf.cpp", "pmx_perceive.cpp")
 DEPS = ("pmx_screen.hip", "pmx_device.h", "pmx_debug.h")
 FLAGS = (
     "--offload-arch=gfx950",

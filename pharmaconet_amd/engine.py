@@ -121,6 +121,18 @@ class DeviceLibrary:
         self.num_unsupported = int(info.n_unsupported)
         return self
 
+    @classmethod
+    def from_features(cls, flat, device=None, check: bool = True) -> "DeviceLibrary":
+        """Typed features -> resident library without the host packer: `pack_features_device` + adoption of its buffers.
+        `flat`: `library.flatten_features(...)` arrays (NumPy: uploaded; or torch tensors already on the device). With `check`
+        a molecule outside the device builder's fixed scratch (status 3) raises - pack such a batch with `pack_features_native`."""
+        offsets, data, status = pack_features_device(flat, device)
+        if check and bool((status == 3).any()):
+            raise _ffi.PmxError("a molecule exceeds the device packer's fixed scratch (include/pmx.h): use library.pack_features_native for this batch")
+        self = cls.from_device_buffers(offsets, data, device if device is not None else offsets.device)
+        self.pack_status = status
+        return self
+
     def __len__(self) -> int:
         return self.num_ligands
 
@@ -134,6 +146,62 @@ class DeviceLibrary:
             self.close()
         except Exception:
             pass
+
+
+FEATURE_FIELDS = ("atom_off", "atomic_num", "nbr_off", "nbr", "feat_off", "feat_type", "feat_flags", "feat_atom_off", "feat_atoms",
+                  "feat_center_off", "feat_centers", "n_conf", "pos_off", "positions")
+
+
+def features_to_device(flat, device=None, non_blocking: bool = False) -> dict:
+    """The arrays of `library.flatten_features` as device tensors (uint64 offsets travel as int64 bits)."""
+    torch = _torch()
+    dev = torch.device("cuda", _device_index(device))
+    out = {}
+    for k in FEATURE_FIELDS:
+        a = flat[k]
+        if not isinstance(a, torch.Tensor):
+            a = np.ascontiguousarray(a)
+            a = torch.from_numpy(a.view(np.int64) if a.dtype == np.uint64 else a)
+        out[k] = a.to(dev, non_blocking=non_blocking)
+    return out
+
+
+def pack_bound(flat) -> int:
+    """Upper bound of the packed size of a feature batch (every feature a node), as `pmx_pack_features`' sizing call computes it."""
+    torch = _torch()
+    feat_off, n_conf = flat["feat_off"], flat["n_conf"]
+    if isinstance(feat_off, torch.Tensor):
+        nf = (feat_off[1:] - feat_off[:-1]).to(torch.int64)
+        c = n_conf.to(torch.int64).clamp(min=1)
+        return int(((((8 + 2 * nf + 3 + 12 * nf * c + 15) // 16) * 16) + 16).sum().item())
+    nf = np.diff(np.asarray(feat_off).astype(np.int64))
+    c = np.maximum(np.asarray(n_conf).astype(np.int64), 1)
+    return int((((8 + 2 * nf + 3 + 12 * nf * c + 15) & ~15) + 16).sum())
+
+
+def pack_features_device(flat, device=None, out=None, bound: int | None = None):
+    """`pmx_pack_features_device` (csrc/pmx_pack_device.hip): LigandGraph + priority sort on the device, on torch's current stream.
+    Returns (offsets int64 [n + 1], data uint8 [bytes], status int32 [n]) as device tensors; records byte-identical to
+    `library.pack_features_native`. `out` = (offsets, data, status) tensors to write into (data at least `pack_bound(flat)` long)."""
+    torch = _torch()
+    lib = _ffi.load()
+    dev_index = _device_index(device if device is not None else (flat["positions"].device if isinstance(flat["positions"], torch.Tensor) else None))
+    tdev = torch.device("cuda", dev_index)
+    if not all(isinstance(flat[k], torch.Tensor) and flat[k].is_cuda for k in FEATURE_FIELDS):
+        flat = features_to_device(flat, tdev)
+    n = int(flat["atom_off"].numel()) - 1
+    if out is None:
+        cap = int(bound) if bound is not None else pack_bound(flat)
+        out = (torch.empty(n + 1, dtype=torch.int64, device=tdev), torch.empty(max(cap, 16), dtype=torch.uint8, device=tdev),
+               torch.empty(max(n, 1), dtype=torch.int32, device=tdev))
+    offsets, data, status = out
+    batch = _ffi.FeatureBatch(n, *(flat[k].data_ptr() for k in FEATURE_FIELDS))
+    nbytes = ctypes.c_uint64(0)
+    with torch.cuda.device(tdev):
+        stream = torch.cuda.current_stream(tdev).cuda_stream
+        _ffi.check(lib.pmx_pack_features_device(ctypes.byref(batch), dev_index, ctypes.c_void_p(stream), offsets.data_ptr(), data.data_ptr(), int(data.numel()),
+                                                ctypes.byref(nbytes), status.data_ptr()))
+    return offsets[: n + 1], data[: int(nbytes.value)], status[:n]
 
 
 @dataclass

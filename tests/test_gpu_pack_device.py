@@ -1,0 +1,160 @@
+"""The library packer on the device (`pmx_pack_features_device`, csrc/pmx_pack_device.hip) against the host packer and the records extracted
+from the reference's own `LigandGraph` (tests/golden/*.pmxlib): byte for byte, status for status."""
+
+import ctypes
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_golden
+from test_library import golden_molecules
+
+pytestmark = pytest.mark.gpu
+
+
+def device_pack(flat):
+    from pharmaconet_amd.engine import pack_features_device
+
+    offsets, data, status = pack_features_device(flat)
+    return offsets.cpu().numpy().astype(np.uint64), data.cpu().numpy(), status.cpu().numpy()
+
+
+@pytest.mark.parametrize("name", ["set_6oim_c8", "set_6oim_c1", "set_6oim_c64", "set_c21_c8", "set_s64_c8"])
+def test_device_packer_matches_reference_ligandgraph(name):
+    """The 708 fixture molecules: node merging, dependence, functional groups, hydrophobic flood, cluster order, priority sort
+    (ligand.py:134-259, graph_match.py:43-60) and the float32 tuple centres (ligand.py:293-301)."""
+    from pharmaconet_amd import PackedLibrary
+    from pharmaconet_amd.library import flatten_features
+
+    want = PackedLibrary.load(GOLDEN / f"{name}.pmxlib")
+    offsets, data, status = device_pack(flatten_features(list(golden_molecules(name))))
+    assert np.all(status == 0)
+    np.testing.assert_array_equal(offsets, want.offsets)
+    assert data.tobytes() == want.data.tobytes()
+
+
+def test_device_packer_on_a_tiled_synthetic_batch():
+    """A hundred thousand molecules of the bench generator's kind (distinct geometry per copy): the whole library equal to the host packer's."""
+    import bench
+    from pharmaconet_amd.library import flatten_features, pack_features_native
+    from tools.synthetic import synthetic_library
+
+    mols = []
+    synthetic_library(512, num_conformers=8, seed=5, molecules_out=mols)
+    flat = bench.tile_features(flatten_features(mols), 200, np.random.default_rng(7))
+    want, want_status = pack_features_native(flat, threads=16)
+    offsets, data, status = device_pack(flat)
+    np.testing.assert_array_equal(status, want_status)
+    np.testing.assert_array_equal(offsets, want.offsets)
+    assert data.size == want.data.size and np.array_equal(data, want.data)
+
+
+def test_device_packer_statuses():
+    """1: outside the format's limits (65 nodes; 65 conformers) - 2: malformed (what pmx_pack_features checks per molecule) or a feature graph the
+    reference's builder raises on - 3: outside the device builder's scratch. The neighbours of such a molecule are packed as usual."""
+    from pharmaconet_amd.library import UNSUPPORTED_RECORD, LigandFeatures, flatten_features, pack_features_native, pack_ligand
+
+    n = 70
+    many_nodes = LigandFeatures([17] * n + [6], [[n]] * n + [list(range(n))], [("Halogen", i, i) for i in range(n)], np.zeros((n + 1, 2, 3), np.float32))
+    small = LigandFeatures([6, 17], [[1], [0]], [("Halogen", 1, 1)], np.ones((2, 4, 3), np.float32))
+    many_conf = LigandFeatures([6, 17], [[1], [0]], [("Halogen", 1, 1)], np.ones((2, 65, 3), np.float32))
+    na = 300
+    many_atoms = LigandFeatures([6] * na, [[(i + 1) % na, (i - 1) % na] for i in range(na)], [("Halogen", 1, 1)], np.ones((na, 2, 3), np.float32))
+    long_feature = LigandFeatures([6] * 20, [[(i + 1) % 20, (i - 1) % 20] for i in range(20)], [("Aromatic", tuple(range(17)), tuple(range(17)))], np.ones((20, 2, 3), np.float32))
+    mols = [small, many_nodes, small, many_conf, many_atoms, long_feature, small]
+    flat = flatten_features(mols)
+    offsets, data, status = device_pack(flat)
+    assert status.tolist() == [0, 1, 0, 1, 3, 3, 0]
+    host, host_status = pack_features_native(mols[:4] + [small], threads=2)
+    assert host_status.tolist() == [0, 1, 0, 1, 0]
+    rec = lambda i: data[int(offsets[i]) : int(offsets[i + 1])].tobytes()
+    assert rec(0) == rec(2) == rec(6) == pack_ligand(small)
+    for i in (1, 3, 4, 5):
+        assert rec(i) == UNSUPPORTED_RECORD
+    # malformed input, molecule by molecule (tests/test_library.py's cases)
+    gm = list(golden_molecules("set_6oim_c8"))[:6]
+    good = [bytes(pack_ligand(m)) for m in gm]
+    base = flatten_features(gm)
+    f0 = int(base["feat_off"][2])
+    cases = {
+        "type id": lambda f: f["feat_type"].__setitem__(f0, 9),
+        "atom index": lambda f: f["feat_atoms"].__setitem__(int(f["feat_atom_off"][f0]), 10_000),
+        "negative centre": lambda f: f["feat_centers"].__setitem__(int(f["feat_center_off"][f0]), -1),
+        "neighbour index": lambda f: f["nbr"].__setitem__(int(f["nbr_off"][int(f["atom_off"][2])]), 777),
+        "no conformers": lambda f: f["n_conf"].__setitem__(2, 0),
+        "feature without atoms": lambda f: f["feat_atom_off"].__setitem__(f0 + 1, int(f["feat_atom_off"][f0])),
+    }
+    for name, fn in cases.items():
+        flat = {k: np.array(v, copy=True) for k, v in base.items()}
+        fn(flat)
+        _, hs = pack_features_native(flat, threads=2)
+        assert hs.tolist() == [0, 0, 2, 0, 0, 0], name
+        offsets, data, status = device_pack(flat)
+        assert status.tolist() == [0, 0, 2, 0, 0, 0], name
+        for i in (0, 1, 3, 4, 5):
+            assert data[int(offsets[i]) : int(offsets[i + 1])].tobytes() == good[i], name
+        assert int(offsets[3] - offsets[2]) == 16 and not data[int(offsets[2]) : int(offsets[3])].any()
+
+
+def test_device_packer_on_merged_keys_and_dependences():
+    """Hand-made feature lists on the corners of __add_nodes: an int key and a 1-tuple key are different nodes, equal tuple keys merge their types,
+    an H-bond atom inside an ion group joins the ion's cluster (ligand.py:134-156,303-329), repeated features, unsorted and repeated key atoms."""
+    from pharmaconet_amd.library import LigandFeatures, flatten_features, pack_features_native, pack_ligand
+
+    pos = np.arange(5 * 3 * 3, dtype=np.float32).reshape(5, 3, 3) * 0.37
+    z = [8, 6, 8, 6, 7]
+    nbrs = [[1], [0, 2, 3], [1], [1, 4], [3]]
+    lists = [
+        [("HBond_acceptor", 0, 0), ("HBond_acceptor", (0,), (0,)), ("Anion", (2, 0, 1), (0, 2)), ("HBond_acceptor", 2, 2), ("Cation", 4, 4), ("HBond_donor", 4, 4)],
+        [("Anion", (0, 2, 1), (2, 0)), ("Anion", (0, 2, 1), (2, 0)), ("HBond_acceptor", 0, 0), ("Hydrophobic", 3, 3), ("Hydrophobic", 1, 1), ("Hydrophobic", 3, 3)],
+        [("Hydrophobic", 1, 1), ("Aromatic", (3, 1, 1, 0), (0, 1, 3)), ("Hydrophobic", 3, 3), ("Halogen", 2, 2), ("Hydrophobic", 4, 4)],
+        [],
+    ]
+    mols = [LigandFeatures(z, nbrs, feats, pos) for feats in lists]
+    want, hs = pack_features_native(mols, threads=1)
+    assert [want.record(i) for i in range(len(mols))] == [bytes(pack_ligand(m)) for m in mols]  # (the step-by-step restatement of LigandGraph)
+    offsets, data, status = device_pack(flatten_features(mols))
+    np.testing.assert_array_equal(status, hs)
+    np.testing.assert_array_equal(offsets, want.offsets)
+    assert data.tobytes() == want.data.tobytes()
+
+
+def test_device_packer_sizing_protocol_and_empty_batch():
+    """include/pmx.h: data_out = NULL sizes exactly; a buffer that is too small fails the call with the need in *data_bytes; an empty batch is an empty library."""
+    import torch
+
+    from pharmaconet_amd import PackedLibrary, _ffi
+    from pharmaconet_amd.engine import FEATURE_FIELDS, features_to_device
+    from pharmaconet_amd.library import flatten_features
+
+    want = PackedLibrary.load(GOLDEN / "set_6oim_c8.pmxlib")
+    flat = features_to_device(flatten_features(list(golden_molecules("set_6oim_c8"))))
+    n = len(want)
+    lib = _ffi.load()
+    batch = _ffi.FeatureBatch(n, *(flat[k].data_ptr() for k in FEATURE_FIELDS))
+    offsets = torch.zeros(n + 1, dtype=torch.int64, device="cuda")
+    nbytes = ctypes.c_uint64(0)
+    assert lib.pmx_pack_features_device(ctypes.byref(batch), 0, None, offsets.data_ptr(), None, 0, ctypes.byref(nbytes), None) == 0
+    assert int(nbytes.value) == want.data.size
+    small = torch.zeros(want.data.size - 16, dtype=torch.uint8, device="cuda")
+    assert lib.pmx_pack_features_device(ctypes.byref(batch), 0, None, offsets.data_ptr(), small.data_ptr(), small.numel(), ctypes.byref(nbytes), None) != 0
+    assert int(nbytes.value) == want.data.size and b"too small" in lib.pmx_last_error()
+    empty = _ffi.FeatureBatch(0, *(flat[k].data_ptr() for k in FEATURE_FIELDS))
+    offsets.fill_(7)
+    assert lib.pmx_pack_features_device(ctypes.byref(empty), 0, None, offsets.data_ptr(), small.data_ptr(), small.numel(), ctypes.byref(nbytes), None) == 0
+    torch.cuda.synchronize()
+    assert int(nbytes.value) == 0 and int(offsets[0]) == 0
+
+
+def test_library_from_features_scores_like_the_uploaded_library():
+    """Features -> `DeviceLibrary.from_features` -> screen: the scores of the library uploaded from the host, bit for bit."""
+    from pharmaconet_amd.engine import DeviceLibrary
+    from pharmaconet_amd.library import flatten_features
+
+    model, lib, weights, d = load_golden("set_6oim_c8")
+    dlib = DeviceLibrary.from_features(flatten_features(list(golden_molecules("set_6oim_c8"))))
+    assert len(dlib) == len(lib) and dlib.num_bytes == lib.data.size
+    got = model.screen(dlib, weights=weights).scores.cpu().numpy()
+    want = model.screen(lib, weights=weights).scores.cpu().numpy()
+    np.testing.assert_array_equal(got, want)
+    dlib.close()
