@@ -344,8 +344,8 @@ def end_to_end_overlapped(molecules, pocket, n_lig_target, topk_k, device, share
 
 def end_to_end_device_packed(molecules, pocket, n_lig_target, topk_k, device, shares=(1, 3, 4)):
     """The same pipeline with the packer ON THE DEVICE (`pmx_pack_features_device`): the typed features and conformer coordinates go over PCIe as they are
-    (pinned flat arrays -> HBM on a copy stream, all chunks queued up front), and per chunk the compute stream runs graph builder + record writer + library adoption +
-    `pmx_score` + `pmx_topk`. No host core does more than enqueue. Timed from the first copy enqueued to the merged top-k on the host."""
+    (pinned flat arrays -> HBM on copy streams, chunk i + 1 while chunk i is packed and scored); per chunk a packer stream runs graph builder + record writer, the library adopts their output
+    in place, and a scoring stream runs `pmx_score` + `pmx_topk` - the next chunk is packed while this one is scored. No host core does more than enqueue. Timed from the first copy enqueued to the merged top-k on the host."""
     import torch
 
     from pharmaconet_amd import engine
@@ -379,29 +379,47 @@ def end_to_end_device_packed(molecules, pocket, n_lig_target, topk_k, device, sh
     bounds = [engine.pack_bound({"feat_off": flat["feat_off"][: cn + 1], "n_conf": flat["n_conf"][:cn]}) for cn in chunk_n]
     dev_out = [(torch.empty(cn + 1, dtype=torch.int64, device=device), torch.empty(bd, dtype=torch.uint8, device=device), torch.empty(cn, dtype=torch.int32, device=device))
                for cn, bd in zip(chunk_n, bounds)]
-    copy_stream = torch.cuda.Stream(device)
+    copy_streams = [torch.cuda.Stream(device) for _ in range(2)]
+    pack_stream = torch.cuda.Stream(device)
+    # scoring streams, taken in turn: with two, a chunk's task rounds (low occupancy, 6 ms) run beside the next chunk's ligand kernel (each stream has its own work buffers)
+    score_streams = [torch.cuda.Stream(device) for _ in range(max(1, int(os.environ.get("PMX_BENCH_E2E_SCORE_STREAMS", "1"))))]
     compute = torch.cuda.current_stream(device)
 
     def run():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        arrived = []
-        with torch.cuda.stream(copy_stream):
-            for i in range(n_chunks):
+
+        def enqueue_copy(i):
+            with torch.cuda.stream(copy_streams[i % 2]):
                 for k in FEATURE_FIELDS:
                     dev_in[i][k].copy_(pinned[k][: lengths[i][k]], non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record(copy_stream)
-                arrived.append(ev)
+
+        enqueue_copy(0)
+        t_enq = time.perf_counter() - t0
         tops, libs, pack_bytes = [], [], 0
+        stages = [0.0, 0.0, 0.0, t_enq]  # host time in: waiting for the chunk's copy + the packer call, library adoption (waits for the record writer), scoring (enqueue only), the first copy's enqueue
         for i in range(n_chunks):
-            compute.wait_event(arrived[i])
-            offsets, data, status = engine.pack_features_device(dev_in[i], device, out=dev_out[i])
-            dlib = DeviceLibrary.from_device_buffers(offsets, data, device)
-            res = engine.screen(pocket, dlib, topk=topk_k, index_base=sum(chunk_n[:i]))
+            # The host does the waiting, and a chunk's copy is enqueued when the one before it has arrived: [MI355X] with all copies and their events queued up front and the packer stream
+            # waiting on the events, the first packer kernel started when the LAST copy had ended (streams share hardware queues; a queued marker holds back what is behind it)
+            t1 = time.perf_counter()
+            copy_streams[i % 2].synchronize()
+            if i + 1 < n_chunks:
+                enqueue_copy(i + 1)
+            with torch.cuda.stream(pack_stream):  # the packer runs beside the previous chunk's scoring
+                offsets, data, status = engine.pack_features_device(dev_in[i], device, out=dev_out[i])
+                t2 = time.perf_counter()
+                dlib = DeviceLibrary.from_device_buffers(offsets, data, device, adopt=True)  # (the packer's output buffers, in place; waits for the record writer)
+            t3 = time.perf_counter()
+            with torch.cuda.stream(score_streams[i % len(score_streams)]):
+                res = engine.screen(pocket, dlib, topk=topk_k, index_base=sum(chunk_n[:i]))
+            stages[0] += t2 - t1
+            stages[1] += t3 - t2
+            stages[2] += time.perf_counter() - t3
             tops.append((res.topk_scores, res.topk_indices))
             libs.append(dlib)
             pack_bytes += int(data.numel())
+        for st in score_streams:
+            compute.wait_stream(st)
         top = engine.topk(torch.cat([t[0] for t in tops]), topk_k, indices=torch.cat([t[1] for t in tops]))
         best = top[0].cpu()
         torch.cuda.synchronize()
@@ -410,10 +428,10 @@ def end_to_end_device_packed(molecules, pocket, n_lig_target, topk_k, device, sh
         n_bad = sum(int((o[2] != 0).sum()) for o in dev_out)
         for l in libs:
             l.close()
-        return dt, total_conf, best, pack_bytes, n_bad
+        return dt, total_conf, best, pack_bytes, n_bad, stages
 
     run()  # warm
-    dt, total_conf, best, pack_bytes, n_bad = min((run() for _ in range(3)), key=lambda r: r[0])
+    dt, total_conf, best, pack_bytes, n_bad, stages = min((run() for _ in range(3)), key=lambda r: r[0])
     # the packer's kernels alone, on the largest chunk (already resident)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -428,9 +446,10 @@ def end_to_end_device_packed(molecules, pocket, n_lig_target, topk_k, device, sh
         "device_packed_library_bytes": pack_bytes,
         "device_packed_molecules_not_packed": n_bad,
         "device_packer_molecules_per_s": chunk_n[-1] / (pack_ms / 1e3),
+        "device_packed_host_s_in_pack_adopt_score_calls": stages,
         "device_packed_best_score_of_the_run": float(best[0]),
-        "device_packed_note": "typed features + conformer coordinates (pinned) -> HBM on a copy stream -> pmx_pack_features_device (graph builder + record writer, records byte-identical "
-                              "to the host packer's: tests/test_gpu_pack_device.py) + pmx_library_upload (device-to-device) + pmx_score + pmx_topk on the compute stream, per chunk; "
+        "device_packed_note": "typed features + conformer coordinates (pinned) -> HBM on copy streams -> pmx_pack_features_device (graph builder + record writer, records byte-identical "
+                              "to the host packer's: tests/test_gpu_pack_device.py) on a packer stream + pmx_library_upload (adopting the packer's buffers in place) + pmx_score + pmx_topk on a scoring stream, per chunk, chunk i + 1 packed while chunk i is scored; "
                               "first copy enqueued to merged top-k on the host; best of three",
     }
 

@@ -81,7 +81,10 @@ typedef struct {
     uint64_t n_ligands;
     const uint64_t *offsets; /* [n_ligands + 1] byte offsets into data, each a multiple of 16 */
     const uint8_t *data;
-    int32_t on_device;       /* 0: host pointers (copied to the device); 1: device pointers (copied device-to-device) */
+    int32_t on_device;       /* 0: host pointers (copied to the device); 1: device pointers (copied device-to-device); 2: device pointers, ADOPTED - the library
+                                reads the caller's buffers in place (no allocation, no copy: what pmx_pack_features_device wrote, as it lies); they must
+                                stay valid and unchanged until pmx_library_destroy, which does not free them. A device view must be complete when the call
+                                is made (the call reads it on the default stream). */
 } pmx_library_view;
 
 typedef struct {

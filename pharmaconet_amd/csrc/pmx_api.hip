@@ -462,6 +462,7 @@ struct pmx_library {
     DevLibrary dl;
     uint64_t *offsets;
     uint8_t *data;
+    bool owns; // false: the caller's device buffers, adopted as they are (pmx_library_view.on_device == 2)
     pmx_library_info info;
 };
 
@@ -477,36 +478,51 @@ extern "C" int pmx_library_upload(const pmx_library_view *v, int device, pmx_lib
     } else {
         nbytes = v->offsets[n];
     }
+    const bool adopt = v->on_device == 2;
+    if (adopt && !v->data) return fail(PMX_ERR_INVALID, "null data");
     pmx_library *lib = new pmx_library();
     lib->device = device;
     lib->offsets = nullptr;
     lib->data = nullptr;
-    hipError_t e = hipMalloc((void **)&lib->offsets, (n + 1) * 8);
-    if (e == hipSuccess) e = hipMalloc((void **)&lib->data, std::max<uint64_t>(nbytes, 16));
-    if (e == hipSuccess) e = hipMemcpy(lib->offsets, v->offsets, (n + 1) * 8, kind);
-    if (e == hipSuccess && nbytes) e = hipMemcpy(lib->data, v->data, nbytes, kind);
-    unsigned long long *stats_dev = nullptr;
+    lib->owns = !adopt;
+    hipError_t e = hipSuccess;
+    if (adopt) { // the buffers stay the caller's: no allocation, no copy
+        lib->offsets = const_cast<uint64_t *>(v->offsets);
+        lib->data = const_cast<uint8_t *>(v->data);
+    } else {
+        e = hipMalloc((void **)&lib->offsets, (n + 1) * 8);
+        if (e == hipSuccess) e = hipMalloc((void **)&lib->data, std::max<uint64_t>(nbytes, 16));
+        if (e == hipSuccess) e = hipMemcpy(lib->offsets, v->offsets, (n + 1) * 8, kind);
+        if (e == hipSuccess && nbytes) e = hipMemcpy(lib->data, v->data, nbytes, kind);
+    }
+    // The counters live in one small buffer per device that is never freed: hipFree waits for every stream of the device, and an adopted
+    // library is made while other streams copy and score ([MI355X] the pipeline's scoring calls each started when the NEXT chunk's copy had ended).
+    static std::mutex stats_mu;
+    static unsigned long long *stats_of_device[64] = {};
     unsigned long long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (e == hipSuccess) e = hipMalloc((void **)&stats_dev, sizeof(stats));
-    if (e == hipSuccess) e = hipMemset(stats_dev, 0, sizeof(stats));
     lib->dl.n = n;
     lib->dl.offsets = lib->offsets;
     lib->dl.data = lib->data;
-    if (e == hipSuccess && n) {
-        library_stats_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256)>>>(lib->dl, lib->data, nbytes, stats_dev);
-        e = hipGetLastError();
+    if (e == hipSuccess && (device < 0 || device >= 64)) e = hipErrorInvalidDevice;
+    if (e == hipSuccess) {
+        std::lock_guard<std::mutex> lock(stats_mu);
+        unsigned long long *&stats_dev = stats_of_device[device];
+        if (!stats_dev) e = hipMalloc((void **)&stats_dev, sizeof(stats));
+        if (e == hipSuccess) e = hipMemset(stats_dev, 0, sizeof(stats));
+        if (e == hipSuccess && n) {
+            library_stats_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256)>>>(lib->dl, lib->data, nbytes, stats_dev);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpy(stats, stats_dev, sizeof(stats), hipMemcpyDeviceToHost);
     }
-    if (e == hipSuccess) e = hipMemcpy(stats, stats_dev, sizeof(stats), hipMemcpyDeviceToHost);
-    if (stats_dev) (void)hipFree(stats_dev);
     if (e != hipSuccess) {
-        if (lib->offsets) (void)hipFree(lib->offsets);
-        if (lib->data) (void)hipFree(lib->data);
+        if (lib->owns && lib->offsets) (void)hipFree(lib->offsets);
+        if (lib->owns && lib->data) (void)hipFree(lib->data);
         delete lib;
         return fail(e == hipErrorOutOfMemory ? PMX_ERR_OOM : PMX_ERR_HIP, "library upload failed: %s", hipGetErrorString(e));
     }
     if (stats[5]) { // offsets are validated on the device, for host and device views alike
-        (void)hipFree(lib->offsets);
-        (void)hipFree(lib->data);
+        if (lib->owns) (void)hipFree(lib->offsets), (void)hipFree(lib->data);
         delete lib;
         return fail(PMX_ERR_INVALID, "%llu record offsets are not 16-byte aligned, run backwards or point past the data", stats[5]);
     }
@@ -530,8 +546,7 @@ extern "C" int pmx_library_info_get(const pmx_library *lib, pmx_library_info *in
 extern "C" int pmx_library_destroy(pmx_library *lib) {
     if (!lib) return PMX_OK;
     (void)hipSetDevice(lib->device);
-    (void)hipFree(lib->offsets);
-    (void)hipFree(lib->data);
+    if (lib->owns) (void)hipFree(lib->offsets), (void)hipFree(lib->data);
     delete lib;
     return PMX_OK;
 }

@@ -2,24 +2,25 @@
 //
 // Same input, same records, byte for byte: LigandGraph's node merging, grouping and clustering (src/pmnet/scoring/ligand.py:110-259) and
 // the priority sort of graph_match.py:43-60. The host packer needs 2.7 CPU-seconds per 10^6 molecules; a host that is granted 16 cores'
-// worth of time packs 6 x 10^6 molecules/s at best, a third of what one resident pass scores. Here the packer
-// is two kernels in front of the scoring call, on the same stream:
+// worth of time packs 6 x 10^6 molecules/s sustained, a tenth of what one resident pass scores. Here the packer
+// is four launches in front of the scoring call, on the caller's stream:
 //
-//   graph_kernel   one wavefront per molecule. All lanes check the raw arrays (what valid_molecule checks) and stage the molecule's
-//                  topology into LDS as bytes (atom indices of a molecule fit one); lane 0 then walks the reference's builder step by
-//                  step on LDS arrays of fixed size - the work is a few thousand dependent steps on a few hundred bytes, and the chip
-//                  runs some 3 000 molecules side by side. Out: a 196-byte descriptor (per packed node its type mask and the feature
-//                  whose centres place it; the clusters' ends), the record's size, the status.
+//   graph_wave_kernel  one wavefront per molecule, the wavefront as the data structure (lane f = feature f, lane i = node i, lane c =
+//                      cluster c, atom sets as 128-bit masks): the reference's node-by-node loops become uniform readlane loops against all
+//                      lanes at once; the hydrophobic flood and the cluster assignment stay sequential, as scalar code. Molecules of up to
+//                      64 features, 128 atoms, 512 neighbour entries, 8 atoms per key. Out: a 196-byte descriptor (per packed node its type
+//                      mask and the feature whose centres place it; the clusters' ends), the record's size, the status.
+//   graph_kernel       the molecules the wave builder left: staged into LDS byte arrays, lane 0 walks pack_one (pmx_pack.cpp) step by step.
 //   (exclusive scan of the sizes: hipcub)
-//   record_kernel  one wavefront per molecule writes the record at its offset: header, type masks, cluster ends, and the node
-//                  positions [node][3][C] gathered from the conformer coordinates (tuple centres: float32 sum atom after atom, one
-//                  IEEE division - LigandNode.set_positions, ligand.py:293-301), stores coalesced.
+//   record_kernel      one wavefront per molecule writes the record at its offset: header, type masks, cluster ends, and the node
+//                      positions [node][3][C] gathered from the conformer coordinates (tuple centres: float32 sum atom after atom, one
+//                      IEEE division - LigandNode.set_positions, ligand.py:293-301), stores coalesced.
 //
 // Fixed scratch means limits beyond the format's own: a molecule of more than 256 atoms, 255 features, 1024 neighbour entries,
 // 1024 feature-atom entries or a feature of more than 16 atoms gets status 3 and a header-only record - pack such a batch with
 // pmx_pack_features. (Drug-like molecules are an order of magnitude below every one of them.) One more difference, in the status
-// only: the 65th node ends the walk with status 1 at once, where the host packer would still report 2 if that molecule's feature
-// graph also made the reference's builder raise.
+// only: the general builder ends its walk at the 65th node with status 1, where the host packer would still report 2 if that
+// molecule's feature graph also made the reference's builder raise.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 

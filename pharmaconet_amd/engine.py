@@ -101,12 +101,19 @@ class DeviceLibrary:
         self.num_unsupported = int(info.n_unsupported)
 
     @classmethod
-    def from_device_buffers(cls, offsets, data, device=None) -> "DeviceLibrary":
-        """Adopt (copy) a library already in device memory: `offsets` int64/uint64 [N + 1] and `data` uint8 torch tensors."""
+    def from_device_buffers(cls, offsets, data, device=None, adopt: bool = False) -> "DeviceLibrary":
+        """A library already in device memory: `offsets` int64/uint64 [N + 1] and `data` uint8 torch tensors - copied, or with `adopt` used in
+        place (the tensors are kept alive by the object and must not be written to while it lives)."""
+        torch = _torch()
         lib = _ffi.load()
         self = cls.__new__(cls)
         self.device = _device_index(device if device is not None else offsets.device)
-        view = _ffi.LibraryView(int(offsets.numel()) - 1, offsets.data_ptr(), data.data_ptr(), 1)
+        torch.cuda.current_stream(torch.device("cuda", self.device)).synchronize()  # (pmx_library_upload reads a complete view, on the default stream)
+        if adopt:
+            if not (offsets.is_contiguous() and data.is_contiguous()):
+                raise ValueError("adopted buffers must be contiguous")
+            self._adopted = (offsets, data)
+        view = _ffi.LibraryView(int(offsets.numel()) - 1, offsets.data_ptr(), data.data_ptr(), 2 if adopt else 1)
         handle = ctypes.c_void_p()
         _ffi.check(lib.pmx_library_upload(ctypes.byref(view), self.device, ctypes.byref(handle)))
         self.handle = handle
@@ -129,7 +136,7 @@ class DeviceLibrary:
         offsets, data, status = pack_features_device(flat, device)
         if check and bool((status == 3).any()):
             raise _ffi.PmxError("a molecule exceeds the device packer's fixed scratch (include/pmx.h): use library.pack_features_native for this batch")
-        self = cls.from_device_buffers(offsets, data, device if device is not None else offsets.device)
+        self = cls.from_device_buffers(offsets, data, device if device is not None else offsets.device, adopt=True)
         self.pack_status = status
         return self
 
@@ -140,6 +147,7 @@ class DeviceLibrary:
         if getattr(self, "handle", None):
             _ffi.load().pmx_library_destroy(self.handle)
             self.handle = None
+        self._adopted = None
 
     def __del__(self):
         try:

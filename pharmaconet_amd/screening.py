@@ -48,7 +48,10 @@ def _read_file(path: str):
     return lig.answers, lig.atom_positions
 
 
-def load_library(library: Path, cpus: int) -> tuple[list[str], PackedLibrary]:
+def load_library(library: Path, cpus: int, on_device: bool = False):
+    """(names, library) of a packed library file or of a directory of molecule files (screening.py:63-68). With `on_device` the records of a
+    directory are made on the GPU (`pmx_pack_features_device`) and the library returned is device-resident; the host packer takes the batch if a
+    molecule is beyond the device builder's fixed scratch, and always without `on_device` (library preparation on a host without a GPU)."""
     if library.is_file():
         lib = PackedLibrary.load(library)
         names_file = Path(str(library) + ".names")
@@ -68,7 +71,18 @@ def load_library(library: Path, cpus: int) -> tuple[list[str], PackedLibrary]:
         read = pool.map(_read_file, [str(f) for f in file_list])
     # features (ligand_utils.py:25-184) and records (LigandGraph, ligand.py:110-259) of all molecules at once, in native code
     flat = perceive_batch([a for a, _ in read], [p for _, p in read], threads=cpus)
-    lib, status = pack_features_native(flat, threads=cpus)
+    lib = status = None
+    if on_device:
+        from .engine import DeviceLibrary
+
+        dlib = DeviceLibrary.from_features(flat, check=False)
+        status = dlib.pack_status.cpu().numpy()
+        if (status == 3).any():
+            dlib.close()
+        else:
+            lib = dlib
+    if lib is None:
+        lib, status = pack_features_native(flat, threads=cpus)
     for f, st in zip(file_list, status):
         if st != 0:  # scored by the reference, not by this engine: reported, never silently dropped
             why = "outside the engine's structural limits (include/pmx.h)" if st == 1 else "feature graph the packer does not accept"
@@ -105,7 +119,7 @@ def main(argv=None) -> None:
         Halogen=args.halogen,
         Hydrophobic=args.hydrophobic,
     )
-    names, lib = load_library(Path(args.library_dir), args.cpus)
+    names, lib = load_library(Path(args.library_dir), args.cpus, on_device=True)
     result = model.screen(lib, weights=weight, float64=True)  # (the reference writes the float64 `GraphMatcher.run()` returns)
     write_csv(Path(args.out), names, result.scores.cpu().numpy(), result.status.cpu().numpy())
 

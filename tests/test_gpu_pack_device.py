@@ -158,3 +158,74 @@ def test_library_from_features_scores_like_the_uploaded_library():
     want = model.screen(lib, weights=weights).scores.cpu().numpy()
     np.testing.assert_array_equal(got, want)
     dlib.close()
+
+
+def test_adopted_device_buffers_are_used_in_place():
+    """pmx_library_view.on_device = 2: no copy - the library scores from the caller's buffers and leaves them alone when it is destroyed."""
+    import torch
+
+    from pharmaconet_amd.engine import DeviceLibrary
+
+    model, lib, weights, d = load_golden("set_c21_c8")
+    offsets = torch.from_numpy(lib.offsets.astype(np.int64)).cuda()
+    data = torch.from_numpy(np.ascontiguousarray(lib.data)).cuda()
+    want = model.screen(lib, weights=weights).scores.cpu().numpy()
+    dlib = DeviceLibrary.from_device_buffers(offsets, data, adopt=True)
+    np.testing.assert_array_equal(model.screen(dlib, weights=weights).scores.cpu().numpy(), want)
+    # in place: another record's bytes under the same offsets change the scores
+    first = slice(int(lib.offsets[0]), int(lib.offsets[1]))
+    keep = data[first].clone()
+    data[first.start + 8 + 64 : first.stop] += 1  # (coordinates of ligand 0, beyond its header / type bytes)
+    changed = model.screen(dlib, weights=weights).scores.cpu().numpy()
+    assert np.array_equal(changed[1:], want[1:])
+    data[first] = keep
+    np.testing.assert_array_equal(model.screen(dlib, weights=weights).scores.cpu().numpy(), want)
+    dlib.close()
+    assert np.array_equal(data.cpu().numpy(), lib.data)  # still the caller's, still there
+
+
+def test_screening_packs_a_directory_on_the_device(tmp_path, monkeypatch):
+    """`screening.load_library(..., on_device=True)` (what `main` calls): files read through the (stand-in) toolkit, perception rules on the batch, records made by
+    the device packer - the library the host path makes, resident."""
+    import gzip
+    import json
+    import sys
+
+    import fake_openbabel
+    from pharmaconet_amd import screening
+
+    fake_openbabel.install()  # (`import openbabel` resolves to the stand-in for this test only)
+
+    def uninstall():
+        for name in ("openbabel", "openbabel.pybel", "openbabel.pybel.ob"):
+            sys.modules.pop(name, None)
+
+    with gzip.open(GOLDEN / "perception.json.gz", "rt") as f:
+        golden = json.load(f)
+    picks = [0, 3, 5, 8, 13, 21, 34]
+    for i in picks:
+        (tmp_path / f"mol{i:03d}.sdf").write_text(json.dumps(golden["molecules"][i]))
+
+    class _Pool:  # (the stand-in toolkit lives in this process only)
+        def __init__(self, n):
+            pass
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+        def map(self, fn, items):
+            return [fn(x) for x in items]
+
+    monkeypatch.setattr(screening.multiprocessing, "Pool", _Pool)
+    try:
+        names, host = screening.load_library(tmp_path, cpus=2)
+        names_dev, dlib = screening.load_library(tmp_path, cpus=2, on_device=True)
+    finally:
+        uninstall()
+    assert names == names_dev and len(dlib) == len(host) and dlib.num_bytes == host.data.size
+    offsets, data = dlib._adopted
+    assert np.array_equal(offsets.cpu().numpy().astype(np.uint64), host.offsets) and np.array_equal(data.cpu().numpy(), host.data)
+    dlib.close()

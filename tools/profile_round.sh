@@ -18,6 +18,8 @@ done
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_BRANCH SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES --output-format csv -d $OUT/pmc_SQ -o p -- python $ROOT/bench.py --ligands 200000 --steps 1 --warmup 0 --no-cpu-baseline --no-serial-leg --no-parity-sample > $OUT/pmc_SQ.log 2>&1
 # the shader clock under this load: GRBM_GUI_ACTIVE (summed over the XCDs) over the kernels' time (collect_profiles.py: "clock" of the SQ summary)
 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_GRBM -o p -- python $ROOT/bench.py --ligands 200000 --steps 1 --warmup 0 --no-cpu-baseline --no-serial-leg --no-parity-sample > $OUT/pmc_GRBM.log 2>&1
+# the device packer alone (graph builder + record writer) on 10^6 resident molecules of the bench generator's kind
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/pack -o s -- python $ROOT/tools/pack_device_bench.py --molecules 1000000 --check > $OUT/pack.log 2>&1 </dev/null
 # BASELINE configs[3] (16 pockets, per-GPU shard) and configs[4] (stress model, 64 conformers): the driver-reproducible lines
 # SURVEY.md 8d-2's own library (tools/survey_library.py): the second headline line
 python $ROOT/bench.py --library survey --steps 3 --warmup 1 > $OUT/bench_survey1M.json 2> $OUT/bench_survey1M.err
