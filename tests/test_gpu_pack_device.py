@@ -229,3 +229,14 @@ def test_screening_packs_a_directory_on_the_device(tmp_path, monkeypatch):
     offsets, data = dlib._adopted
     assert np.array_equal(offsets.cpu().numpy().astype(np.uint64), host.offsets) and np.array_equal(data.cpu().numpy(), host.data)
     dlib.close()
+
+
+def test_device_packer_against_the_host_packer_on_random_feature_batches():
+    """Differential soak (tools/fuzz_pack_device.py): random bond graphs, random feature lists with repeated keys, tuple keys of up to 18 atoms, up to 80 features
+    and 300 atoms per molecule - the wave builder, the general builder and the status-3 exit all take part; every status and every byte equal to the host packer's."""
+    from tools import fuzz_pack_device as fz
+
+    for seed in (3, 4):
+        n, n3, n_host_bad, bad = fz.compare(fz.random_batch(np.random.default_rng([seed, 0]), 4000))
+        assert n == 4000 and not bad, bad[:5]
+        assert n3 > 50 and n_host_bad > 10  # (the draw reaches the exits it is meant to reach)
