@@ -702,18 +702,31 @@ __global__ __launch_bounds__(64) void record_kernel(DevBatch b, const PackDesc *
     float *xyz = reinterpret_cast<float *>(out + head4);
     const uint64_t f0 = b.feat_off[i];
     const float *pos = b.positions + b.pos_off[i];
-    const int per_node = 3 * C, total = n * per_node;
-    const int padded = (int)((record_bytes(n, ncl, C) - head4) / 4);
-    for (int e = lane; e < padded; e += 64) {
+    // per packed node, once: where its centre atoms are listed and how many are averaged (1: the position of the first, as it is)
+    __shared__ uint64_t s_first[64];
+    __shared__ uint32_t s_count[64];
+    if (lane < n) {
+        const uint64_t f = f0 + d.feat[lane];
+        const uint64_t c0 = b.feat_center_off[f];
+        s_first[lane] = c0;
+        s_count[lane] = ((b.feat_flags[f] >> 1) & 1) ? (uint32_t)(b.feat_center_off[f + 1] - c0) : 1u;
+    }
+    __syncthreads();
+    const uint32_t per_node = 3u * (uint32_t)C, total = (uint32_t)n * per_node;
+    const uint32_t padded = (uint32_t)((record_bytes(n, ncl, C) - head4) / 4);
+    // exact division of e < 2^16 by per_node <= 192 and by C <= 64: multiply by floor(2^32 / d) + 1, keep the high word (d = 1 has no such multiplier in 32 bits)
+    const uint32_t m_node = 0xFFFFFFFFu / per_node + 1u, m_conf = 0xFFFFFFFFu / (uint32_t)C + 1u;
+    for (uint32_t e = lane; e < padded; e += 64) {
         float v = 0.f;
         if (e < total) {
-            const int p = e / per_node, r = e - p * per_node, dd = r / C, c = r - dd * C;
-            const uint64_t f = f0 + d.feat[p];
-            const uint64_t c0 = b.feat_center_off[f], c1 = b.feat_center_off[f + 1];
-            v = pos[((size_t)b.feat_centers[c0] * C + c) * 3 + dd];
-            if ((b.feat_flags[f] >> 1) & 1) { // float32 mean over the centre atoms, atom after atom, then one division
-                for (uint64_t q = c0 + 1; q < c1; ++q) v = v + pos[((size_t)b.feat_centers[q] * C + c) * 3 + dd];
-                v = __fdiv_rn(v, (float)(c1 - c0));
+            const uint32_t p = __umulhi(e, m_node), r = e - p * per_node, dd = C == 1 ? r : __umulhi(r, m_conf), c = r - dd * (uint32_t)C;
+            const uint64_t c0 = s_first[p];
+            const uint32_t cnt = s_count[p];
+            const size_t at = (size_t)c * 3 + dd;
+            v = pos[(size_t)b.feat_centers[c0] * per_node + at];
+            if (cnt > 1) { // float32 mean over the centre atoms, atom after atom, then one division
+                for (uint32_t q = 1; q < cnt; ++q) v = v + pos[(size_t)b.feat_centers[c0 + q] * per_node + at];
+                v = __fdiv_rn(v, (float)cnt);
             }
         }
         xyz[e] = v;
