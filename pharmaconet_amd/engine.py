@@ -109,6 +109,7 @@ class DeviceLibrary:
         self = cls.__new__(cls)
         self.device = _device_index(device if device is not None else offsets.device)
         torch.cuda.current_stream(torch.device("cuda", self.device)).synchronize()  # (pmx_library_upload reads a complete view, on the default stream)
+        adopt = adopt and data.numel() > 0  # (an empty library has nothing to adopt: torch hands out a null pointer for it)
         if adopt:
             if not (offsets.is_contiguous() and data.is_contiguous()):
                 raise ValueError("adopted buffers must be contiguous")

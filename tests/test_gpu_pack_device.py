@@ -240,3 +240,16 @@ def test_device_packer_against_the_host_packer_on_random_feature_batches():
         n, n3, n_host_bad, bad = fz.compare(fz.random_batch(np.random.default_rng([seed, 0]), 4000))
         assert n == 4000 and not bad, bad[:5]
         assert n3 > 50 and n_host_bad > 10  # (the draw reaches the exits it is meant to reach)
+
+
+def test_library_from_an_empty_feature_batch():
+    """No molecules: an empty resident library that screens to nothing."""
+    from pharmaconet_amd.engine import DeviceLibrary
+    from pharmaconet_amd.library import flatten_features
+
+    model, lib, weights, d = load_golden("set_6oim_c8")
+    dlib = DeviceLibrary.from_features(flatten_features([]))
+    assert len(dlib) == 0 and dlib.num_bytes == 0
+    res = model.screen(dlib, topk=5)
+    assert res.scores.numel() == 0
+    dlib.close()
