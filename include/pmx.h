@@ -220,6 +220,8 @@ int pmx_pack_features(const pmx_feature_batch *batch, int threads, uint64_t *off
  * 8-byte read) before it enqueues the record writer and returns: *data_bytes is the exact size, offsets_out and data_out are
  * complete in stream order. A call with data_out = NULL only sizes (EXACTLY, unlike the host call's bound; the bound
  * sum(((8 + 2 nf + 3 + 12 nf c + 15) & ~15) + 16) over the molecules' feature and conformer counts needs no call at all).
+ * Calls share one set of work buffers per process: they are serialised on the host, and a call made on another stream than the one before
+ * it starts, on the device, behind that call's record writer.
  * status_out as above, plus 3: the molecule is outside the fixed scratch of the device builder (more than 256 atoms, 255 features,
  * 1024 neighbour entries, 1024 feature-atom entries, or a feature of more than 16 atoms) and became a header-only record - pack
  * such a batch with pmx_pack_features. Two differences in reporting, none in records: a molecule whose offsets run backwards is

@@ -743,6 +743,9 @@ struct PackWork {
     int device = -1;
     void *desc = nullptr, *sizes = nullptr, *scan = nullptr, *status = nullptr;
     size_t desc_bytes = 0, sizes_bytes = 0, scan_bytes = 0, status_bytes = 0;
+    hipEvent_t done = nullptr;     // behind the last call's record writer (it reads `desc` after the call has returned)
+    hipStream_t last = nullptr;    // the stream that call was made on
+    bool pending = false;
 };
 PackWork g_work;
 
@@ -779,8 +782,15 @@ extern "C" int pmx_pack_features_device(const pmx_feature_batch *b, int device, 
         }
         g_work.desc = g_work.sizes = g_work.scan = g_work.status = nullptr;
         g_work.desc_bytes = g_work.sizes_bytes = g_work.scan_bytes = g_work.status_bytes = 0;
+        if (g_work.done) (void)hipEventDestroy(g_work.done);
+        g_work.done = nullptr;
+        g_work.pending = false;
         g_work.device = device;
     }
+    // The buffers are shared by all calls: one made on another stream than the last starts behind that call's record writer.
+    if (!g_work.done && hipEventCreateWithFlags(&g_work.done, hipEventDisableTiming) != hipSuccess) return pmx_topk_fail(PMX_ERR_HIP, "pmx_pack_features_device: hipEventCreate failed");
+    if (g_work.pending && g_work.last != stream && hipStreamWaitEvent(stream, g_work.done, 0) != hipSuccess)
+        return pmx_topk_fail(PMX_ERR_HIP, "pmx_pack_features_device: hipStreamWaitEvent failed");
     size_t scan_need = 0;
     (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_need, (const uint64_t *)nullptr, (uint64_t *)nullptr, (int)n, stream);
     if (!grow(&g_work.desc, &g_work.desc_bytes, n * sizeof(PackDesc)) || !grow(&g_work.sizes, &g_work.sizes_bytes, n * 8) ||
@@ -808,6 +818,9 @@ extern "C" int pmx_pack_features_device(const pmx_feature_batch *b, int device, 
     if (total > data_cap) return pmx_topk_fail(PMX_ERR_INVALID, "data_out too small (data_bytes holds the size needed)");
     record_kernel<<<dim3((unsigned)n), dim3(64), 0, stream>>>(d, desc, offsets_out_dev, data_out_dev);
     e = hipGetLastError();
+    if (e == hipSuccess) e = hipEventRecord(g_work.done, stream);
     if (e != hipSuccess) return pmx_topk_fail(PMX_ERR_HIP, hipGetErrorString(e));
+    g_work.last = stream;
+    g_work.pending = true;
     return PMX_OK;
 }

@@ -253,3 +253,31 @@ def test_library_from_an_empty_feature_batch():
     res = model.screen(dlib, topk=5)
     assert res.scores.numel() == 0
     dlib.close()
+
+
+def test_device_packer_calls_on_two_streams_do_not_share_descriptors():
+    """The packer's work buffers are shared by all calls: a call on a second stream, made while the first call's record writer may still run, has to leave that one's records alone."""
+    import torch
+
+    import bench
+    from pharmaconet_amd.engine import features_to_device, pack_bound, pack_features_device
+    from pharmaconet_amd.library import flatten_features, pack_features_native
+    from tools.synthetic import synthetic_library
+
+    mols = []
+    synthetic_library(256, num_conformers=8, seed=5, molecules_out=mols)
+    big = bench.tile_features(flatten_features(mols), 400, np.random.default_rng(3))
+    small = flatten_features(list(golden_molecules("set_c21_c8")))
+    want_big, _ = pack_features_native(big, threads=16)
+    want_small, _ = pack_features_native(small, threads=2)
+    dev_big, dev_small = features_to_device(big), features_to_device(small)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    for _ in range(3):
+        with torch.cuda.stream(streams[0]):
+            o1, d1, s1 = pack_features_device(dev_big, bound=pack_bound(big))
+        with torch.cuda.stream(streams[1]):
+            o2, d2, s2 = pack_features_device(dev_small, bound=pack_bound(small))
+        torch.cuda.synchronize()
+        assert np.array_equal(d1.cpu().numpy(), want_big.data) and np.array_equal(o1.cpu().numpy().astype(np.uint64), want_big.offsets)
+        assert np.array_equal(d2.cpu().numpy(), want_small.data) and np.array_equal(o2.cpu().numpy().astype(np.uint64), want_small.offsets)
