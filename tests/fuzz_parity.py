@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised parity soak (GPU box): models x conformer counts x type weights drawn at random, SURVEY 8d-2-style ligands drawn on the model's own nodes,
-the GPU's scores against the CPU oracle's at the parity tests' tolerance. `python tools/fuzz_parity.py [rounds] [ligands]`."""
+the GPU's scores against the CPU oracle's at the parity tests' tolerance. `python tests/fuzz_parity.py [rounds] [ligands]` (it lives under tests/: only tests, smoke() and bench.py's checker legs may call the oracle)."""
 import json
 import sys
 import time
