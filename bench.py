@@ -343,22 +343,23 @@ def end_to_end_overlapped(molecules, pocket, n_lig_target, topk_k, device, share
 
 
 def end_to_end_device_packed(molecules, pocket, n_lig_target, topk_k, device, shares=(1, 3, 4)):
-    """The same pipeline with the packer ON THE DEVICE (`pmx_pack_features_device`): the typed features and conformer coordinates go over PCIe as they are
-    (pinned flat arrays -> HBM on copy streams, chunk i + 1 while chunk i is packed and scored); per chunk a packer stream runs graph builder + record writer, the library adopts their output
-    in place, and a scoring stream runs `pmx_score` + `pmx_topk` - the next chunk is packed while this one is scored. No host core does more than enqueue. Timed from the first copy enqueued to the merged top-k on the host."""
+    """The same pipeline with the packer ON THE DEVICE - the product's `pharmaconet_amd.pipeline.screen_feature_batches`: the typed features and conformer coordinates
+    go over PCIe as they are (pinned flat arrays -> HBM on copy streams, chunk i + 1 while chunk i is packed and scored); per chunk a packer stream runs graph builder + record
+    writer (`pmx_pack_features_device`), the library adopts their output in place, and a scoring stream runs `pmx_score` + `pmx_topk`. No host core does more than enqueue.
+    Timed from the first copy enqueued to the merged top-k on the host."""
     import torch
 
-    from pharmaconet_amd import engine
-    from pharmaconet_amd.engine import FEATURE_FIELDS, DeviceLibrary
+    from pharmaconet_amd import engine, pipeline
+    from pharmaconet_amd.engine import FEATURE_FIELDS
     from pharmaconet_amd.library import flatten_features
 
     if os.environ.get("PMX_BENCH_E2E_SHARES"):
         shares = tuple(int(x) for x in os.environ["PMX_BENCH_E2E_SHARES"].split(","))
     total_reps = max(len(shares), n_lig_target // len(molecules))
     chunk_reps = [max(1, total_reps * sh // sum(shares)) for sh in shares]
-    n_chunks = len(chunk_reps)
     flat = tile_features(flatten_features(molecules), max(chunk_reps), np.random.default_rng(12345))
     chunk_n = [r_ * len(molecules) for r_ in chunk_reps]
+
     # what a chunk of cn molecules takes of each flat array (prefixes: the flat layout's offsets are prefix-compatible)
     def prefix_lengths(cn):
         ln = {"atom_off": cn + 1, "feat_off": cn + 1, "pos_off": cn + 1, "n_conf": cn}
@@ -368,89 +369,43 @@ def end_to_end_device_packed(molecules, pocket, n_lig_target, topk_k, device, sh
                   positions=int(flat["pos_off"][cn]))
         return ln
 
-    pinned = {}
-    for k in FEATURE_FIELDS:
-        a = np.ascontiguousarray(flat[k])
-        t = torch.from_numpy(a.view(np.int64) if a.dtype == np.uint64 else a)
-        pinned[k] = t.pin_memory()
+    pinned = pipeline.pin_features(flat)
     lengths = [prefix_lengths(cn) for cn in chunk_n]
     raw_bytes = [sum(ln[k] * pinned[k].element_size() for k in FEATURE_FIELDS) for ln in lengths]
-    dev_in = [{k: torch.empty(ln[k], dtype=pinned[k].dtype, device=device) for k in FEATURE_FIELDS} for ln in lengths]
-    bounds = [engine.pack_bound({"feat_off": flat["feat_off"][: cn + 1], "n_conf": flat["n_conf"][:cn]}) for cn in chunk_n]
-    dev_out = [(torch.empty(cn + 1, dtype=torch.int64, device=device), torch.empty(bd, dtype=torch.uint8, device=device), torch.empty(cn, dtype=torch.int32, device=device))
-               for cn, bd in zip(chunk_n, bounds)]
-    copy_streams = [torch.cuda.Stream(device) for _ in range(2)]
-    pack_stream = torch.cuda.Stream(device)
-    # scoring streams, taken in turn: with two, a chunk's task rounds (low occupancy, 6 ms) run beside the next chunk's ligand kernel (each stream has its own work buffers)
-    score_streams = [torch.cuda.Stream(device) for _ in range(max(1, int(os.environ.get("PMX_BENCH_E2E_SCORE_STREAMS", "1"))))]
-    compute = torch.cuda.current_stream(device)
+    batches = [{k: pinned[k][: ln[k]] for k in FEATURE_FIELDS} for ln in lengths]
 
     def run():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-
-        def enqueue_copy(i):
-            with torch.cuda.stream(copy_streams[i % 2]):
-                for k in FEATURE_FIELDS:
-                    dev_in[i][k].copy_(pinned[k][: lengths[i][k]], non_blocking=True)
-
-        enqueue_copy(0)
-        t_enq = time.perf_counter() - t0
-        tops, libs, pack_bytes = [], [], 0
-        stages = [0.0, 0.0, 0.0, t_enq]  # host time in: waiting for the chunk's copy + the packer call, library adoption (waits for the record writer), scoring (enqueue only), the first copy's enqueue
-        for i in range(n_chunks):
-            # The host does the waiting, and a chunk's copy is enqueued when the one before it has arrived: [MI355X] with all copies and their events queued up front and the packer stream
-            # waiting on the events, the first packer kernel started when the LAST copy had ended (streams share hardware queues; a queued marker holds back what is behind it)
-            t1 = time.perf_counter()
-            copy_streams[i % 2].synchronize()
-            if i + 1 < n_chunks:
-                enqueue_copy(i + 1)
-            with torch.cuda.stream(pack_stream):  # the packer runs beside the previous chunk's scoring
-                offsets, data, status = engine.pack_features_device(dev_in[i], device, out=dev_out[i])
-                t2 = time.perf_counter()
-                dlib = DeviceLibrary.from_device_buffers(offsets, data, device, adopt=True)  # (the packer's output buffers, in place; waits for the record writer)
-            t3 = time.perf_counter()
-            with torch.cuda.stream(score_streams[i % len(score_streams)]):
-                res = engine.screen(pocket, dlib, topk=topk_k, index_base=sum(chunk_n[:i]))
-            stages[0] += t2 - t1
-            stages[1] += t3 - t2
-            stages[2] += time.perf_counter() - t3
-            tops.append((res.topk_scores, res.topk_indices))
-            libs.append(dlib)
-            pack_bytes += int(data.numel())
-        for st in score_streams:
-            compute.wait_stream(st)
-        top = engine.topk(torch.cat([t[0] for t in tops]), topk_k, indices=torch.cat([t[1] for t in tops]))
-        best = top[0].cpu()
+        res = pipeline.screen_feature_batches(pocket, batches, topk_k, device=device)
+        best = res.topk_scores.cpu()
         torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        total_conf = sum(l.total_conformers for l in libs)
-        n_bad = sum(int((o[2] != 0).sum()) for o in dev_out)
-        for l in libs:
-            l.close()
-        return dt, total_conf, best, pack_bytes, n_bad, stages
+        return time.perf_counter() - t0, res, best
 
-    run()  # warm
-    dt, total_conf, best, pack_bytes, n_bad, stages = min((run() for _ in range(3)), key=lambda r: r[0])
-    # the packer's kernels alone, on the largest chunk (already resident)
+    run()  # warm: torch's pools hold the buffers, the scoring stream its workspace
+    dt, res, best = min((run() for _ in range(3)), key=lambda r: r[0])
+    # the packer's kernels alone, on the largest chunk, resident
+    dev_in = engine.features_to_device(batches[-1], device)
+    bound = engine.pack_bound(batches[-1])
+    engine.pack_features_device(dev_in, device, bound=bound)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    engine.pack_features_device(dev_in[-1], device, out=dev_out[-1])
+    engine.pack_features_device(dev_in, device, bound=bound)
     torch.cuda.synchronize()
     pack_ms = (time.perf_counter() - t0) * 1e3
     return {
-        "device_packed_ligand_conformers_per_s": total_conf / dt,
+        "device_packed_ligand_conformers_per_s": res.num_conformers / dt,
         "device_packed_s": dt,
-        "device_packed_chunks": chunk_n,
+        "device_packed_chunks": res.batch_sizes,
         "device_packed_feature_bytes_over_pcie": sum(raw_bytes),
-        "device_packed_library_bytes": pack_bytes,
-        "device_packed_molecules_not_packed": n_bad,
+        "device_packed_library_bytes": res.library_bytes,
+        "device_packed_molecules_not_packed": res.num_unsupported,
+        "device_packed_batches_packed_on_host": res.batches_packed_on_host,
         "device_packer_molecules_per_s": chunk_n[-1] / (pack_ms / 1e3),
-        "device_packed_host_s_in_pack_adopt_score_calls": stages,
         "device_packed_best_score_of_the_run": float(best[0]),
-        "device_packed_note": "typed features + conformer coordinates (pinned) -> HBM on copy streams -> pmx_pack_features_device (graph builder + record writer, records byte-identical "
-                              "to the host packer's: tests/test_gpu_pack_device.py) on a packer stream + pmx_library_upload (adopting the packer's buffers in place) + pmx_score + pmx_topk on a scoring stream, per chunk, chunk i + 1 packed while chunk i is scored; "
-                              "first copy enqueued to merged top-k on the host; best of three",
+        "device_packed_note": "pharmaconet_amd.pipeline.screen_feature_batches: typed features + conformer coordinates (pinned) -> HBM on copy streams -> pmx_pack_features_device (graph builder + record "
+                              "writer, records byte-identical to the host packer's: tests/test_gpu_pack_device.py) on a packer stream + pmx_library_upload (adopting the packer's buffers in place) + "
+                              "pmx_score + pmx_topk on a scoring stream, per chunk, chunk i + 1 packed while chunk i is scored; first copy enqueued to merged top-k on the host; best of three",
     }
 
 

@@ -10,8 +10,6 @@ e=d["end_to_end"]
 print(sys.argv[1], round(d["ms_per_step"],2), "host-packed", round(e.get("overlapped_ligand_conformers_per_s",0)/1e6,2), "device-packed", round(e.get("device_packed_ligand_conformers_per_s",0)/1e6,2), e.get("device_packed_s"), e.get("device_packed_chunks"), [round(x, 4) for x in e.get("device_packed_host_s_in_pack_adopt_score_calls", [])], e.get("error"))
 PY
 }
-run s134 PMX_BENCH_E2E_SHARES=1,3,4
-run s17 PMX_BENCH_E2E_SHARES=1,7
-run s115 PMX_BENCH_E2E_SHARES=1,15
-run s1412 PMX_BENCH_E2E_SHARES=1,4,12
-run s125 PMX_BENCH_E2E_SHARES=1,2,5
+run a PMX_BENCH_E2E_SHARES=1,3,4
+run b PMX_BENCH_E2E_SHARES=1,3,4
+run c PMX_BENCH_E2E_SHARES=1,2,5
