@@ -38,6 +38,8 @@ class PipelineResult:
     batches_packed_on_host: int = 0
     library_bytes: int = 0         # packed records made (all of them resident until the call returns)
     batch_sizes: list = field(default_factory=list)
+    scores: "object | None" = None  # with keep_scores: torch.float32 [num_ligands] on the device, in the order the molecules came (NaN: not scored)
+    status: "object | None" = None  # with keep_scores: torch.int32 [num_ligands], PMX_LIGAND_* per molecule
 
     def ranking(self) -> list[tuple[int, float]]:
         idx, sc = self.topk_indices.cpu().numpy(), self.topk_scores.cpu().numpy()
@@ -73,19 +75,21 @@ def _host_numpy(flat) -> dict:
     return out
 
 
-def screen_feature_batches(model, batches: Iterable[dict], topk: int, weights: dict[str, float] | None = None, device=None, host_threads: int = 16) -> PipelineResult:
+def screen_feature_batches(model, batches: Iterable[dict], topk: int, weights: dict[str, float] | None = None, device=None, host_threads: int = 16,
+                           keep_scores: bool = False) -> PipelineResult:
     """Score every molecule of `batches` (an iterable of feature batches: dicts of NumPy arrays or - faster - of pinned host tensors, see
     `pin_features`) against `model` and return the `topk` best of all of them. Batch sizes are the caller's: a small first batch starts the GPU
     early, large later ones amortise the scoring call's fixed tail (bench.py uses 1 : 3 : 4). The packed records of all batches stay in device memory until the
-    call returns (a 10^6-ligand library of 8 conformers: 1.7 GB, twice that reserved); a library beyond the device's memory is screened in several calls."""
+    call returns (a 10^6-ligand library of 8 conformers: 1.7 GB, twice that reserved); a library beyond the device's memory is screened in several calls.
+    `keep_scores`: every molecule's score and status come back as well (what a CSV of the whole library, `screening.py:70-75`, is written from)."""
     import torch
 
     tdev = torch.device("cuda", engine._device_index(device))
     with torch.cuda.device(tdev):
-        return _run(model, iter(batches), int(topk), weights, tdev, int(host_threads))
+        return _run(model, iter(batches), int(topk), weights, tdev, int(host_threads), bool(keep_scores))
 
 
-def _run(model, it, topk, weights, tdev, host_threads):
+def _run(model, it, topk, weights, tdev, host_threads, keep_scores):
     import torch
 
     from .library import pack_features_native
@@ -153,6 +157,9 @@ def _run(model, it, topk, weights, tdev, host_threads):
     else:
         res.topk_scores = torch.full((topk,), float("-inf"), dtype=torch.float32, device=tdev)
         res.topk_indices = torch.full((topk,), -1, dtype=torch.int64, device=tdev)
+    if keep_scores:
+        res.scores = torch.cat([o.scores for _, o in in_flight]) if in_flight else torch.empty(0, dtype=torch.float32, device=tdev)
+        res.status = torch.cat([o.status for _, o in in_flight]) if in_flight else torch.empty(0, dtype=torch.int32, device=tdev)
     main.synchronize()
     for dlib, _ in in_flight:
         dlib.close()

@@ -35,7 +35,11 @@ def test_pipeline_equals_one_pass_over_the_packed_library(name):
         assert res.library_bytes == lib.data.size
         np.testing.assert_array_equal(res.topk_indices.cpu().numpy(), want_i)
         np.testing.assert_array_equal(res.topk_scores.cpu().numpy(), want_s)
-    assert [i for i, _ in res.ranking()] == want_i.tolist()
+    assert [i for i, _ in res.ranking()] == want_i.tolist() and res.scores is None
+    full = screen_feature_batches(model, batches, 25, weights=weights, keep_scores=True)
+    one_pass = model.screen(lib, weights=weights)
+    np.testing.assert_array_equal(full.scores.cpu().numpy(), one_pass.scores.cpu().numpy())
+    np.testing.assert_array_equal(full.status.cpu().numpy(), one_pass.status.cpu().numpy())
 
 
 def test_pipeline_hands_a_batch_with_an_oversized_molecule_to_the_host_packer():
